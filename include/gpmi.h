@@ -1,0 +1,155 @@
+/* gpmi.h — C ABI of libgpmi.so: MI355X-native exact-GP fit / predict.
+ *
+ * This is the drop-in boundary for ONE hot path of STOR-i/GaussianProcesses.jl:
+ *   GPE.update_mll!  (cov! -> nugget -> Cholesky -> alpha -> logdet -> mll)
+ *   predict_f        (cross-cov -> whiten -> mean / variance)
+ * The reference has no FFI; its seam is Julia dispatch on CovarianceStrategy /
+ * AbstractPDMat (src/GP.jl:10-20).  Each entry point below names the reference
+ * code it replaces (paths relative to the reference repository root); the
+ * Julia-side binding that calls them is shown in INTEGRATION.md and
+ * gaussianprocesses.jl_amd/julia/GPMI355X.jl.
+ *
+ * Conventions
+ *   - Every matrix is column-major as Julia passes it.  `x` is d x n (one
+ *     observation per column, src/GPE.jl:41) == a C row-major n x d array.
+ *   - Return codes: GPMI_OK; GPMI_ENOTPD (-> LinearAlgebra.PosDefException(info),
+ *     src/GP.jl:110, caught by src/optimize.jl:56-58,81-83); GPMI_EARG
+ *     (-> ArgumentError, src/GPE.jl:42,129, src/GP.jl:65,103,
+ *     src/kernels/kernels.jl:34,41,62,64); GPMI_EDEVICE (-> ErrorException with
+ *     gpmi_last_error()).  After any non-zero return the handle stays usable.
+ *   - The caller owns every host pointer; nothing is retained past return.
+ *     Device memory belongs to the handle (Julia: finalizer -> gpmi_gp_destroy).
+ *   - Calls are synchronous: results are on the host when a call returns.
+ *   - dtype 64 = IEEE double end to end (the reference's only precision,
+ *     src/GP.jl:14-20); dtype 32 = float storage/arithmetic with fp64
+ *     reductions (no reference counterpart; parity is rtol 1e-2 vs fp64).
+ *   - There is NO CPU backend: without a gfx950 device gpmi_ctx_create fails.
+ */
+#ifndef GPMI_H
+#define GPMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPMI_OK 0
+#define GPMI_ENOTPD 1
+#define GPMI_EARG 2
+#define GPMI_EDEVICE 3
+
+#define GPMI_MAX_OPS 32     /* nodes in a kernel tree            */
+#define GPMI_MAX_PARAMS 160 /* stored kernel parameters, total   */
+#define GPMI_MAX_DIMS 160   /* masked active-dim entries, total  */
+
+/* Kernel-tree node codes.  A kernel is a POSTFIX program over these. */
+enum gpmi_op {
+    GPMI_K_SE_ISO = 1,     /* src/kernels/se_iso.jl:39     s2*exp(-0.5*r/l2),   r = sq-euclid        params [l2, s2]        */
+    GPMI_K_SE_ARD = 2,     /* src/kernels/se_ard.jl:43     s2*exp(-r/2),        r = weighted sq      params [il2[nd], s2]   */
+    GPMI_K_MAT12_ISO = 3,  /* src/kernels/mat12_iso.jl:41  s2*exp(-r/l),        r = euclid           params [l, s2]         */
+    GPMI_K_MAT12_ARD = 4,  /* src/kernels/mat12_ard.jl:43  s2*exp(-r),          r = weighted euclid  params [il2[nd], s2]   */
+    GPMI_K_MAT32_ISO = 5,  /* src/kernels/mat32_iso.jl:41  s=sqrt3 r/l; s2(1+s)e^-s                  params [l, s2]         */
+    GPMI_K_MAT32_ARD = 6,  /* src/kernels/mat32_ard.jl:43  s=sqrt3 r                                 params [il2[nd], s2]   */
+    GPMI_K_MAT52_ISO = 7,  /* src/kernels/mat52_iso.jl:40  s=sqrt5 r/l; s2(1+s+s^2/3)e^-s            params [l, s2]         */
+    GPMI_K_MAT52_ARD = 8,  /* src/kernels/mat52_ard.jl:43  s=sqrt5 r                                 params [il2[nd], s2]   */
+    GPMI_K_RQ_ISO = 9,     /* src/kernels/rq_iso.jl:44     s2*(1+r/(2 a l2))^-a                      params [l2, s2, a]     */
+    GPMI_K_RQ_ARD = 10,    /* src/kernels/rq_ard.jl:47     s2*(1+0.5 r/a)^-a                         params [il2[nd], s2, a]*/
+    GPMI_K_NOISE = 11,     /* src/kernels/noise.jl:29-39   s2*[all_z x_z ~= y_z]  (isapprox, rtol sqrt(eps)) params [s2]    */
+    GPMI_K_CONST = 12,     /* src/kernels/const.jl:36      s2                                        params [s2]            */
+    GPMI_K_SUM = 100,      /* src/kernels/sum_kernel.jl:15  pops right, left; pushes left+right                             */
+    GPMI_K_PROD = 101      /* src/kernels/prod_kernel.jl:14 pops right, left; pushes left*right                             */
+};
+
+/* Flattened kernel tree (what a Julia `Kernel` serialises to).
+ *   ops[n_ops]          postfix program (leaves push, SUM/PROD combine).
+ *   dims_off[n_ops+1]   leaf i acts on input rows dims[dims_off[i] .. dims_off[i+1])
+ *                       (0-based; this is how Masked, src/kernels/masked_kernel.jl:44-49,
+ *                       is expressed).  An EMPTY range means "all d rows".  FixedKernel
+ *                       (fixed_kernel.jl:69) does not change cov and needs no encoding.
+ *   params[n_params]    the kernels' STORED (transformed) fields in program order,
+ *                       exactly the struct fields of the reference types (l2 | l |
+ *                       il2[], s2, a) so host and device evaluate the same expression.
+ *                       nd = size of the leaf's active-dim range (d when empty). */
+typedef struct gpmi_kernel {
+    int32_t n_ops;
+    const int32_t* ops;
+    const int32_t* dims_off;
+    const int32_t* dims;
+    const double* params;
+    int32_t n_params;
+} gpmi_kernel;
+
+typedef struct gpmi_ctx gpmi_ctx; /* one per process: device(s), streams, error text */
+typedef struct gpmi_gp gpmi_gp;   /* one per GPE: resident x, factor, alpha          */
+
+/* ---- context ---------------------------------------------------------- */
+/* n_devices == 1: one process drives one GPU (multi-GPU runs are one process
+ * per GPU).  device_ids may be NULL (-> device 0).            */
+int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out);
+void gpmi_ctx_destroy(gpmi_ctx*);
+const char* gpmi_last_error(gpmi_ctx*);
+const char* gpmi_version(void);
+
+/* ---- model object: replaces alloc_cK (src/GP.jl:14-20) + KernelData ----- */
+/* Copies x (d x n col-major, element type given by dtype) to the device and
+ * allocates ONE n x n factor buffer (the reference keeps two, GP.jl:16-17).   */
+int gpmi_gp_create(gpmi_ctx*, int dtype /*64|32*/, int d, int64_t n, const void* x, gpmi_gp** out);
+void gpmi_gp_destroy(gpmi_gp*);
+
+/* ---- fit: replaces update_cK! + update_mll! (src/GPE.jl:169-212) and
+ *      make_posdef! (src/GP.jl:101-112) -------------------------------------
+ * log_noise: n_noise == 1 -> scalar logNoise (nugget exp(2 logNoise), GPE.jl:173)
+ *            n_noise == n -> heteroscedastic vector (GPE.jl:177-186).
+ * y_minus_mu: y - mean(m, x) (GPE.jl:206-207; the mean stays on the host).
+ * mll_out:   -(y'alpha + logdet + n log 2pi)/2  (GPE.jl:210), always double.
+ * alpha_out: n elements of dtype, may be NULL.
+ * info_out:  0, or the 1-based failing pivot when GPMI_ENOTPD is returned.    */
+int gpmi_fit(gpmi_gp*, const gpmi_kernel*, const double* log_noise, int64_t n_noise,
+             const void* y_minus_mu, double* mll_out, void* alpha_out, int64_t* info_out);
+
+/* ---- predict: replaces predict_f / predictMVN (src/GP.jl:25-84) ----------
+ * xpred: d x p col-major.  mean_pred: mean(m, xpred), p elements.
+ * full_cov == 0: var_out[p] = max(k(x*,x*) - |L^-1 k*|^2, 0)   (GP.jl:69-77, batched)
+ * full_cov != 0: var_out[p x p] = Kpred - (L^-1 K*)'(L^-1 K*), no clamp (GP.jl:25-30,51-54) */
+int gpmi_predict(gpmi_gp*, const gpmi_kernel*, int64_t p, const void* xpred, const void* mean_pred,
+                 int full_cov, void* mu_out, void* var_out);
+
+/* ---- cov: replaces cov / cov! (src/kernels/kernels.jl:31-71) -------------
+ * out is n1 x n2 col-major; x2 == NULL selects the symmetric X1 === X2 form. */
+int gpmi_cov(gpmi_ctx*, const gpmi_kernel*, int dtype, int d, int64_t n1, const void* x1,
+             int64_t n2, const void* x2, void* out);
+
+/* ---- AbstractPDMat surface of the fitted factor (PDMats `\`, whiten!, logdet;
+ *      src/GPE.jl:208,210, src/GP.jl:27,136, src/GPE.jl:162) ----------------
+ * b_inout is n x nrhs col-major, overwritten with the result.               */
+int gpmi_solve(gpmi_gp*, int64_t nrhs, void* b_inout);  /* (K + noise)^-1 b     */
+int gpmi_whiten(gpmi_gp*, int64_t nrhs, void* b_inout); /* L^-1 b,  L = U'      */
+int gpmi_logdet(gpmi_gp*, double* out);                 /* 2 sum log U_ii       */
+/* U_out: n x n col-major with the upper factor in its upper triangle and zeros
+ * below (== Cholesky(factors,'U',0), src/GPE.jl:60).                        */
+int gpmi_factor_to_host(gpmi_gp*, void* U_out);
+
+/* ---- measurement hooks (bench.py; no reference counterpart) --------------
+ * When enabled, every launch of a profiled kernel class is bracketed by HIP
+ * events on the stream it is launched on.  gpmi_profile_get drains them.    */
+enum gpmi_prof_class {
+    GPMI_PROF_SYRK = 0,  /* Cholesky trailing update (MFMA)        */
+    GPMI_PROF_COV = 1,   /* covariance assembly                    */
+    GPMI_PROF_PANEL = 2, /* potf2 + trsm + in-panel update         */
+    GPMI_PROF_SOLVE = 3, /* alpha solves, logdet                   */
+    GPMI_PROF_PREDICT = 4,
+    GPMI_PROF_NCLASS = 5
+};
+int gpmi_profile_enable(gpmi_ctx*, int on);
+/* launches, total milliseconds and algorithmic work (flops for SYRK/PANEL/
+ * PREDICT, bytes for COV/SOLVE) accumulated since the last call for `cls`.  */
+int gpmi_profile_get(gpmi_ctx*, int cls, int64_t* launches, double* total_ms, double* work);
+/* Peak-rate micro-benchmark of v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32:
+ * returns measured TFLOP/s with every SIMD issuing back-to-back MFMAs.      */
+int gpmi_mfma_peak(gpmi_ctx*, int dtype, double* tflops_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPMI_H */

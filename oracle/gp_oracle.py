@@ -1,0 +1,380 @@
+"""CPU oracle for the GaussianProcesses.jl exact-GP fit/predict path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is part of the product:
+only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import it, and only as the checker / reported baseline.  The
+product path (``gaussianprocesses.jl_amd/``) never imports this module and has
+no CPU fallback.
+
+PARITY PINNING.  The reference (Julia) cannot be executed in the build
+container and its test-suite holds **no stored numeric golden for the exact
+path** (SURVEY.md §8c).  This restatement is therefore pinned by
+  (i)  the relational properties the reference tests assert (tests/test_oracle.py
+       mirrors test/kernels.jl:39-41,55-60, test/gp.jl:47-53),
+  (ii) an independent implementation of the same mathematics (scikit-learn's
+       GaussianProcessRegressor, tests/test_oracle.py::test_vs_sklearn_*), and
+  (iii) closed forms for N = 1, 2.
+There are no reference-produced outputs to compare with: *parity unpinned by
+reference outputs* (see DESIGN.md).
+
+Every function cites the reference file:line it follows (paths relative to
+/root/reference).  Arrays use the reference orientation: ``x`` is ``d × N``
+(one observation per COLUMN, src/GPE.jl:41).
+
+Kernel *specs* are nested tuples (0-based ``active_dims``; the reference is
+1-based):
+
+    ("se_iso", ll, lsig)            ("se_ard", [ll...], lsig)
+    ("mat12_iso", ll, lsig)         ("mat12_ard", [ll...], lsig)
+    ("mat32_iso", ll, lsig)         ("mat32_ard", [ll...], lsig)
+    ("mat52_iso", ll, lsig)         ("mat52_ard", [ll...], lsig)
+    ("rq_iso", ll, lsig, lalpha)    ("rq_ard", [ll...], lsig, lalpha)
+    ("noise", lsig)                 ("const", lsig)
+    ("sum", k1, k2)                 ("prod", k1, k2)
+    ("masked", k, [dims...])        ("fixed", k, [free...])
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import scipy.linalg as sla
+
+LOG2PI = math.log(2.0 * math.pi)
+SQRT3 = math.sqrt(3.0)
+SQRT5 = math.sqrt(5.0)
+# Julia `x ≈ y` for Float64: rtol = sqrt(eps(Float64)), atol = 0 (Base.isapprox)
+ISAPPROX_RTOL = math.sqrt(np.finfo(np.float64).eps)
+
+_ISO = {"se_iso", "mat12_iso", "mat32_iso", "mat52_iso", "rq_iso"}
+_ARD = {"se_ard", "mat12_ard", "mat32_ard", "mat52_ard", "rq_ard"}
+_SQ = {"se_iso", "se_ard", "rq_iso", "rq_ard"}  # (weighted) squared-euclidean metric
+
+
+# --------------------------------------------------------------------------
+# distances  (src/kernels/distance.jl:41-106, src/kernels/stationary.jl:10-22)
+# --------------------------------------------------------------------------
+def _sqdist(X1, X2, w=None):
+    """r[i,j] = sum_k w_k (X1[k,i]-X2[k,j])^2, accumulated from 0.0 in index
+    order k = 1..d exactly as _SqEuclidean_ij / _WeightedSqEuclidean_ij do
+    (distance.jl:43-56, 75-88): term = (x-y)^2 * w."""
+    d = X1.shape[0]
+    r = np.zeros((X1.shape[1], X2.shape[1]), dtype=np.result_type(X1, X2))
+    for k in range(d):
+        diff = X1[k, :, None] - X2[k, None, :]
+        if w is None:
+            r += diff * diff
+        else:
+            r += diff * diff * w[k]
+    return r
+
+
+def _isapprox_cols(X1, X2):
+    """Noise kernel δ: all_z X1[z,i] ≈ X2[z,j]  (noise.jl:31-37)."""
+    same = np.ones((X1.shape[1], X2.shape[1]), dtype=bool)
+    for z in range(X1.shape[0]):
+        a = X1[z, :, None]
+        b = X2[z, None, :]
+        ok = (a == b) | (np.abs(a - b) <= ISAPPROX_RTOL * np.maximum(np.abs(a), np.abs(b)))
+        same &= ok
+    return same
+
+
+# --------------------------------------------------------------------------
+# leaf kernels:  cov(k, r)   (SURVEY §8 a7 — one line per leaf file)
+# --------------------------------------------------------------------------
+def _leaf(spec, X1, X2):
+    name = spec[0]
+    dt = np.result_type(X1, X2)
+    if name == "noise":  # noise.jl:27-39
+        s2 = math.exp(2.0 * spec[1])
+        return np.where(_isapprox_cols(X1, X2), dt.type(s2), dt.type(0.0))
+    if name == "const":  # const.jl:25,36
+        s2 = math.exp(2.0 * spec[1])
+        return np.full((X1.shape[1], X2.shape[1]), s2, dtype=dt)
+    if name in _ISO:
+        ll, ls = float(spec[1]), float(spec[2])
+        s2 = math.exp(2.0 * ls)
+        r = _sqdist(X1, X2)
+        if name == "se_iso":  # se_iso.jl:28,39   σ2*exp(-0.5*r/ℓ2)
+            l2 = math.exp(2.0 * ll)
+            return s2 * np.exp(-0.5 * r / l2)
+        if name == "rq_iso":  # rq_iso.jl:33,44  σ2*(1+r/(2αℓ2))^(-α)
+            l2 = math.exp(2.0 * ll)
+            al = math.exp(float(spec[3]))
+            return s2 * (1.0 + r / (2.0 * al * l2)) ** (-al)
+        r = np.sqrt(r)  # Euclidean metric (distance.jl:64-71)
+        ell = math.exp(ll)
+        if name == "mat12_iso":  # mat12_iso.jl:30,41
+            return s2 * np.exp(-r / ell)
+        if name == "mat32_iso":  # mat32_iso.jl:30,41-42
+            s = SQRT3 * r / ell
+            return s2 * (1.0 + s) * np.exp(-s)
+        if name == "mat52_iso":  # mat52_iso.jl:30,40-41
+            s = SQRT5 * r / ell
+            return s2 * (1.0 + s + s * s / 3.0) * np.exp(-s)
+    if name in _ARD:
+        ll = np.asarray(spec[1], dtype=np.float64)
+        if ll.shape[0] != X1.shape[0]:
+            raise ValueError("ARD kernel dimension mismatch")
+        s2 = math.exp(2.0 * float(spec[2]))
+        w = np.exp(-2.0 * ll)  # iℓ2, se_ard.jl:31
+        r = _sqdist(X1, X2, w)
+        if name == "se_ard":  # se_ard.jl:43   σ2*exp(-r/2)
+            return s2 * np.exp(-r / 2.0)
+        if name == "rq_ard":  # rq_ard.jl:47   σ2*(1+0.5*r/α)^(-α)
+            al = math.exp(float(spec[3]))
+            return s2 * (1.0 + 0.5 * r / al) ** (-al)
+        r = np.sqrt(r)  # WeightedEuclidean (distance.jl:99-106)
+        if name == "mat12_ard":  # mat12_ard.jl:43
+            return s2 * np.exp(-r)
+        if name == "mat32_ard":  # mat32_ard.jl:43-44
+            s = SQRT3 * r
+            return s2 * (1.0 + s) * np.exp(-s)
+        if name == "mat52_ard":  # mat52_ard.jl:43-44
+            s = SQRT5 * r
+            return s2 * (1.0 + s + s * s / 3.0) * np.exp(-s)
+    raise ValueError(f"unknown kernel spec {name!r}")
+
+
+def cov(spec, X1, X2=None):
+    """cov(k, X1, X2) / cov(k, X)  — src/kernels/kernels.jl:31-71.
+
+    Returns the nobs1 × nobs2 matrix cK[i,j] = cov_ij(k, X1, X2, i, j).
+    """
+    X1 = np.asarray(X1)
+    X2 = X1 if X2 is None else np.asarray(X2)
+    if X1.shape[0] != X2.shape[0]:
+        raise ValueError("X1 and X2 must have same dimension")  # kernels.jl:34
+    name = spec[0]
+    if name == "sum":  # sum_kernel.jl:15-16
+        return cov(spec[1], X1, X2) + cov(spec[2], X1, X2)
+    if name == "prod":  # prod_kernel.jl:14-15
+        return cov(spec[1], X1, X2) * cov(spec[2], X1, X2)
+    if name == "masked":  # masked_kernel.jl:44-49 (view of the active rows)
+        dims = list(spec[2])
+        return cov(spec[1], X1[dims, :], X2[dims, :])
+    if name == "fixed":  # fixed_kernel.jl:69
+        return cov(spec[1], X1, X2)
+    return _leaf(spec, X1, X2)
+
+
+def cov_scalar(spec, x, y):
+    """cov(k, x::Vector, y::Vector) — the pairwise definition used by
+    test/kernels.jl:41,57 as the meaning of cov!; pure-Python scalar loops."""
+    name = spec[0]
+    if name == "sum":
+        return cov_scalar(spec[1], x, y) + cov_scalar(spec[2], x, y)
+    if name == "prod":
+        return cov_scalar(spec[1], x, y) * cov_scalar(spec[2], x, y)
+    if name == "masked":
+        dims = list(spec[2])
+        return cov_scalar(spec[1], [x[i] for i in dims], [y[i] for i in dims])
+    if name == "fixed":
+        return cov_scalar(spec[1], x, y)
+    d = len(x)
+    if name == "noise":
+        s2 = math.exp(2.0 * spec[1])
+        for a, b in zip(x, y):
+            if not (a == b or abs(a - b) <= ISAPPROX_RTOL * max(abs(a), abs(b))):
+                return 0.0
+        return s2
+    if name == "const":
+        return math.exp(2.0 * spec[1])
+    if name in _ISO:
+        w = [1.0] * d
+    else:
+        w = [math.exp(-2.0 * float(v)) for v in spec[1]]
+    r = 0.0
+    for k in range(d):
+        r += (x[k] - y[k]) ** 2 * w[k]
+    s2 = math.exp(2.0 * float(spec[2]))
+    if name == "se_iso":
+        return s2 * math.exp(-0.5 * r / math.exp(2.0 * spec[1]))
+    if name == "se_ard":
+        return s2 * math.exp(-r / 2.0)
+    if name == "rq_iso":
+        al = math.exp(spec[3])
+        return s2 * (1.0 + r / (2.0 * al * math.exp(2.0 * spec[1]))) ** (-al)
+    if name == "rq_ard":
+        al = math.exp(spec[3])
+        return s2 * (1.0 + 0.5 * r / al) ** (-al)
+    r = math.sqrt(r)
+    if name.endswith("_iso"):
+        r = r / math.exp(spec[1])
+    if name.startswith("mat12"):
+        return s2 * math.exp(-r)
+    if name.startswith("mat32"):
+        s = SQRT3 * r
+        return s2 * (1.0 + s) * math.exp(-s)
+    if name.startswith("mat52"):
+        s = SQRT5 * r
+        return s2 * (1.0 + s + s * s / 3.0) * math.exp(-s)
+    raise ValueError(name)
+
+
+def num_params(spec):
+    """num_params(k) — leaf files + pair_kernel.jl:14."""
+    name = spec[0]
+    if name in ("sum", "prod"):
+        return num_params(spec[1]) + num_params(spec[2])
+    if name == "masked":
+        return num_params(spec[1])
+    if name == "fixed":
+        return len(spec[2])
+    if name in ("noise", "const"):
+        return 1
+    if name in _ISO:
+        return 3 if name == "rq_iso" else 2
+    n = len(spec[1]) + 1
+    return n + 1 if name == "rq_ard" else n
+
+
+# --------------------------------------------------------------------------
+# means  (src/means/means.jl:6-13, mZero.jl:16, mConst.jl:27, mLin.jl:27)
+# --------------------------------------------------------------------------
+def mean(mspec, X):
+    X = np.asarray(X)
+    name = mspec[0]
+    if name == "zero":
+        return np.zeros(X.shape[1])
+    if name == "const":
+        return np.full(X.shape[1], float(mspec[1]))
+    if name == "lin":
+        return X.T @ np.asarray(mspec[1], dtype=np.float64)
+    raise ValueError(name)
+
+
+# --------------------------------------------------------------------------
+# fit:  update_cK! + update_mll!   (src/GPE.jl:169-212, src/GP.jl:101-112)
+# --------------------------------------------------------------------------
+class NotPosDef(Exception):
+    """LinearAlgebra.PosDefException(info) analogue (GP.jl:110)."""
+
+    def __init__(self, info):
+        super().__init__(f"matrix is not positive definite; Cholesky factorization failed (info={info})")
+        self.info = info
+
+
+def update_cK(spec, x, log_noise):
+    """update_cK! (GPE.jl:169-186) + make_posdef! (GP.jl:101-112).
+
+    Returns (Σ, U) with Σ = cov!(x,x) + nugget on the diagonal and
+    Σ = UᵀU (upper factor, dpotrf 'U' as cholesky!(Symmetric(·,:U)))."""
+    x = np.asarray(x, dtype=np.float64)
+    K = cov(spec, x)
+    n = K.shape[0]
+    if np.ndim(log_noise) == 0:
+        K[np.diag_indices(n)] += math.exp(2.0 * float(log_noise))  # GPE.jl:173, GP.jl:104-108
+    else:
+        ln = np.asarray(log_noise, dtype=np.float64)
+        if ln.shape != (n,):
+            raise ValueError("heteroscedastic logNoise must have length nobs")
+        K[np.diag_indices(n)] += np.exp(2.0 * ln)  # GPE.jl:181-183
+    # dpotrf('U') — the routine Julia's cholesky! dispatches to (GP.jl:110)
+    U, info = sla.lapack.dpotrf(K, lower=0, clean=1, overwrite_a=0)
+    if info != 0:
+        raise NotPosDef(int(info))
+    return K, U
+
+
+def update_mll(spec, x, y, log_noise, mspec=("zero",)):
+    """update_mll! (GPE.jl:202-212).  Returns dict(mll, alpha, U, K)."""
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    if y.shape[0] != x.shape[1]:
+        raise ValueError("Input and output observations must have consistent dimensions.")  # GPE.jl:42
+    K, U = update_cK(spec, x, log_noise)
+    ym = y - mean(mspec, x)  # GPE.jl:206-207
+    alpha = sla.cho_solve((U, False), ym)  # GPE.jl:208  (PDMats `\` = dpotrs)
+    logdet = 2.0 * np.sum(np.log(np.diag(U)))  # PDMats.logdet
+    mll = -(float(ym @ alpha) + logdet + LOG2PI * x.shape[1]) / 2.0  # GPE.jl:210
+    return {"mll": mll, "alpha": alpha, "U": U, "K": K, "logdet": logdet}
+
+
+# --------------------------------------------------------------------------
+# predict  (src/GP.jl:25-84, src/GPE.jl:399-416)
+# --------------------------------------------------------------------------
+def predict_full(spec, x, fit, xpred, mspec=("zero",)):
+    """predictMVN (GP.jl:39-49) + predictMVN! (GP.jl:25-30)."""
+    x = np.asarray(x, dtype=np.float64)
+    xpred = np.asarray(xpred, dtype=np.float64)
+    Kcross = cov(spec, x, xpred)  # GP.jl:44
+    Kpred = cov(spec, xpred)  # GP.jl:45  (X1 === X2 branch)
+    mx = mean(mspec, xpred)
+    mu = mx + Kcross.T @ fit["alpha"]  # GP.jl:26
+    # whiten!(Kff, Kfx) = L⁻¹ Kfx with L = Uᵀ  (GP.jl:27)
+    Lck = sla.solve_triangular(fit["U"], Kcross, trans="T", lower=False)
+    Sigma = Kpred - Lck.T @ Lck  # GP.jl:51-54 (syrk + copytri ⇒ symmetric)
+    Sigma = np.triu(Sigma) + np.triu(Sigma, 1).T
+    return mu, Sigma
+
+
+def predict_f(spec, x, fit, xpred, mspec=("zero",), full_cov=False, pointwise=False):
+    """predict_f (GP.jl:64-79).
+
+    full_cov=False is, in the reference, a loop of P single-point
+    predict_full calls with σ² clamped at 0 (GP.jl:69-77).  ``pointwise=True``
+    runs literally that loop; the default computes the same numbers batched
+    (one triangular solve with P right-hand sides)."""
+    x = np.asarray(x, dtype=np.float64)
+    xpred = np.asarray(xpred, dtype=np.float64)
+    if xpred.shape[0] != x.shape[0]:
+        raise ValueError("Gaussian Process object and input observations do not have consistent dimensions")
+    if full_cov:
+        return predict_full(spec, x, fit, xpred, mspec)
+    P = xpred.shape[1]
+    if pointwise:
+        mu = np.empty(P)
+        s2 = np.empty(P)
+        for k in range(P):
+            m, sig = predict_full(spec, x, fit, xpred[:, k : k + 1], mspec)
+            mu[k] = m[0]
+            s2[k] = max(sig[0, 0], 0.0)
+        return mu, s2
+    Kcross = cov(spec, x, xpred)
+    mu = mean(mspec, xpred) + Kcross.T @ fit["alpha"]
+    Lck = sla.solve_triangular(fit["U"], Kcross, trans="T", lower=False)
+    # prior variance = cov(k, xp, xp)[1,1] of each single-column slice (GP.jl:45,73)
+    kdiag = _kdiag(spec, xpred)
+    s2 = np.maximum(kdiag - np.sum(Lck * Lck, axis=0), 0.0)
+    return mu, s2
+
+
+def _kdiag(spec, X):
+    """diag(cov(k, X)) without forming the P×P matrix."""
+    name = spec[0]
+    P = X.shape[1]
+    if name == "sum":
+        return _kdiag(spec[1], X) + _kdiag(spec[2], X)
+    if name == "prod":
+        return _kdiag(spec[1], X) * _kdiag(spec[2], X)
+    if name == "masked":
+        return _kdiag(spec[1], X[list(spec[2]), :])
+    if name == "fixed":
+        return _kdiag(spec[1], X)
+    if name in ("noise", "const"):
+        return np.full(P, math.exp(2.0 * spec[1]))
+    return np.full(P, math.exp(2.0 * float(spec[2])))  # every stationary leaf: k(0) = σ2
+
+
+def predict_y(spec, x, fit, xpred, log_noise, mspec=("zero",), full_cov=False):
+    """predict_y (GPE.jl:408-416): predict_f + noise_variance."""
+    mu, s2 = predict_f(spec, x, fit, xpred, mspec, full_cov=full_cov)
+    nv = math.exp(2.0 * float(log_noise))
+    if full_cov:
+        return mu, s2 + nv * np.eye(s2.shape[0])
+    return mu, s2 + nv
+
+
+# --------------------------------------------------------------------------
+# synthetic workload of SURVEY.md §8(d)  (shared by tests and bench.py's
+# cpu_baseline leg so CPU and GPU see byte-identical inputs)
+# --------------------------------------------------------------------------
+def synthetic_inputs(n, d, p=1024, seed=20240501):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(0.0, 1.0, size=(d, n))
+    f = np.sin(2.0 * np.pi * x).sum(axis=0) / d
+    y = f + 0.1 * rng.standard_normal(n)
+    xpred = rng.uniform(0.0, 1.0, size=(d, p))
+    return x, y, xpred

@@ -1,0 +1,199 @@
+"""Pins the CPU oracle (oracle/) — the checker every GPU parity test relies on.
+
+The reference stores no numeric golden for the exact-GP path, so
+the oracle is pinned by (i) the relational properties the reference's own tests
+assert, (ii) scikit-learn as an independent implementation of the same maths,
+(iii) closed forms, (iv) agreement of the two restatements (NumPy vs scalar C).
+"""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from oracle import gp_oracle as G
+from kernel_cases import ALL, COMPOSITES, D, LEAVES, ids
+
+
+def _data(n=6, n2=3, d=D, seed=1):
+    rng = np.random.default_rng(seed)
+    return rng.standard_normal((d, n)), rng.standard_normal((d, n2))
+
+
+# --- test/kernels.jl:39-41  cov(k,X)[i,j] ≈ cov(k, x_i, x_j) ------------------
+@pytest.mark.parametrize("spec", ALL, ids=ids(ALL))
+def test_cov_matches_pairwise_definition_symmetric(spec):
+    X, _ = _data()
+    K = G.cov(spec, X)
+    n = X.shape[1]
+    for i in range(n):
+        for j in range(n):
+            assert K[i, j] == pytest.approx(G.cov_scalar(spec, list(X[:, i]), list(X[:, j])), rel=1e-13, abs=1e-300)
+    assert np.array_equal(K, K.T)
+
+
+# --- test/kernels.jl:55-60  cov(k,X,X2)[i,j] ≈ cov(k, x_i, x2_j) -------------
+@pytest.mark.parametrize("spec", ALL, ids=ids(ALL))
+def test_cov_matches_pairwise_definition_rect(spec):
+    X, X2 = _data()
+    K = G.cov(spec, X, X2)
+    assert K.shape == (X.shape[1], X2.shape[1])
+    for i in range(X.shape[1]):
+        for j in range(X2.shape[1]):
+            assert K[i, j] == pytest.approx(G.cov_scalar(spec, list(X[:, i]), list(X2[:, j])), rel=1e-13, abs=1e-300)
+
+
+# --- the two restatements agree (NumPy vectorised vs scalar C loops) ---------
+@pytest.mark.parametrize("spec", ALL, ids=ids(ALL))
+def test_numpy_and_c_oracle_agree(spec):
+    X, X2 = _data(n=40, n2=17)
+    np.testing.assert_allclose(c_oracle.cov(spec, X), G.cov(spec, X), rtol=2e-14, atol=1e-300)
+    np.testing.assert_allclose(c_oracle.cov(spec, X, X2), G.cov(spec, X, X2), rtol=2e-14, atol=1e-300)
+
+
+def test_c_oracle_assemble_adds_nugget():
+    X, _ = _data(n=20)
+    spec = ("se_ard", [0.1, 0.2, 0.3], 0.0)
+    A = c_oracle.assemble(spec, X, -1.0)
+    np.testing.assert_allclose(A, G.cov(spec, X) + math.exp(-2.0) * np.eye(20), rtol=1e-14)
+    ln = np.linspace(-2, -1, 20)
+    A = c_oracle.assemble(spec, X, ln)
+    np.testing.assert_allclose(A, G.cov(spec, X) + np.diag(np.exp(2 * ln)), rtol=1e-14)
+
+
+# --- noise.jl:31-37: δ is isapprox on coordinates, not index equality --------
+def test_noise_kernel_isapprox_semantics():
+    X = np.array([[0.5, 0.5, 0.5 * (1 + 1e-9), 0.7], [1.0, 1.0, 1.0, 1.0]])
+    K = G.cov(("noise", 0.0), X)
+    expect = np.array([[1, 1, 1, 0], [1, 1, 1, 0], [1, 1, 1, 0], [0, 0, 0, 1]], dtype=float)
+    np.testing.assert_array_equal(K, expect)
+    np.testing.assert_array_equal(c_oracle.cov(("noise", 0.0), X), expect)
+    X2 = np.array([[0.5 * (1 + 1e-7)], [1.0]])  # outside rtol sqrt(eps)
+    assert G.cov(("noise", 0.0), X, X2)[0, 0] == 0.0
+
+
+# --- closed forms --------------------------------------------------------------
+def test_closed_form_n1_and_n2():
+    # N = 1: mll = -(y²/(s2+n2) + log(s2+n2) + log 2π)/2
+    x = np.array([[0.3]])
+    y = np.array([0.7])
+    s2, n2 = math.exp(2 * 0.2), math.exp(2 * -1.0)
+    fit = G.update_mll(("se_iso", 0.0, 0.2), x, y, -1.0)
+    v = s2 + n2
+    assert fit["mll"] == pytest.approx(-(0.49 / v + math.log(v) + G.LOG2PI) / 2, rel=1e-14)
+    # N = 2 SEIso: explicit 2×2 inverse / determinant
+    x = np.array([[0.0, 1.0]])
+    y = np.array([1.0, -0.5])
+    k01 = s2 * math.exp(-0.5 * 1.0 / 1.0)
+    a, b = s2 + n2, k01
+    det = a * a - b * b
+    quad = (a * y[0] ** 2 - 2 * b * y[0] * y[1] + a * y[1] ** 2) / det
+    fit = G.update_mll(("se_iso", 0.0, 0.2), x, y, -1.0)
+    assert fit["mll"] == pytest.approx(-(quad + math.log(det) + 2 * G.LOG2PI) / 2, rel=1e-13)
+    np.testing.assert_allclose(fit["alpha"], np.array([a * y[0] - b * y[1], -b * y[0] + a * y[1]]) / det, rtol=1e-13)
+
+
+# --- independent implementation: scikit-learn --------------------------------
+def _sk_kernel(spec):
+    from sklearn.gaussian_process import kernels as SK
+
+    name = spec[0]
+    if name == "sum":
+        return _sk_kernel(spec[1]) + _sk_kernel(spec[2])
+    if name == "prod":
+        return _sk_kernel(spec[1]) * _sk_kernel(spec[2])
+    if name == "noise":
+        return SK.WhiteKernel(noise_level=math.exp(2 * spec[1]))
+    if name == "const":
+        return SK.ConstantKernel(math.exp(2 * spec[1]))
+    amp = SK.ConstantKernel(math.exp(2 * spec[2]))
+    ls = math.exp(spec[1]) if name.endswith("_iso") else np.exp(np.asarray(spec[1]))
+    if name.startswith("se"):
+        return amp * SK.RBF(length_scale=ls)
+    if name.startswith("mat12"):
+        return amp * SK.Matern(length_scale=ls, nu=0.5)
+    if name.startswith("mat32"):
+        return amp * SK.Matern(length_scale=ls, nu=1.5)
+    if name.startswith("mat52"):
+        return amp * SK.Matern(length_scale=ls, nu=2.5)
+    if name == "rq_iso":
+        return amp * SK.RationalQuadratic(length_scale=ls, alpha=math.exp(spec[3]))
+    raise KeyError(name)
+
+
+SK_CASES = [s for s in LEAVES if s[0] not in ("rq_ard", "noise")] + [
+    ("sum", ("se_iso", 0.3, 0.1), ("rq_iso", 0.3, 0.2, 0.4)),
+    ("prod", ("se_iso", 0.3, 0.1), ("mat12_iso", 0.2, -0.1)),
+    ("sum", ("se_ard", [0.3, -0.2, 0.5], 0.0), ("mat52_iso", math.log(0.7), math.log(0.5))),
+]
+
+
+@pytest.mark.parametrize("spec", SK_CASES, ids=ids(SK_CASES))
+def test_vs_sklearn_mll_and_predict(spec):
+    from sklearn.gaussian_process import GaussianProcessRegressor
+
+    rng = np.random.default_rng(7)
+    n, p = 40, 9
+    x = rng.uniform(size=(D, n))
+    y = np.sin(3 * x.sum(axis=0)) + 0.1 * rng.standard_normal(n)
+    xs = rng.uniform(size=(D, p))
+    log_noise = math.log(0.3)
+    gpr = GaussianProcessRegressor(kernel=_sk_kernel(spec), alpha=math.exp(2 * log_noise), optimizer=None).fit(x.T, y)
+    fit = G.update_mll(spec, x, y, log_noise)
+    assert fit["mll"] == pytest.approx(gpr.log_marginal_likelihood_value_, rel=1e-12)
+    np.testing.assert_allclose(fit["alpha"], gpr.alpha_, rtol=1e-9)
+    mu, s2 = G.predict_f(spec, x, fit, xs)
+    mu_sk, cov_sk = gpr.predict(xs.T, return_cov=True)
+    np.testing.assert_allclose(mu, mu_sk, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(s2, np.diag(cov_sk), rtol=1e-8, atol=1e-12)
+    _, Sig = G.predict_f(spec, x, fit, xs, full_cov=True)
+    np.testing.assert_allclose(Sig, cov_sk, rtol=1e-8, atol=1e-11)
+
+
+# --- test/gp.jl:47-53: predict at the training inputs ≈ y; σ² ≡ diag(full cov);
+#     and the per-point loop of GP.jl:69-77 ≡ the batched computation ----------
+@pytest.mark.parametrize("spec", [LEAVES[1], LEAVES[7], COMPOSITES[2]], ids=["se_ard", "mat52_ard", "sum+noise"])
+def test_predict_properties(spec):
+    rng = np.random.default_rng(3)
+    n = 10
+    x = 2 * np.pi * rng.uniform(size=(D, n))
+    y = np.sin(x.sum(axis=0)) + 0.05 * rng.standard_normal(n)
+    fit = G.update_mll(spec, x, y, -2.0)
+    mu, s2 = G.predict_y(spec, x, fit, x, -2.0)
+    np.testing.assert_allclose(mu, y, atol=0.1)  # gp.jl:50
+    mu_f, s2_f = G.predict_f(spec, x, fit, x)
+    _, Sig = G.predict_f(spec, x, fit, x, full_cov=True)
+    np.testing.assert_allclose(s2_f, np.maximum(np.diag(Sig), 0.0), rtol=1e-9, atol=1e-13)  # gp.jl:52
+    mu_p, s2_p = G.predict_f(spec, x, fit, x, pointwise=True)
+    np.testing.assert_allclose(mu_p, mu_f, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(s2_p, s2_f, rtol=1e-9, atol=1e-13)
+
+
+def test_mean_functions_and_arg_errors():
+    X, _ = _data()
+    np.testing.assert_array_equal(G.mean(("zero",), X), np.zeros(6))
+    np.testing.assert_array_equal(G.mean(("const", 1.5), X), np.full(6, 1.5))
+    np.testing.assert_allclose(G.mean(("lin", [1.0, 2.0, 3.0]), X), X.T @ np.array([1.0, 2.0, 3.0]))
+    with pytest.raises(ValueError):
+        G.update_mll(("se_iso", 0.0, 0.0), X, np.zeros(5), -1.0)  # GPE.jl:42
+    with pytest.raises(ValueError):
+        G.cov(("se_iso", 0.0, 0.0), X, np.zeros((2, 4)))  # kernels.jl:34
+
+
+def test_not_posdef_reports_pivot():
+    # duplicate points, Const kernel, no noise ⇒ rank-1 matrix: dpotrf fails at pivot 2
+    x = np.zeros((1, 3))
+    with pytest.raises(G.NotPosDef) as ei:
+        G.update_mll(("const", 0.0), x, np.ones(3), -400.0)
+    assert ei.value.info == 2
+
+
+def test_heteroscedastic_noise_path():
+    rng = np.random.default_rng(5)
+    x = rng.uniform(size=(2, 30))
+    y = rng.standard_normal(30)
+    ln = rng.uniform(-2, -1, size=30)
+    fit = G.update_mll(("se_iso", -0.5, 0.0), x, y, ln)
+    K = G.cov(("se_iso", -0.5, 0.0), x) + np.diag(np.exp(2 * ln))
+    np.testing.assert_allclose(K @ fit["alpha"], y, rtol=1e-9, atol=1e-11)
+    assert np.isfinite(fit["mll"])  # heteroscedastic.jl:34-48
