@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""bench.py — GP fits/sec (update_mll! + predict_f) on MI355X, BASELINE.json's metric.
+
+One "step" = the reference's steady-state unit of work:
+    set_params!(gp, hyp)  ->  update_mll!(gp)  ->  predict_f(gp, xpred)      (full_cov=false)
+with x already resident in HBM (uploaded once by GP(), as fit! does) and the hyper-parameters
+perturbed every step so nothing can be cached.  Workload at N=1: BASELINE.json configs[1]
+(N=20000, d=8, SEArd, fp64, MeanZero, P=1024 test points, SURVEY §8d hyper-parameters).
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     — the dominant kernel (Cholesky trailing update, MFMA-bound): algorithmic flops per
+                 launch / mean launch duration, measured live with HIP events on the library's
+                 stream over the timed region (gpmi_profile_*).
+  cpu_baseline — the CPU oracle (a port: the Julia reference cannot run here) timed on this host
+                 on a bounded sample and scaled to the bench size stage by stage.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "gaussianprocesses.jl_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (v_mfma_f64_16x16x4_f64): 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: Peak FP32 (matrix)
+
+
+def synthetic_inputs(n, d, p, seed=20240501):
+    """SURVEY.md §8(d) inputs (same generator as oracle.gp_oracle.synthetic_inputs)."""
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(0.0, 1.0, size=(d, n))
+    f = np.sin(2.0 * np.pi * x).sum(axis=0) / d
+    y = f + 0.1 * rng.standard_normal(n)
+    xpred = rng.uniform(0.0, 1.0, size=(d, p))
+    return x, y, xpred
+
+
+def cpu_baseline(n_bench, d, p, ll, n_sample):
+    """Oracle timed on the host: cov! as the reference's single-threaded scalar loop (C), LAPACK
+    dpotrf/dpotrs/dtrsm on all cores; scaled from n_sample to n_bench per stage (N^2 / N^3)."""
+    import scipy.linalg as sla
+
+    from oracle import c_oracle
+    from oracle import gp_oracle as G
+
+    x, y, xs = G.synthetic_inputs(n_sample, d, p)
+    spec = ("se_ard", ll, 0.0)
+    t0 = time.perf_counter()
+    K = c_oracle.assemble(spec, x, math.log(0.1))
+    t1 = time.perf_counter()
+    U, info = sla.lapack.dpotrf(K, lower=0, clean=0, overwrite_a=1)
+    assert info == 0
+    t2 = time.perf_counter()
+    alpha = sla.cho_solve((U, False), y)
+    mll = -(float(y @ alpha) + 2.0 * np.sum(np.log(np.diag(U))) + G.LOG2PI * n_sample) / 2.0
+    t3 = time.perf_counter()
+    Kc = c_oracle.cov(spec, x, xs)
+    mu = Kc.T @ alpha
+    Lck = sla.solve_triangular(U, Kc, trans="T", lower=False, overwrite_b=True)
+    s2 = np.maximum(1.0 - np.sum(Lck * Lck, axis=0), 0.0)
+    t4 = time.perf_counter()
+    assert np.isfinite(mll) and np.all(np.isfinite(mu)) and np.all(np.isfinite(s2))
+    r = n_bench / n_sample
+    t_cov, t_chol, t_solve, t_pred = t1 - t0, t2 - t1, t3 - t2, t4 - t3
+    est = t_cov * r**2 + t_chol * r**3 + t_solve * r**2 + t_pred * r**2
+    return {
+        "value": 1.0 / est,
+        "unit": "GP fits/sec",
+        "cores": os.cpu_count(),
+        "kind": "port",
+        "sample": (f"oracle fit+predict measured at N={n_sample} d={d} P={p} "
+                   f"(cov! 1-thread C loop {t_cov:.2f}s, dpotrf {t_chol:.2f}s, dpotrs+mll {t_solve:.2f}s, "
+                   f"predict {t_pred:.2f}s = {1.0/(t4-t0):.4f} fits/s), scaled to N={n_bench} per stage (N^2/N^3)"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=20000)
+    ap.add_argument("--d", type=int, default=8)
+    ap.add_argument("--p", type=int, default=1024)
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--cpu-sample-n", type=int, default=10000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a MI355X: no GPU visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import gpmi355x as g
+
+    n, d, p = args.n, args.d, args.p
+    np_dt = np.float64 if args.dtype == "f64" else np.float32
+    x, y, xpred = synthetic_inputs(n, d, p)
+    ll = [math.log(0.5) + 0.05 * k for k in range(d)]
+    log_noise = math.log(0.1)
+    ctx = g.Context.default(local_rank)
+    t_build0 = time.perf_counter()
+    gp = g.GP(x, y, g.MeanZero(), g.SEArd(ll, 0.0), log_noise, dtype=np_dt, ctx=ctx)  # uploads x, first fit
+    t_build = time.perf_counter() - t_build0
+    base = np.asarray(gp.get_params())
+
+    def step(i):
+        gp.set_params(base + 1e-3 * ((i % 7) + 1) * np.where(np.arange(len(base)) == 0, 0.0, 1.0))
+        gp.update_mll()
+        return gp.predict_f(xpred)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    ctx.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        mu, s2 = step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    n_syrk, ms_syrk, fl_syrk = ctx.profile_get(g._lib.PROF_SYRK)
+    n_cov, ms_cov, by_cov = ctx.profile_get(g._lib.PROF_COV)
+    n_pan, ms_pan, fl_pan = ctx.profile_get(g._lib.PROF_PANEL)
+    n_sol, ms_sol, _ = ctx.profile_get(g._lib.PROF_SOLVE)
+    n_pre, ms_pre, _ = ctx.profile_get(g._lib.PROF_PREDICT)
+    ctx.profile_enable(False)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    assert np.all(np.isfinite(mu)) and np.all(np.isfinite(s2)) and math.isfinite(gp.mll)
+    if rank == 0:
+        peak = FP64_MFMA_PEAK_TFLOPS if args.dtype == "f64" else FP32_MFMA_PEAK_TFLOPS
+        achieved = (fl_syrk / max(ms_syrk, 1e-9)) * 1e-9  # flop/ms -> TFLOP/s
+        out = {
+            "metric": "GP fits/sec (update_mll!+predict_f)",
+            "value": world * args.steps / elapsed,
+            "unit": "GP fits/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": f"N={n}, d={d}, SEArd + MeanZero, {args.dtype}, P={p} test points, full_cov=false "
+                            "(BASELINE.json configs[1])",
+                "parallelism": "single GPU" if world == 1 else f"{world} independent replicas, one per GPU (no collective)",
+                "mll": gp.mll,
+            },
+            "roofline": {
+                "kernel": "gemm_nt_kernel (Cholesky trailing update, K=256)",
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": peak,
+                "unit": "TFLOP/s",
+                "frac": achieved / peak,
+                "traffic": None,
+                "launches": n_syrk,
+                "avg_launch_ms": ms_syrk / max(n_syrk, 1),
+                "algorithmic_flops_per_launch": fl_syrk / max(n_syrk, 1),
+            },
+            "stage_ms_per_step": {
+                "cov": ms_cov / args.steps,
+                "cov_GBps": (by_cov / max(ms_cov, 1e-9)) * 1e-6,
+                "chol_trailing_update": ms_syrk / args.steps,
+                "panel_potf2_trsm_update": ms_pan / args.steps,
+                "alpha_solve_mll": ms_sol / args.steps,
+                "predict": ms_pre / args.steps,
+            },
+            "first_fit_incl_upload_s": t_build,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, d, p, ll, min(args.cpu_sample_n, n))
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,616 @@
+// api.hip — the C ABI of include/gpmi.h and the host-side drivers (blocked Cholesky, solves,
+// predict).  All device work is enqueued on ctx->stream; every export returns after the
+// results are on the host (the reference's callers are synchronous).
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+using namespace gpmi;
+
+namespace gpmi {
+
+// ---------------------------------------------------------------------------------------------
+// kernel descriptor -> device program
+// ---------------------------------------------------------------------------------------------
+static bool is_ard(int op) {
+    return op == GPMI_K_SE_ARD || op == GPMI_K_MAT12_ARD || op == GPMI_K_MAT32_ARD || op == GPMI_K_MAT52_ARD ||
+           op == GPMI_K_RQ_ARD;
+}
+static bool is_iso(int op) {
+    return op == GPMI_K_SE_ISO || op == GPMI_K_MAT12_ISO || op == GPMI_K_MAT32_ISO || op == GPMI_K_MAT52_ISO ||
+           op == GPMI_K_RQ_ISO;
+}
+
+int digest_kernel(const gpmi_kernel* k, int d, DevProgram* out, std::string* err) {
+    if (!k || !k->ops || !k->dims_off || !k->params || k->n_ops <= 0) {
+        *err = "kernel descriptor: null field or empty program";
+        return GPMI_EARG;
+    }
+    if (k->n_ops > GPMI_MAX_OPS) {
+        *err = "kernel descriptor: more than GPMI_MAX_OPS nodes";
+        return GPMI_EARG;
+    }
+    if (d <= 0 || d > MAX_D) {
+        *err = "input dimension must be in 1..64";
+        return GPMI_EARG;
+    }
+    memset(out, 0, sizeof(DevProgram));
+    out->n_ops = k->n_ops;
+    out->d = d;
+    int pp = 0, depth = 0, wcur = 0;
+    double kst[GPMI_MAX_OPS];
+    for (int o = 0; o < k->n_ops; ++o) {
+        const int op = k->ops[o];
+        DevLeaf& lf = out->leaf[o];
+        lf.op = op;
+        if (op == GPMI_K_SUM || op == GPMI_K_PROD) {
+            if (depth < 2) {
+                *err = "kernel descriptor: SUM/PROD without two operands";
+                return GPMI_EARG;
+            }
+            const double r = kst[--depth], l = kst[--depth];
+            kst[depth++] = (op == GPMI_K_SUM) ? l + r : l * r;
+            continue;
+        }
+        if (!(is_ard(op) || is_iso(op) || op == GPMI_K_NOISE || op == GPMI_K_CONST)) {
+            *err = "kernel descriptor: unknown op code";
+            return GPMI_EARG;
+        }
+        const int d0 = k->dims_off[o], d1 = k->dims_off[o + 1];
+        if (d1 < d0 || (d1 > d0 && !k->dims)) {
+            *err = "kernel descriptor: bad dims_off";
+            return GPMI_EARG;
+        }
+        const int nd = (d1 > d0) ? d1 - d0 : d;
+        const int npar = is_ard(op) ? nd + 1 + (op == GPMI_K_RQ_ARD) : is_iso(op) ? 2 + (op == GPMI_K_RQ_ISO) : 1;
+        if (pp + npar > k->n_params) {
+            *err = "kernel descriptor: params shorter than the program needs";
+            return GPMI_EARG;
+        }
+        const double* par = k->params + pp;
+        pp += npar;
+        lf.woff = wcur;
+        double* w = out->w + wcur;
+        wcur += d;
+        for (int z = 0; z < nd; ++z) {
+            const int kk = (d1 > d0) ? k->dims[d0 + z] : z;
+            if (kk < 0 || kk >= d) {
+                *err = "kernel descriptor: active dim out of range";
+                return GPMI_EARG;
+            }
+            w[kk] += is_ard(op) ? par[z] : 1.0;
+        }
+        if (op == GPMI_K_NOISE || op == GPMI_K_CONST) {
+            lf.s2 = par[0];
+            if (op == GPMI_K_NOISE) out->has_noise_leaf = 1;
+        } else if (is_iso(op)) {
+            lf.s2 = par[1];
+            if (op == GPMI_K_RQ_ISO) {
+                lf.p1 = par[2];
+                lf.p0 = 1.0 / (2.0 * par[2] * par[0]);
+            } else {
+                lf.p0 = 1.0 / par[0];
+            }
+        } else {
+            lf.s2 = par[nd];
+            if (op == GPMI_K_RQ_ARD) {
+                lf.p1 = par[nd + 1];
+                lf.p0 = 0.5 / par[nd + 1];
+            } else {
+                lf.p0 = 1.0;
+            }
+        }
+        if (depth >= 6) {
+            *err = "kernel descriptor: expression stack deeper than 6";
+            return GPMI_EARG;
+        }
+        kst[depth++] = lf.s2;  // every leaf evaluates to s2 at coincident points
+    }
+    if (depth != 1 || pp != k->n_params) {
+        *err = "kernel descriptor: malformed program (stack/params left over)";
+        return GPMI_EARG;
+    }
+    out->kdiag = kst[0];
+    return GPMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// profiling scope
+// ---------------------------------------------------------------------------------------------
+static hipEvent_t take_event(gpmi_ctx* c) {
+    if (!c->ev_pool.empty()) {
+        hipEvent_t e = c->ev_pool.back();
+        c->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+ProfScope::ProfScope(gpmi_ctx* ctx, int cls, double work) : c(ctx) {
+    if (!c->prof_on) return;
+    ProfRec r;
+    r.a = take_event(c);
+    r.b = take_event(c);
+    r.cls = cls;
+    r.work = work;
+    hipEventRecord(r.a, c->stream);
+    idx = (int)c->prof.size();
+    c->prof.push_back(r);
+}
+ProfScope::~ProfScope() {
+    if (idx >= 0) hipEventRecord(c->prof[idx].b, c->stream);
+}
+
+static int drain_profile(gpmi_ctx* c) {
+    if (c->prof.empty()) return GPMI_OK;
+    GPMI_HIP(c, hipStreamSynchronize(c->stream));
+    for (auto& r : c->prof) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, r.a, r.b);
+        c->prof_n[r.cls] += 1;
+        c->prof_ms[r.cls] += ms;
+        c->prof_work[r.cls] += r.work;
+        c->ev_pool.push_back(r.a);
+        c->ev_pool.push_back(r.b);
+    }
+    c->prof.clear();
+    return GPMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// drivers
+// ---------------------------------------------------------------------------------------------
+static int upload_program(gpmi_ctx* c, const gpmi_kernel* k, int d) {
+    int rc = digest_kernel(k, d, c->h_prog, &c->err);
+    if (rc != GPMI_OK) return rc;
+    GPMI_HIP(c, hipMemcpyAsync(c->d_prog, c->h_prog, sizeof(DevProgram), hipMemcpyHostToDevice, c->stream));
+    // h_prog is reused by the next call: make sure the copy has left the staging buffer
+    GPMI_HIP(c, hipStreamSynchronize(c->stream));
+    return GPMI_OK;
+}
+
+// Solve the block-column [k0, k0+nbk) of a row matrix R (Mr rows) against the already
+// factored diagonal block of A, then push the update into R's remaining columns:
+//   R[:, k0:kend] <- R[:, k0:kend] * L_kk^-T ;  R[:, kend:npad] -= R[:, k0:kend] * A[kend:npad, k0:kend]'
+template <typename T>
+static void rows_block_solve(gpmi_ctx* c, const T* A, int64_t ld, int64_t npad, T* R, int64_t ldr, int64_t Mr,
+                             int64_t k0, int64_t nbk) {
+    const int64_t kend = k0 + nbk;
+    for (int64_t j0 = k0; j0 < kend; j0 += IB) {
+        launch_trsm_rows<T>(c, R + j0, ldr, A + j0 * ld + j0, ld, Mr, nullptr);
+        const int64_t nc = kend - (j0 + IB);
+        if (nc > 0)
+            launch_gemm_nt<T>(c, R + (j0 + IB), ldr, R + j0, ldr, A + (j0 + IB) * ld + j0, ld, Mr, nc, IB, 0, nullptr);
+    }
+    if (kend < npad)
+        launch_gemm_nt<T>(c, R + kend, ldr, R + k0, ldr, A + kend * ld + k0, ld, Mr, npad - kend, nbk, 0, nullptr);
+}
+
+template <typename T>
+static void whiten_rows(gpmi_ctx* c, const T* A, int64_t ld, int64_t npad, T* R, int64_t ldr, int64_t Mr) {
+    for (int64_t k0 = 0; k0 < npad; k0 += NB) rows_block_solve<T>(c, A, ld, npad, R, ldr, Mr, k0, std::min<int64_t>(NB, npad - k0));
+}
+
+// Blocked right-looking Cholesky of the row-major lower triangle of A (npad x npad), carrying
+// `extra` rows below it (row npad = y) through the panel solves and trailing updates, so that
+// on exit row npad holds z = L^-1 y (the forward half of cK \ y, GPE.jl:208).
+template <typename T>
+static void cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, int64_t npad, int64_t extra, int* d_info) {
+    const int64_t Mtot = npad + extra;
+    for (int64_t k0 = 0; k0 < npad; k0 += NB) {
+        const int64_t nbk = std::min<int64_t>(NB, npad - k0);
+        const int64_t kend = k0 + nbk;
+        for (int64_t j0 = k0; j0 < kend; j0 += IB) {
+            launch_potf2<T>(c, A + j0 * ld + j0, ld, d_info, j0);
+            const int64_t r0 = j0 + IB;
+            const int64_t M = Mtot - r0;
+            if (M <= 0) continue;
+            launch_trsm_rows<T>(c, A + r0 * ld + j0, ld, A + j0 * ld + j0, ld, M, d_info);
+            const int64_t nc = kend - r0;
+            if (nc > 0)  // in-panel update of the columns still to be factored (K = 64)
+                launch_gemm_nt<T>(c, A + r0 * ld + r0, ld, A + r0 * ld + j0, ld, A + r0 * ld + j0, ld, M, nc, IB, 0, d_info);
+        }
+        const int64_t M = Mtot - kend;
+        if (M > 0 && kend < npad)  // trailing update (SYRK shape, K = nbk): the MFMA-bound bulk
+            launch_gemm_nt<T>(c, A + kend * ld + kend, ld, A + kend * ld + k0, ld, A + kend * ld + k0, ld, M, npad - kend,
+                              nbk, 1, d_info);
+    }
+}
+
+template <typename T>
+static int fit_t(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int64_t n_noise, const void* y_minus_mu,
+                 double* mll_out, void* alpha_out, int64_t* info_out) {
+    gpmi_ctx* c = gp->ctx;
+    const int64_t n = gp->n, npad = gp->npad, ld = gp->ld;
+    T* A = (T*)gp->A;
+    gp->fitted = false;
+    int rc = upload_program(c, k, gp->d);
+    if (rc != GPMI_OK) return rc;
+
+    double nugget = 0.0;
+    const double* d_noise = nullptr;
+    if (n_noise == 1) {
+        nugget = exp(2.0 * log_noise[0]);  // GPE.jl:173
+    } else {
+        std::vector<double> nv((size_t)n);
+        for (int64_t i = 0; i < n; ++i) nv[(size_t)i] = exp(2.0 * log_noise[i]);  // GPE.jl:181-183
+        if (!gp->noise) GPMI_HIP(c, hipMalloc(&gp->noise, (size_t)n * sizeof(double)));
+        GPMI_HIP(c, hipMemcpy(gp->noise, nv.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+        d_noise = gp->noise;
+    }
+    // y - mu -> device (zero padded) and into the carried row npad of A
+    GPMI_HIP(c, hipMemsetAsync(gp->ymu, 0, (size_t)npad * sizeof(T), c->stream));
+    GPMI_HIP(c, hipMemcpyAsync(gp->ymu, y_minus_mu, (size_t)n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    GPMI_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
+
+    launch_cov<T>(c, (const T*)gp->x, n, (const T*)gp->x, n, gp->d, A, ld, npad, npad,
+                  COV_LOWER | COV_NUGGET | COV_PAD_IDENTITY, nugget, d_noise);
+    GPMI_HIP(c, hipMemcpyAsync(A + npad * ld, gp->ymu, (size_t)npad * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+
+    cholesky_lower<T>(c, A, ld, npad, 1, c->d_info);
+
+    {
+        ProfScope ps(c, GPMI_PROF_SOLVE, (double)npad * (double)npad * 0.5 * sizeof(T));
+        for (int64_t j0 = npad - IB; j0 >= 0; j0 -= IB)
+            launch_bsolve_step<T>(c, A, ld, j0, A + npad * ld, (T*)gp->alpha);
+        launch_finalize<T>(c, A, ld, n, (const T*)gp->ymu, (const T*)gp->alpha, c->d_scal);
+    }
+    int h_info = 0;
+    GPMI_HIP(c, hipMemcpyAsync(c->h_scal, c->d_scal, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    GPMI_HIP(c, hipMemcpyAsync(&h_info, c->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    GPMI_HIP(c, hipStreamSynchronize(c->stream));
+    GPMI_HIP(c, hipGetLastError());
+    if (info_out) *info_out = h_info;
+    if (h_info != 0) {
+        c->err = "matrix is not positive definite; Cholesky factorization failed";
+        return GPMI_ENOTPD;
+    }
+    gp->mll = c->h_scal[0];
+    gp->logdet = c->h_scal[1];
+    gp->fitted = true;
+    if (mll_out) *mll_out = gp->mll;
+    if (alpha_out) GPMI_HIP(c, hipMemcpy(alpha_out, gp->alpha, (size_t)n * sizeof(T), hipMemcpyDeviceToHost));
+    return GPMI_OK;
+}
+
+static int grow(gpmi_ctx* c, void** p, int64_t* cap, int64_t need_bytes) {
+    if (*cap >= need_bytes) return GPMI_OK;
+    if (*p) hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    GPMI_HIP(c, hipMalloc(p, (size_t)need_bytes));
+    *cap = need_bytes;
+    return GPMI_OK;
+}
+
+template <typename T>
+static int predict_t(gpmi_gp* gp, const gpmi_kernel* k, int64_t P, const void* xpred, const void* mean_pred,
+                     int full_cov, void* mu_out, void* var_out) {
+    gpmi_ctx* c = gp->ctx;
+    const int64_t n = gp->n, npad = gp->npad, ld = gp->ld;
+    const int d = gp->d;
+    const T* A = (const T*)gp->A;
+    int rc = upload_program(c, k, d);
+    if (rc != GPMI_OK) return rc;
+    const double kdiag = c->h_prog->kdiag;
+
+    int64_t rows_bytes = P * ld * (int64_t)sizeof(T);
+    if ((rc = grow(c, &gp->rows, &gp->rows_cap, rows_bytes)) != GPMI_OK) return rc;
+    if ((rc = grow(c, &gp->xp, &gp->xp_cap, P * d * (int64_t)sizeof(T))) != GPMI_OK) return rc;
+    if ((rc = grow(c, &gp->small, &gp->small_cap, std::max<int64_t>(3 * P, npad) * (int64_t)sizeof(T))) != GPMI_OK) return rc;
+    T* R = (T*)gp->rows;
+    T* xp = (T*)gp->xp;
+    T* d_mean = (T*)gp->small;
+    T* d_mu = d_mean + P;
+    T* d_var = d_mu + P;
+    GPMI_HIP(c, hipMemcpyAsync(xp, xpred, (size_t)(P * d) * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    GPMI_HIP(c, hipMemcpyAsync(d_mean, mean_pred, (size_t)P * sizeof(T), hipMemcpyHostToDevice, c->stream));
+
+    {
+        ProfScope ps(c, GPMI_PROF_PREDICT, (double)npad * (double)npad * (double)P);
+        // K*' (P x npad, one test point per row): cov(k, xtrain, xpred)', GP.jl:44
+        launch_cov<T>(c, xp, P, (const T*)gp->x, n, d, R, ld, P, npad, 0, 0.0, nullptr);
+        launch_row_gemv<T>(c, R, ld, P, n, (const T*)gp->alpha, d_mean, d_mu);  // mu = mx + Kfx' alpha, GP.jl:26
+        whiten_rows<T>(c, A, ld, npad, R, ld, P);                               // Lck = whiten!(Kff, Kfx), GP.jl:27
+        if (!full_cov) launch_row_var<T>(c, R, ld, P, npad, kdiag, d_var);
+    }
+    GPMI_HIP(c, hipMemcpyAsync(mu_out, d_mu, (size_t)P * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    if (!full_cov) {
+        GPMI_HIP(c, hipMemcpyAsync(var_out, d_var, (size_t)P * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+        GPMI_HIP(c, hipStreamSynchronize(c->stream));
+        GPMI_HIP(c, hipGetLastError());
+        return GPMI_OK;
+    }
+    // full covariance: Kpred - Lck'Lck (GP.jl:45,51-54); no clamp in this branch
+    const int64_t ldp = (P + 63) / 64 * 64;
+    T* Kpp = nullptr;
+    GPMI_HIP(c, hipMalloc(&Kpp, (size_t)(P * ldp) * sizeof(T)));
+    launch_cov<T>(c, xp, P, xp, P, d, Kpp, ldp, P, ldp, 0, 0.0, nullptr);
+    launch_gemm_nt<T>(c, Kpp, ldp, R, ld, R, ld, P, P, npad, 0, nullptr);
+    hipError_t e = hipMemcpy2DAsync(var_out, (size_t)P * sizeof(T), Kpp, (size_t)ldp * sizeof(T), (size_t)P * sizeof(T),
+                                    (size_t)P, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(Kpp);
+    GPMI_HIP(c, e);
+    GPMI_HIP(c, hipGetLastError());
+    return GPMI_OK;
+}
+
+template <typename T>
+static int cov_t(gpmi_ctx* c, const gpmi_kernel* k, int d, int64_t n1, const void* x1, int64_t n2, const void* x2,
+                 void* out) {
+    int rc = upload_program(c, k, d);
+    if (rc != GPMI_OK) return rc;
+    const bool sym = (x2 == nullptr);
+    if (sym) n2 = n1;
+    // out is n1 x n2 col-major == row-major [n2][n1]: rows index x2, columns index x1
+    const int64_t ldc = (n1 + 63) / 64 * 64;
+    T *dx1 = nullptr, *dx2 = nullptr, *dC = nullptr;
+    hipError_t e = hipMalloc(&dx1, (size_t)(n1 * d) * sizeof(T));
+    if (e == hipSuccess && !sym) e = hipMalloc(&dx2, (size_t)(n2 * d) * sizeof(T));
+    if (e == hipSuccess) e = hipMalloc(&dC, (size_t)(n2 * ldc) * sizeof(T));
+    if (e == hipSuccess) e = hipMemcpyAsync(dx1, x1, (size_t)(n1 * d) * sizeof(T), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && !sym) e = hipMemcpyAsync(dx2, x2, (size_t)(n2 * d) * sizeof(T), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        launch_cov<T>(c, sym ? dx1 : dx2, n2, dx1, n1, d, dC, ldc, n2, ldc, 0, 0.0, nullptr);
+        e = hipMemcpy2DAsync(out, (size_t)n1 * sizeof(T), dC, (size_t)ldc * sizeof(T), (size_t)n1 * sizeof(T), (size_t)n2,
+                             hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    hipFree(dx1);
+    hipFree(dx2);
+    hipFree(dC);
+    GPMI_HIP(c, e);
+    return GPMI_OK;
+}
+
+// b (n x nrhs col-major) -> rows of R, whiten (and optionally back-substitute), copy back
+template <typename T>
+static int solve_t(gpmi_gp* gp, int64_t nrhs, void* b_inout, bool backward) {
+    gpmi_ctx* c = gp->ctx;
+    const int64_t n = gp->n, npad = gp->npad, ld = gp->ld;
+    const T* A = (const T*)gp->A;
+    int rc;
+    if ((rc = grow(c, &gp->rows, &gp->rows_cap, nrhs * ld * (int64_t)sizeof(T))) != GPMI_OK) return rc;
+    if ((rc = grow(c, &gp->small, &gp->small_cap, npad * (int64_t)sizeof(T))) != GPMI_OK) return rc;
+    T* R = (T*)gp->rows;
+    GPMI_HIP(c, hipMemsetAsync(R, 0, (size_t)(nrhs * ld) * sizeof(T), c->stream));
+    GPMI_HIP(c, hipMemcpy2DAsync(R, (size_t)ld * sizeof(T), b_inout, (size_t)n * sizeof(T), (size_t)n * sizeof(T),
+                                 (size_t)nrhs, hipMemcpyHostToDevice, c->stream));
+    whiten_rows<T>(c, A, ld, npad, R, ld, nrhs);
+    if (backward) {
+        T* tmp = (T*)gp->small;
+        for (int64_t r = 0; r < nrhs; ++r) {
+            for (int64_t j0 = npad - IB; j0 >= 0; j0 -= IB) launch_bsolve_step<T>(c, A, ld, j0, R + r * ld, tmp);
+            GPMI_HIP(c, hipMemcpyAsync(R + r * ld, tmp, (size_t)npad * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+        }
+    }
+    GPMI_HIP(c, hipMemcpy2DAsync(b_inout, (size_t)n * sizeof(T), R, (size_t)ld * sizeof(T), (size_t)n * sizeof(T),
+                                 (size_t)nrhs, hipMemcpyDeviceToHost, c->stream));
+    GPMI_HIP(c, hipStreamSynchronize(c->stream));
+    GPMI_HIP(c, hipGetLastError());
+    return GPMI_OK;
+}
+
+}  // namespace gpmi
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+const char* gpmi_version(void) { return "gpmi 0.1 (gfx950)"; }
+
+int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
+    if (!out) return GPMI_EARG;
+    *out = nullptr;
+    if (n_devices != 1) return GPMI_EARG;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return GPMI_EDEVICE;  // no GPU: no fallback
+    const int dev = device_ids ? device_ids[0] : 0;
+    if (dev < 0 || dev >= count) return GPMI_EARG;
+    gpmi_ctx* c = new gpmi_ctx();
+    c->device = dev;
+    if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(&c->d_prog, sizeof(DevProgram)) != hipSuccess ||
+        hipHostMalloc(&c->h_prog, sizeof(DevProgram)) != hipSuccess || hipMalloc(&c->d_info, sizeof(int)) != hipSuccess ||
+        hipMalloc(&c->d_scal, 8 * sizeof(double)) != hipSuccess ||
+        hipHostMalloc(&c->h_scal, 8 * sizeof(double)) != hipSuccess) {
+        gpmi_ctx_destroy(c);
+        return GPMI_EDEVICE;
+    }
+    *out = c;
+    return GPMI_OK;
+}
+
+void gpmi_ctx_destroy(gpmi_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto& r : c->prof) {
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+    }
+    for (auto e : c->ev_pool) hipEventDestroy(e);
+    if (c->d_prog) hipFree(c->d_prog);
+    if (c->h_prog) hipHostFree(c->h_prog);
+    if (c->d_info) hipFree(c->d_info);
+    if (c->d_scal) hipFree(c->d_scal);
+    if (c->h_scal) hipHostFree(c->h_scal);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* gpmi_last_error(gpmi_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int gpmi_gp_create(gpmi_ctx* c, int dtype, int d, int64_t n, const void* x, gpmi_gp** out) {
+    if (!c) return GPMI_EARG;
+    if (!out || !x || (dtype != 64 && dtype != 32) || d <= 0 || d > MAX_D || n <= 0) {
+        c->err = "gpmi_gp_create: bad argument (dtype must be 64|32, 1 <= d <= 64, n >= 1)";
+        return GPMI_EARG;
+    }
+    *out = nullptr;
+    GPMI_HIP(c, hipSetDevice(c->device));
+    gpmi_gp* gp = new gpmi_gp();
+    gp->ctx = c;
+    gp->dtype = dtype;
+    gp->d = d;
+    gp->n = n;
+    gp->npad = (n + IB - 1) / IB * IB;
+    gp->ld = gp->npad;
+    const size_t es = dtype == 64 ? 8 : 4;
+    hipError_t e = hipMalloc(&gp->x, (size_t)(n * d) * es);
+    if (e == hipSuccess) e = hipMalloc(&gp->A, (size_t)((gp->npad + 8) * gp->ld) * es);
+    if (e == hipSuccess) e = hipMalloc(&gp->ymu, (size_t)gp->npad * es);
+    if (e == hipSuccess) e = hipMalloc(&gp->alpha, (size_t)gp->npad * es);
+    if (e == hipSuccess) e = hipMemcpy(gp->x, x, (size_t)(n * d) * es, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset((char*)gp->A + (size_t)(gp->npad * gp->ld) * es, 0, (size_t)(8 * gp->ld) * es);
+    if (e != hipSuccess) {
+        c->err = std::string("gpmi_gp_create: ") + hipGetErrorString(e);
+        gpmi_gp_destroy(gp);
+        return GPMI_EDEVICE;
+    }
+    *out = gp;
+    return GPMI_OK;
+}
+
+void gpmi_gp_destroy(gpmi_gp* gp) {
+    if (!gp) return;
+    if (gp->ctx) {
+        hipSetDevice(gp->ctx->device);
+        hipStreamSynchronize(gp->ctx->stream);
+    }
+    void* ptrs[] = {gp->x, gp->A, gp->ymu, gp->alpha, gp->noise, gp->rows, gp->xp, gp->small};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    delete gp;
+}
+
+int gpmi_fit(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int64_t n_noise, const void* y_minus_mu,
+             double* mll_out, void* alpha_out, int64_t* info_out) {
+    if (!gp) return GPMI_EARG;
+    gpmi_ctx* c = gp->ctx;
+    if (info_out) *info_out = 0;
+    if (!k || !log_noise || !y_minus_mu || (n_noise != 1 && n_noise != gp->n)) {
+        c->err = "gpmi_fit: bad argument (logNoise must have length 1 or nobs)";
+        return GPMI_EARG;
+    }
+    GPMI_HIP(c, hipSetDevice(c->device));
+    return gp->dtype == 64 ? fit_t<double>(gp, k, log_noise, n_noise, y_minus_mu, mll_out, alpha_out, info_out)
+                           : fit_t<float>(gp, k, log_noise, n_noise, y_minus_mu, mll_out, alpha_out, info_out);
+}
+
+int gpmi_predict(gpmi_gp* gp, const gpmi_kernel* k, int64_t p, const void* xpred, const void* mean_pred, int full_cov,
+                 void* mu_out, void* var_out) {
+    if (!gp) return GPMI_EARG;
+    gpmi_ctx* c = gp->ctx;
+    if (!k || p <= 0 || !xpred || !mean_pred || !mu_out || !var_out) {
+        c->err = "gpmi_predict: bad argument";
+        return GPMI_EARG;
+    }
+    if (!gp->fitted) {
+        c->err = "gpmi_predict: no valid factorisation (call gpmi_fit first)";
+        return GPMI_EARG;
+    }
+    GPMI_HIP(c, hipSetDevice(c->device));
+    return gp->dtype == 64 ? predict_t<double>(gp, k, p, xpred, mean_pred, full_cov, mu_out, var_out)
+                           : predict_t<float>(gp, k, p, xpred, mean_pred, full_cov, mu_out, var_out);
+}
+
+int gpmi_cov(gpmi_ctx* c, const gpmi_kernel* k, int dtype, int d, int64_t n1, const void* x1, int64_t n2, const void* x2,
+             void* out) {
+    if (!c) return GPMI_EARG;
+    if (!k || !x1 || !out || n1 <= 0 || (x2 && n2 <= 0) || (dtype != 64 && dtype != 32)) {
+        c->err = "gpmi_cov: bad argument";
+        return GPMI_EARG;
+    }
+    GPMI_HIP(c, hipSetDevice(c->device));
+    return dtype == 64 ? cov_t<double>(c, k, d, n1, x1, n2, x2, out) : cov_t<float>(c, k, d, n1, x1, n2, x2, out);
+}
+
+static int need_fit(gpmi_gp* gp, const char* who) {
+    if (!gp) return GPMI_EARG;
+    if (!gp->fitted) {
+        gp->ctx->err = std::string(who) + ": no valid factorisation (call gpmi_fit first)";
+        return GPMI_EARG;
+    }
+    return GPMI_OK;
+}
+
+int gpmi_solve(gpmi_gp* gp, int64_t nrhs, void* b) {
+    int rc = need_fit(gp, "gpmi_solve");
+    if (rc) return rc;
+    if (nrhs <= 0 || !b) return GPMI_EARG;
+    GPMI_HIP(gp->ctx, hipSetDevice(gp->ctx->device));
+    return gp->dtype == 64 ? solve_t<double>(gp, nrhs, b, true) : solve_t<float>(gp, nrhs, b, true);
+}
+
+int gpmi_whiten(gpmi_gp* gp, int64_t nrhs, void* b) {
+    int rc = need_fit(gp, "gpmi_whiten");
+    if (rc) return rc;
+    if (nrhs <= 0 || !b) return GPMI_EARG;
+    GPMI_HIP(gp->ctx, hipSetDevice(gp->ctx->device));
+    return gp->dtype == 64 ? solve_t<double>(gp, nrhs, b, false) : solve_t<float>(gp, nrhs, b, false);
+}
+
+int gpmi_logdet(gpmi_gp* gp, double* out) {
+    int rc = need_fit(gp, "gpmi_logdet");
+    if (rc) return rc;
+    if (!out) return GPMI_EARG;
+    *out = gp->logdet;
+    return GPMI_OK;
+}
+
+int gpmi_factor_to_host(gpmi_gp* gp, void* U_out) {
+    int rc = need_fit(gp, "gpmi_factor_to_host");
+    if (rc) return rc;
+    if (!U_out) return GPMI_EARG;
+    gpmi_ctx* c = gp->ctx;
+    GPMI_HIP(c, hipSetDevice(c->device));
+    const size_t es = gp->dtype == 64 ? 8 : 4;
+    const int64_t n = gp->n;
+    // row-major lower L  ==  column-major upper U: a straight 2-D copy, then clear the other triangle
+    GPMI_HIP(c, hipMemcpy2D(U_out, (size_t)n * es, gp->A, (size_t)gp->ld * es, (size_t)n * es, (size_t)n, hipMemcpyDeviceToHost));
+    char* o = (char*)U_out;
+    for (int64_t i = 0; i + 1 < n; ++i) memset(o + ((size_t)i * n + (size_t)i + 1) * es, 0, (size_t)(n - 1 - i) * es);
+    return GPMI_OK;
+}
+
+int gpmi_profile_enable(gpmi_ctx* c, int on) {
+    if (!c) return GPMI_EARG;
+    int rc = drain_profile(c);
+    c->prof_on = on != 0;
+    for (int i = 0; i < GPMI_PROF_NCLASS; ++i) {
+        c->prof_n[i] = 0;
+        c->prof_ms[i] = 0;
+        c->prof_work[i] = 0;
+    }
+    return rc;
+}
+
+int gpmi_profile_get(gpmi_ctx* c, int cls, int64_t* launches, double* total_ms, double* work) {
+    if (!c || cls < 0 || cls >= GPMI_PROF_NCLASS) return GPMI_EARG;
+    int rc = drain_profile(c);
+    if (rc) return rc;
+    if (launches) *launches = c->prof_n[cls];
+    if (total_ms) *total_ms = c->prof_ms[cls];
+    if (work) *work = c->prof_work[cls];
+    c->prof_n[cls] = 0;
+    c->prof_ms[cls] = 0;
+    c->prof_work[cls] = 0;
+    return GPMI_OK;
+}
+
+int gpmi_mfma_peak(gpmi_ctx* c, int dtype, double* tflops_out) {
+    if (!c || !tflops_out || (dtype != 64 && dtype != 32)) return GPMI_EARG;
+    GPMI_HIP(c, hipSetDevice(c->device));
+    return dtype == 64 ? mfma_peak<double>(c, tflops_out) : mfma_peak<float>(c, tflops_out);
+}
+
+}  // extern "C"

@@ -1,0 +1,164 @@
+// common.h — shared declarations of libgpmi.so (gfx950 only; no other target is supported).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/gpmi.h"
+
+namespace gpmi {
+
+// ------------------------------------------------------------------------------------------
+// Blocking constants of the factorisation
+// ------------------------------------------------------------------------------------------
+constexpr int IB = 64;        // inner block: potf2 / trsm granularity; n is padded to a multiple
+constexpr int NB = 256;       // outer block: K of the MFMA trailing update
+constexpr int GEMM_BM = 128;  // trailing-update tile
+constexpr int GEMM_BN = 128;
+constexpr int SUPER = 8;      // tiles per super-tile edge (XCD-aware ordering)
+
+// ------------------------------------------------------------------------------------------
+// Device-side kernel program: the gpmi_kernel postfix descriptor, digested on the host.
+// Every leaf carries a DENSE weight vector over all d input rows (0 on rows a Masked
+// wrapper hides, il2[z] on active ARD rows, 1 on active iso rows), so the device loop
+// is the same for Masked / ARD / iso leaves:  r = sum_k w_k (x_k - y_k)^2.
+// ------------------------------------------------------------------------------------------
+constexpr int MAX_D = 64;
+struct DevLeaf {
+    int32_t op;     // gpmi_op
+    int32_t woff;   // offset of this leaf's d weights inside DevProgram::w (leaf ops only)
+    double s2;      // signal variance
+    double p0;      // iso: l2 (SE/RQ) or l (Matern); unused for ARD
+    double p1;      // RQ: alpha
+};
+struct DevProgram {
+    int32_t n_ops;
+    int32_t d;
+    int32_t has_noise_leaf;
+    int32_t pad_;
+    double kdiag;  // k(x,x): the program evaluated with every leaf at r = 0
+    DevLeaf leaf[GPMI_MAX_OPS];
+    double w[GPMI_MAX_OPS * MAX_D];
+};
+
+// digest + validate; returns GPMI_OK / GPMI_EARG and fills err
+int digest_kernel(const gpmi_kernel* k, int d, DevProgram* out, std::string* err);
+
+// ------------------------------------------------------------------------------------------
+// profiling (event pairs around launches, per class)
+// ------------------------------------------------------------------------------------------
+struct ProfRec {
+    hipEvent_t a, b;
+    int cls;
+    double work;
+};
+
+}  // namespace gpmi
+
+struct gpmi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    gpmi::DevProgram* d_prog = nullptr;  // device copy of the current kernel program
+    gpmi::DevProgram* h_prog = nullptr;  // pinned staging
+    int* d_info = nullptr;               // not-PD flag (1-based pivot)
+    double* d_scal = nullptr;            // small double outputs (mll, logdet, dot)
+    double* h_scal = nullptr;            // pinned
+    bool prof_on = false;
+    std::vector<gpmi::ProfRec> prof;
+    std::vector<hipEvent_t> ev_pool;
+    int64_t prof_n[GPMI_PROF_NCLASS] = {0};
+    double prof_ms[GPMI_PROF_NCLASS] = {0};
+    double prof_work[GPMI_PROF_NCLASS] = {0};
+};
+
+struct gpmi_gp {
+    gpmi_ctx* ctx = nullptr;
+    int dtype = 64;
+    int d = 0;
+    int64_t n = 0;     // observations
+    int64_t npad = 0;  // n rounded up to IB (padding rows/cols are the identity)
+    int64_t ld = 0;    // leading dimension (elements) of the row-major factor
+    void* x = nullptr;       // n x d row-major (== d x n col-major), dtype
+    void* A = nullptr;       // (npad + 8) x ld; lower triangle holds L (K = L L'), row npad holds z = L^-1 y
+    void* ymu = nullptr;     // y - mu, npad elements (zero padded)
+    void* alpha = nullptr;   // npad elements
+    double* noise = nullptr; // per-point nugget (heteroscedastic) or nullptr
+    bool fitted = false;
+    double logdet = 0.0;
+    double mll = 0.0;
+    // scratch for predict / solve, grown on demand
+    void* rows = nullptr;
+    int64_t rows_cap = 0;  // rows allocated (each ld wide)
+    void* xp = nullptr;
+    int64_t xp_cap = 0;
+    void* small = nullptr;  // mean / mu / var staging
+    int64_t small_cap = 0;
+};
+
+namespace gpmi {
+
+// RAII-free helpers -------------------------------------------------------------------------
+#define GPMI_HIP(ctx, call)                                                                     \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                    \
+            return GPMI_EDEVICE;                                                                \
+        }                                                                                       \
+    } while (0)
+
+struct ProfScope {
+    gpmi_ctx* c;
+    int idx = -1;
+    ProfScope(gpmi_ctx* ctx, int cls, double work);
+    ~ProfScope();
+};
+
+// kernel launchers (each enqueues on ctx->stream; T = double | float) -------------------------
+enum CovFlags { COV_LOWER = 1, COV_NUGGET = 2, COV_PAD_IDENTITY = 4 };
+
+// C[i][j] = k(xa_i, xb_j) for i < nrows_total, j < ncols_total (row-major, ld = ldc).
+// rows >= na / cols >= nb are padding: 0, or the identity when COV_PAD_IDENTITY.
+template <typename T>
+void launch_cov(gpmi_ctx* ctx, const T* xa, int64_t na, const T* xb, int64_t nb, int d, T* C, int64_t ldc,
+                int64_t nrows_total, int64_t ncols_total, int flags, double nugget, const double* nugget_vec);
+
+// C[M x N] -= A[M x K] * B[N x K]'   (all row-major; K % 16 == 0 for double, % 32 for float)
+// lower != 0: only tiles that intersect {col <= row} are computed (C is a trailing square).
+template <typename T>
+void launch_gemm_nt(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M,
+                    int64_t N, int64_t K, int lower, const int* info);
+
+// in-place Cholesky of the 64 x 64 block at A (row-major, ld): lower factor; upper part zeroed.
+// On a non-positive pivot j (0-based) writes *info = pivot_base + j + 1 (if *info == 0).
+template <typename T>
+void launch_potf2(gpmi_ctx* ctx, T* A, int64_t ld, int* info, int64_t pivot_base);
+
+// X[M x 64] <- X * L11^-T  (row-wise forward substitution against the 64 x 64 lower L11)
+template <typename T>
+void launch_trsm_rows(gpmi_ctx* ctx, T* X, int64_t ldx, const T* L11, int64_t ldl, int64_t M, const int* info);
+
+// One step of the backward solve  L' alpha = z  for the 64-block starting at j0:
+//   alpha[j0..j0+64) = L_bb^-T z[j0..);  z[0..j0) -= L[j0..j0+64, 0..j0)' alpha_b
+template <typename T>
+void launch_bsolve_step(gpmi_ctx* ctx, const T* A, int64_t ld, int64_t j0, T* z, T* alpha);
+
+// mll / logdet / y'alpha  ->  out[0] = mll, out[1] = logdet, out[2] = y'alpha
+template <typename T>
+void launch_finalize(gpmi_ctx* ctx, const T* A, int64_t ld, int64_t n, const T* y, const T* alpha, double* out);
+
+// mu[p] = mean[p] + sum_j R[p][j] * alpha[j]   (j < n)
+template <typename T>
+void launch_row_gemv(gpmi_ctx* ctx, const T* R, int64_t ldr, int64_t P, int64_t n, const T* alpha, const T* mean,
+                     T* mu);
+// var[p] = max(kdiag - sum_j R[p][j]^2, 0)
+template <typename T>
+void launch_row_var(gpmi_ctx* ctx, const T* R, int64_t ldr, int64_t P, int64_t n, double kdiag, T* var);
+
+// MFMA peak micro-benchmark; returns achieved TFLOP/s
+template <typename T>
+int mfma_peak(gpmi_ctx* ctx, double* tflops);
+
+}  // namespace gpmi

@@ -1,0 +1,282 @@
+// cov.hip — covariance-matrix assembly (replaces cov!/cov_ij/distij of the reference:
+// src/kernels/kernels.jl:39-71, src/kernels/stationary.jl:25-27, src/kernels/distance.jl:41-106,
+// and the leaf cov(k,r) functions listed in include/gpmi.h).
+//
+// Design (gfx950): HBM-write bound — 8 B (fp64) per entry against ~(3d + 45) fp64 VALU ops.
+//   * one 256-thread workgroup = 64 rows x (64 lanes * VEC) columns, VEC = 16 B / sizeof(T):
+//     every wavefront store instruction writes 1 KiB of ONE output row (fully coalesced);
+//   * the d x tile input blocks are staged in LDS with coalesced loads of x: the row block
+//     as [row][k] (read back as wave-uniform broadcasts), the column block transposed
+//     [k][col] so a lane's VEC columns are one conflict-free 16-B read, held in registers
+//     for the whole tile (d <= 16) — no per-entry LDS traffic;
+//   * the kernel tree is a postfix program interpreted with wave-uniform control flow;
+//     (x-y)^2 per input row is computed once per entry and shared by all leaves;
+//   * nugget, identity padding and the lower-triangle tile skip are fused in.
+#include "common.h"
+
+namespace gpmi {
+
+namespace {
+
+constexpr int STK = 6;  // evaluation-stack depth (validated on the host)
+
+template <typename T>
+struct Tr;
+template <>
+struct Tr<double> {
+    static __device__ __forceinline__ double exp_(double x) { return exp(x); }
+    static __device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
+    static __device__ __forceinline__ double pow_(double x, double y) { return pow(x, y); }
+    static __device__ __forceinline__ double fma_(double a, double b, double c) { return fma(a, b, c); }
+    static constexpr double isapprox_rtol = 1.4901161193847656e-08;  // sqrt(eps(Float64))
+};
+template <>
+struct Tr<float> {
+    static __device__ __forceinline__ float exp_(float x) { return expf(x); }
+    static __device__ __forceinline__ float sqrt_(float x) { return sqrtf(x); }
+    static __device__ __forceinline__ float pow_(float x, float y) { return powf(x, y); }
+    static __device__ __forceinline__ float fma_(float a, float b, float c) { return fmaf(a, b, c); }
+    static constexpr float isapprox_rtol = 3.4526698300124393e-04f;  // sqrt(eps(Float32))
+};
+
+// leaf cov(k, r): r is the (weighted) SQUARED distance; Matern leaves take its root
+// (distij(::Euclidean) = sqrt, exact 0 on coincident points because r is exactly 0 there).
+template <typename T>
+__device__ __forceinline__ T leaf_value(int op, T r, T s2, T p0inv, T p1) {
+    switch (op) {
+        case GPMI_K_SE_ISO: return s2 * Tr<T>::exp_((T(-0.5) * r) * p0inv);            // se_iso.jl:39
+        case GPMI_K_SE_ARD: return s2 * Tr<T>::exp_(T(-0.5) * r);                       // se_ard.jl:43
+        case GPMI_K_MAT12_ISO: return s2 * Tr<T>::exp_(-(Tr<T>::sqrt_(r) * p0inv));     // mat12_iso.jl:41
+        case GPMI_K_MAT12_ARD: return s2 * Tr<T>::exp_(-Tr<T>::sqrt_(r));               // mat12_ard.jl:43
+        case GPMI_K_MAT32_ISO:
+        case GPMI_K_MAT32_ARD: {                                                         // mat32_*.jl
+            T s = T(1.7320508075688772935) * Tr<T>::sqrt_(r) * p0inv;
+            return s2 * (T(1) + s) * Tr<T>::exp_(-s);
+        }
+        case GPMI_K_MAT52_ISO:
+        case GPMI_K_MAT52_ARD: {                                                         // mat52_*.jl
+            T s = T(2.2360679774997896964) * Tr<T>::sqrt_(r) * p0inv;
+            return s2 * (T(1) + s + s * s * T(1.0 / 3.0)) * Tr<T>::exp_(-s);
+        }
+        case GPMI_K_RQ_ISO:                                                              // rq_iso.jl:44
+        case GPMI_K_RQ_ARD:                                                              // rq_ard.jl:47
+            return s2 * Tr<T>::pow_(T(1) + r * p0inv, -p1);
+        default: return s2;  // GPMI_K_CONST (const.jl:36)
+    }
+}
+
+template <typename T, int DMAX>
+__global__ __launch_bounds__(256) void cov_kernel(const T* __restrict__ xa, int64_t na, const T* __restrict__ xb,
+                                                  int64_t nb, int d, T* __restrict__ C, int64_t ldc, int64_t nrows,
+                                                  int64_t ncols, const DevProgram* __restrict__ prog, int flags,
+                                                  double nugget, const double* __restrict__ nugget_vec) {
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int TC = 64 * VEC;
+    constexpr int TR = 64;
+    using VT = T __attribute__((ext_vector_type(VEC)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* sa = reinterpret_cast<T*>(smem);  // [TR][d]
+    T* sbT = sa + TR * d;                // [d][TC]
+
+    const int64_t row0 = (int64_t)blockIdx.y * TR;
+    const int64_t col0 = (int64_t)blockIdx.x * TC;
+    if ((flags & COV_LOWER) && col0 > row0 + TR - 1) return;  // tile strictly above the diagonal
+
+    const int tid = threadIdx.x;
+    for (int e = tid; e < TR * d; e += 256) {
+        int r = e / d, k = e - r * d;
+        int64_t gr = row0 + r;
+        gr = gr < na ? gr : na - 1;
+        sa[e] = xa[gr * d + k];
+    }
+    for (int e = tid; e < TC * d; e += 256) {
+        int c = e / d, k = e - c * d;
+        int64_t gc = col0 + c;
+        gc = gc < nb ? gc : nb - 1;
+        sbT[k * TC + c] = xb[gc * d + k];
+    }
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int nops = prog->n_ops;
+    const bool has_noise = prog->has_noise_leaf != 0;
+
+    T xbr[DMAX > 0 ? DMAX : 1][VEC];
+    if constexpr (DMAX > 0) {
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) {
+            if (k < d) {
+                VT v = *reinterpret_cast<const VT*>(&sbT[k * TC + lane * VEC]);
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) xbr[k][q] = v[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) xbr[k][q] = T(0);
+            }
+        }
+    }
+
+    for (int rr = 0; rr < TR / 4; ++rr) {
+        const int row = wave * (TR / 4) + rr;
+        const int64_t grow = row0 + row;
+        if (grow >= nrows) break;
+        const T* sar = sa + row * d;
+
+        T dsq[DMAX > 0 ? DMAX : 1][VEC];
+        if constexpr (DMAX > 0) {
+#pragma unroll
+            for (int k = 0; k < DMAX; ++k) {
+                if (k < d) {
+                    T a = sar[k];
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) {
+                        T df = a - xbr[k][q];
+                        dsq[k][q] = df * df;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) dsq[k][q] = T(0);
+                }
+            }
+        }
+
+        T st[STK][VEC];
+#pragma unroll
+        for (int s = 0; s < STK; ++s)
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) st[s][q] = T(0);
+
+        for (int o = 0; o < nops; ++o) {
+            const int op = prog->leaf[o].op;
+            if (op == GPMI_K_SUM || op == GPMI_K_PROD) {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) st[0][q] = (op == GPMI_K_SUM) ? (st[1][q] + st[0][q]) : (st[1][q] * st[0][q]);
+#pragma unroll
+                for (int s = 1; s < STK - 1; ++s)
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) st[s][q] = st[s + 1][q];
+                continue;
+            }
+            T val[VEC];
+            const T s2 = (T)prog->leaf[o].s2;
+            if (op == GPMI_K_CONST) {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) val[q] = s2;
+            } else if (op == GPMI_K_NOISE) {
+                // noise.jl:31-37: all active rows z satisfy X1[z,i] ≈ X2[z,j]
+                const double* w = prog->w + prog->leaf[o].woff;
+                bool same[VEC];
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) same[q] = true;
+                for (int k = 0; k < d; ++k) {
+                    if (w[k] != 0.0) {
+                        T a = sar[k];
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) {
+                            T b = sbT[k * TC + lane * VEC + q];
+                            T m = fabs(a) > fabs(b) ? fabs(a) : fabs(b);
+                            bool ok = (a == b) || (fabs(a - b) <= Tr<T>::isapprox_rtol * m);
+                            same[q] = same[q] && ok;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) val[q] = same[q] ? s2 : T(0);
+            } else {
+                const double* w = prog->w + prog->leaf[o].woff;
+                T r[VEC];
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) r[q] = T(0);
+                if constexpr (DMAX > 0) {
+#pragma unroll
+                    for (int k = 0; k < DMAX; ++k) {
+                        if (k < d) {
+                            T wk = (T)w[k];
+#pragma unroll
+                            for (int q = 0; q < VEC; ++q) r[q] = Tr<T>::fma_(dsq[k][q], wk, r[q]);
+                        }
+                    }
+                } else {
+                    for (int k = 0; k < d; ++k) {
+                        T wk = (T)w[k];
+                        T a = sar[k];
+                        VT bv = *reinterpret_cast<const VT*>(&sbT[k * TC + lane * VEC]);
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) {
+                            T df = a - bv[q];
+                            r[q] = Tr<T>::fma_(df * df, wk, r[q]);
+                        }
+                    }
+                }
+                const T p0inv = (T)prog->leaf[o].p0;
+                const T p1 = (T)prog->leaf[o].p1;
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) val[q] = leaf_value<T>(op, r[q], s2, p0inv, p1);
+            }
+            // push
+#pragma unroll
+            for (int s = STK - 1; s > 0; --s)
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) st[s][q] = st[s - 1][q];
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) st[0][q] = val[q];
+        }
+        (void)has_noise;
+
+        const int64_t gcol0 = col0 + (int64_t)lane * VEC;
+        VT out;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            const int64_t gcol = gcol0 + q;
+            T v = st[0][q];
+            if (grow >= na || gcol >= nb) {
+                v = ((flags & COV_PAD_IDENTITY) && grow == gcol) ? T(1) : T(0);
+            } else if ((flags & COV_NUGGET) && grow == gcol) {
+                v += nugget_vec ? (T)nugget_vec[grow] : (T)nugget;  // GPE.jl:173,181-183 / GP.jl:104-108
+            }
+            out[q] = v;
+        }
+        if (gcol0 + VEC <= ncols) *reinterpret_cast<VT*>(&C[grow * ldc + gcol0]) = out;
+    }
+}
+
+template <typename T, int DMAX>
+void launch_cov_t(gpmi_ctx* ctx, const T* xa, int64_t na, const T* xb, int64_t nb, int d, T* C, int64_t ldc,
+                  int64_t nrows_total, int64_t ncols_total, int flags, double nugget, const double* nugget_vec) {
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int TC = 64 * VEC;
+    constexpr int TR = 64;
+    dim3 grid((unsigned)((ncols_total + TC - 1) / TC), (unsigned)((nrows_total + TR - 1) / TR));
+    size_t lds = (size_t)(TR + TC) * d * sizeof(T);
+    auto kern = cov_kernel<T, DMAX>;
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, xa, na, xb, nb, d, C, ldc, nrows_total, ncols_total,
+                       ctx->d_prog, flags, nugget, nugget_vec);
+}
+
+}  // namespace
+
+template <typename T>
+void launch_cov(gpmi_ctx* ctx, const T* xa, int64_t na, const T* xb, int64_t nb, int d, T* C, int64_t ldc,
+                int64_t nrows_total, int64_t ncols_total, int flags, double nugget, const double* nugget_vec) {
+    // algorithmic bytes: one write per generated entry (lower-triangle tiles only when COV_LOWER)
+    double entries = (flags & COV_LOWER) ? 0.5 * (double)nrows_total * ((double)ncols_total + 1.0)
+                                         : (double)nrows_total * (double)ncols_total;
+    ProfScope ps(ctx, GPMI_PROF_COV, entries * sizeof(T));
+    if (d <= 4)
+        launch_cov_t<T, 4>(ctx, xa, na, xb, nb, d, C, ldc, nrows_total, ncols_total, flags, nugget, nugget_vec);
+    else if (d <= 8)
+        launch_cov_t<T, 8>(ctx, xa, na, xb, nb, d, C, ldc, nrows_total, ncols_total, flags, nugget, nugget_vec);
+    else if (d <= 16)
+        launch_cov_t<T, 16>(ctx, xa, na, xb, nb, d, C, ldc, nrows_total, ncols_total, flags, nugget, nugget_vec);
+    else
+        launch_cov_t<T, 0>(ctx, xa, na, xb, nb, d, C, ldc, nrows_total, ncols_total, flags, nugget, nugget_vec);
+}
+
+template void launch_cov<double>(gpmi_ctx*, const double*, int64_t, const double*, int64_t, int, double*, int64_t,
+                                 int64_t, int64_t, int, double, const double*);
+template void launch_cov<float>(gpmi_ctx*, const float*, int64_t, const float*, int64_t, int, float*, int64_t, int64_t,
+                                int64_t, int, double, const double*);
+
+}  // namespace gpmi

@@ -1,0 +1,153 @@
+"""ctypes binding of libgpmi.so (include/gpmi.h).
+
+This is the same binding a Julia `ccall` shim makes (see ../julia/GPMI355X.jl and
+INTEGRATION.md).  There is deliberately NO fallback: if the HIP library is missing
+or no gfx950 device is present, importing the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgpmi.so")
+
+GPMI_OK, GPMI_ENOTPD, GPMI_EARG, GPMI_EDEVICE = 0, 1, 2, 3
+PROF_SYRK, PROF_COV, PROF_PANEL, PROF_SOLVE, PROF_PREDICT = range(5)
+
+# every symbol include/gpmi.h declares (tests/test_abi.py checks header == this list == library)
+SYMBOLS = [
+    "gpmi_ctx_create", "gpmi_ctx_destroy", "gpmi_last_error", "gpmi_version",
+    "gpmi_gp_create", "gpmi_gp_destroy", "gpmi_fit", "gpmi_predict", "gpmi_cov",
+    "gpmi_solve", "gpmi_whiten", "gpmi_logdet", "gpmi_factor_to_host",
+    "gpmi_profile_enable", "gpmi_profile_get", "gpmi_mfma_peak",
+]
+
+
+class GpmiKernel(C.Structure):
+    _fields_ = [
+        ("n_ops", C.c_int32),
+        ("ops", C.POINTER(C.c_int32)),
+        ("dims_off", C.POINTER(C.c_int32)),
+        ("dims", C.POINTER(C.c_int32)),
+        ("params", C.POINTER(C.c_double)),
+        ("n_params", C.c_int32),
+    ]
+
+
+class PosDefException(ArithmeticError):
+    """LinearAlgebra.PosDefException(info) — raised where the reference's cholesky! throws (src/GP.jl:110)."""
+
+    def __init__(self, info):
+        super().__init__(f"matrix is not positive definite; Cholesky factorization failed (info={info}).")
+        self.info = int(info)
+
+
+class ArgumentError(ValueError):
+    """Julia ArgumentError (src/GPE.jl:42,129; src/GP.jl:65,103; src/kernels/kernels.jl:34)."""
+
+
+class DeviceError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """dlopen libgpmi.so and declare prototypes.  Fails loudly when the extension is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i64, dbl = C.c_void_p, C.c_int64, C.c_double
+    lib.gpmi_version.restype = C.c_char_p
+    lib.gpmi_last_error.restype = C.c_char_p
+    lib.gpmi_last_error.argtypes = [vp]
+    lib.gpmi_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
+    lib.gpmi_ctx_destroy.argtypes = [vp]
+    lib.gpmi_ctx_destroy.restype = None
+    lib.gpmi_gp_create.argtypes = [vp, C.c_int, C.c_int, i64, vp, C.POINTER(vp)]
+    lib.gpmi_gp_destroy.argtypes = [vp]
+    lib.gpmi_gp_destroy.restype = None
+    lib.gpmi_fit.argtypes = [vp, C.POINTER(GpmiKernel), C.POINTER(dbl), i64, vp, C.POINTER(dbl), vp, C.POINTER(i64)]
+    lib.gpmi_predict.argtypes = [vp, C.POINTER(GpmiKernel), i64, vp, vp, C.c_int, vp, vp]
+    lib.gpmi_cov.argtypes = [vp, C.POINTER(GpmiKernel), C.c_int, C.c_int, i64, vp, i64, vp, vp]
+    lib.gpmi_solve.argtypes = [vp, i64, vp]
+    lib.gpmi_whiten.argtypes = [vp, i64, vp]
+    lib.gpmi_logdet.argtypes = [vp, C.POINTER(dbl)]
+    lib.gpmi_factor_to_host.argtypes = [vp, vp]
+    lib.gpmi_profile_enable.argtypes = [vp, C.c_int]
+    lib.gpmi_profile_get.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(dbl), C.POINTER(dbl)]
+    lib.gpmi_mfma_peak.argtypes = [vp, C.c_int, C.POINTER(dbl)]
+    _lib = lib
+    return lib
+
+
+class Context:
+    """gpmi_ctx: one per process and GPU."""
+
+    _default = {}
+
+    def __init__(self, device=0):
+        lib = load()
+        h = C.c_void_p()
+        ids = (C.c_int * 1)(int(device))
+        rc = lib.gpmi_ctx_create(1, ids, C.byref(h))
+        if rc != GPMI_OK:
+            raise DeviceError(
+                f"gpmi_ctx_create failed (rc={rc}): no usable gfx950 device {device}. "
+                "libgpmi has no CPU backend by design.")
+        self.h = h
+        self.device = int(device)
+
+    @classmethod
+    def default(cls, device=None):
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) if "GPMI_DEVICE" not in os.environ else int(os.environ["GPMI_DEVICE"])
+        if device not in cls._default:
+            cls._default[device] = cls(device)
+        return cls._default[device]
+
+    def check(self, rc, info=0):
+        if rc == GPMI_OK:
+            return
+        msg = load().gpmi_last_error(self.h).decode()
+        if rc == GPMI_ENOTPD:
+            raise PosDefException(info)
+        if rc == GPMI_EARG:
+            raise ArgumentError(msg)
+        raise DeviceError(msg)
+
+    def profile_enable(self, on=True):
+        self.check(load().gpmi_profile_enable(self.h, 1 if on else 0))
+
+    def profile_get(self, cls_id):
+        n, ms, work = C.c_int64(), C.c_double(), C.c_double()
+        self.check(load().gpmi_profile_get(self.h, cls_id, C.byref(n), C.byref(ms), C.byref(work)))
+        return n.value, ms.value, work.value
+
+    def mfma_peak(self, dtype=64):
+        out = C.c_double()
+        self.check(load().gpmi_mfma_peak(self.h, dtype, C.byref(out)))
+        return out.value
+
+    def close(self):
+        if self.h:
+            load().gpmi_ctx_destroy(self.h)
+            self.h = None
+
+
+def np_dtype(bits):
+    return np.float64 if bits == 64 else np.float32
+
+
+def colmajor(x, dtype):
+    """d x n array -> Fortran-contiguous buffer (what Julia hands to ccall)."""
+    return np.asfortranarray(np.asarray(x, dtype=dtype))

@@ -1,0 +1,270 @@
+"""GPE / GP() / update_mll! / predict_f — the reference's exact-GP API surface
+(src/GPE.jl, src/GP.jl) driving the MI355X path through the C ABI.
+
+Mirrors, with the same argument meaning and error behaviour:
+    GP(x, y, mean, kernel, logNoise=-2.0)      src/GPE.jl:92-120
+    GPE.fit!(gp, x, y)                         src/GPE.jl:128-138
+    update_cK! / update_mll!(gp; noise, domean, kern)   src/GPE.jl:169-212
+    initialise_target! / update_target!        src/GPE.jl:346-365 (no priors: target == mll)
+    predict_f / predict_y (full_cov)           src/GP.jl:64-84, src/GPE.jl:408-416
+    get_params / set_params! / num_params      src/GPE.jl:447-512
+    optimize!                                  src/optimize.jl:19-97 (error contract only)
+The covariance strategy (src/GP.jl:10-20) is what this module replaces: `HIPPDMat`
+plays the AbstractPDMat role of `gp.cK` (`\\`, whiten!, logdet, cholfactors).
+
+Python has no `!`: update_mll!(gp) is `update_mll(gp)` etc.
+x is d × N (one observation per column) exactly as in the reference.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from .kernels import Kernel
+from .means import Mean, MeanZero
+
+
+class HIPPDMat:
+    """Device-resident (K + σ²I) = UᵀU.  AbstractPDMat surface used by the reference:
+    `cK \\ y` (GPE.jl:208), logdet (GPE.jl:210), whiten! (GP.jl:27), cholfactors (GP.jl:89)."""
+
+    def __init__(self, ctx, x_colmajor, bits):
+        self.ctx = ctx
+        self.bits = bits
+        d, n = x_colmajor.shape
+        self.dim, self.n = d, n
+        h = C.c_void_p()
+        ctx.check(_lib.load().gpmi_gp_create(ctx.h, bits, d, n, x_colmajor.ctypes.data, C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None) and self.ctx.h:
+                _lib.load().gpmi_gp_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def _rhs(self, b):
+        dt = _lib.np_dtype(self.bits)
+        b = np.array(b, dtype=dt, order="F", copy=True)
+        if b.shape[0] != self.n:
+            raise _lib.ArgumentError("right-hand side has the wrong number of rows")
+        return b
+
+    def solve(self, b):  # cK \ b
+        b = self._rhs(b)
+        nrhs = 1 if b.ndim == 1 else b.shape[1]
+        self.ctx.check(_lib.load().gpmi_solve(self.h, nrhs, b.ctypes.data))
+        return b
+
+    def whiten(self, b):  # L⁻¹ b, L = Uᵀ
+        b = self._rhs(b)
+        nrhs = 1 if b.ndim == 1 else b.shape[1]
+        self.ctx.check(_lib.load().gpmi_whiten(self.h, nrhs, b.ctypes.data))
+        return b
+
+    def logdet(self):
+        out = C.c_double()
+        self.ctx.check(_lib.load().gpmi_logdet(self.h, C.byref(out)))
+        return out.value
+
+    def cholfactors(self):
+        """Upper factor U (n × n), as Cholesky(factors, 'U', 0) holds it (GPE.jl:60)."""
+        U = np.empty((self.n, self.n), dtype=_lib.np_dtype(self.bits), order="F")
+        self.ctx.check(_lib.load().gpmi_factor_to_host(self.h, U.ctypes.data))
+        return U
+
+
+class GPE:
+    def __init__(self, x, y, mean=None, kernel=None, logNoise=-2.0, dtype=np.float64, ctx=None):
+        if kernel is None or not isinstance(kernel, Kernel):
+            raise _lib.ArgumentError("a Kernel is required")
+        self.mean = mean if mean is not None else MeanZero()
+        if not isinstance(self.mean, Mean):
+            raise _lib.ArgumentError("mean must be a Mean")
+        self.kernel = kernel
+        self.logNoise = np.asarray(logNoise, dtype=np.float64).copy() if np.ndim(logNoise) else float(logNoise)
+        self.bits = 64 if np.dtype(dtype) == np.float64 else 32
+        self.ctx = ctx if ctx is not None else _lib.Context.default()
+        self.alpha = None
+        self.mll = float("nan")
+        self.target = float("nan")
+        self.fit(x, y)
+
+    # -- fit!(gp, x, y) : GPE.jl:128-138 --------------------------------------
+    def fit(self, x, y):
+        x = np.asarray(x)
+        if x.ndim == 1:
+            x = x[None, :]  # x::Vector -> x' row matrix (GPE.jl:96-97)
+        y = np.asarray(y, dtype=np.float64)
+        if y.ndim != 1 or y.shape[0] != x.shape[1]:
+            raise _lib.ArgumentError("Input and output observations must have consistent dimensions.")
+        self.x = _lib.colmajor(x, _lib.np_dtype(self.bits))
+        self.y = y
+        self.dim, self.nobs = self.x.shape
+        self.cK = HIPPDMat(self.ctx, self.x, self.bits)  # alloc_cK (GP.jl:14-20)
+        self.initialise_target()
+        return self
+
+    # -- update_mll! : GPE.jl:202-212 ------------------------------------------
+    def update_mll(self, noise=True, domean=True, kern=True):
+        dt = _lib.np_dtype(self.bits)
+        mu = self.mean.mean(self.x)
+        ymu = np.ascontiguousarray(self.y - mu, dtype=dt)
+        ln = np.atleast_1d(np.asarray(self.logNoise, dtype=np.float64))
+        if ln.shape[0] not in (1, self.nobs):
+            raise _lib.ArgumentError("logNoise must be a scalar or have one entry per observation")
+        kd, keep = self.kernel.descriptor(self.dim)
+        alpha = np.empty(self.nobs, dtype=dt)
+        mll = C.c_double()
+        info = C.c_int64()
+        rc = _lib.load().gpmi_fit(self.cK.h, C.byref(kd), ln.ctypes.data_as(C.POINTER(C.c_double)), ln.shape[0],
+                                  ymu.ctypes.data, C.byref(mll), alpha.ctypes.data, C.byref(info))
+        del keep
+        self.ctx.check(rc, info.value)
+        self.alpha = alpha
+        self.mll = mll.value
+        return self
+
+    def initialise_target(self):  # GPE.jl:346-350 (no priors on this path)
+        self.update_mll()
+        self.target = self.mll
+        return self
+
+    def update_target(self, **kw):  # GPE.jl:361-365
+        self.update_mll(**kw)
+        self.target = self.mll
+        return self
+
+    # -- predict : GP.jl:64-84, GPE.jl:408-416 ---------------------------------
+    def predict_f(self, x, full_cov=False):
+        x = np.asarray(x)
+        if x.ndim == 1:
+            x = x[None, :]
+        if x.shape[0] != self.dim:
+            raise _lib.ArgumentError("Gaussian Process object and input observations do not have consistent dimensions")
+        dt = _lib.np_dtype(self.bits)
+        xp = _lib.colmajor(x, dt)
+        P = xp.shape[1]
+        mx = np.ascontiguousarray(self.mean.mean(xp), dtype=dt)
+        mu = np.empty(P, dtype=dt)
+        var = np.empty((P, P), dtype=dt, order="F") if full_cov else np.empty(P, dtype=dt)
+        kd, keep = self.kernel.descriptor(self.dim)
+        rc = _lib.load().gpmi_predict(self.cK.h, C.byref(kd), P, xp.ctypes.data, mx.ctypes.data,
+                                      1 if full_cov else 0, mu.ctypes.data, var.ctypes.data)
+        del keep
+        self.ctx.check(rc)
+        return mu, var
+
+    def noise_variance(self):  # GPE.jl:269-271
+        return np.exp(2.0 * np.asarray(self.logNoise))
+
+    def predict_y(self, x, full_cov=False):
+        mu, s2 = self.predict_f(x, full_cov=full_cov)
+        nv = self.noise_variance()
+        if full_cov:
+            return mu, s2 + nv * np.eye(s2.shape[0], dtype=s2.dtype)
+        return mu, s2 + nv
+
+    # -- parameters : GPE.jl:447-512 -------------------------------------------
+    def get_params(self, noise=True, domean=True, kern=True):
+        p = []
+        if noise:
+            p += list(np.atleast_1d(self.logNoise))
+        if domean:
+            p += list(self.mean.get_params())
+        if kern:
+            p += list(self.kernel.get_params())
+        return [float(v) for v in p]
+
+    def num_params(self, **kw):
+        return len(self.get_params(**kw))
+
+    def set_params(self, hyp, noise=True, domean=True, kern=True):
+        hyp = [float(v) for v in hyp]
+        i = 0
+        if noise:
+            nn = 1 if np.ndim(self.logNoise) == 0 else len(self.logNoise)
+            self.logNoise = hyp[0] if nn == 1 and np.ndim(self.logNoise) == 0 else np.asarray(hyp[:nn])
+            i += nn
+        nm = self.mean.num_params()
+        if domean and nm > 0:
+            self.mean.set_params(hyp[i:i + nm])
+            i += nm
+        if kern:
+            nk = self.kernel.num_params()
+            self.kernel.set_params(hyp[i:i + nk])
+            i += nk
+
+
+def GP(x, y, mean=None, kernel=None, logNoise=-2.0, **kw):
+    """GP(x, y, mean, kernel, logNoise) — src/GPE.jl:119-120."""
+    return GPE(x, y, mean, kernel, logNoise, **kw)
+
+
+# functional spellings of the reference's exported verbs
+def update_mll(gp, **kw):
+    return gp.update_mll(**kw)
+
+
+def update_target(gp, **kw):
+    return gp.update_target(**kw)
+
+
+def predict_f(gp, x, full_cov=False):
+    return gp.predict_f(x, full_cov=full_cov)
+
+
+def predict_y(gp, x, full_cov=False):
+    return gp.predict_y(x, full_cov=full_cov)
+
+
+def get_params(gp, **kw):
+    return gp.get_params(**kw)
+
+
+def set_params(gp, hyp, **kw):
+    return gp.set_params(hyp, **kw)
+
+
+def optimize(gp, noise=True, domean=True, kern=True, method="L-BFGS-B", options=None, eps=1e-5):
+    """optimize!(gp) — src/optimize.jl:19-37 with its error contract (:48-58, :74-83): a
+    PosDefException / ArgumentError during an evaluation restores the previous parameters
+    and the point is reported as infeasible (Inf).
+
+    The analytic gradient path (update_dmll!, src/GPE.jl:298-324) is SURVEY.md §8f-1
+    ("next"); until it is on the device this driver differentiates the device mll by
+    central differences (2·nparams fits per gradient)."""
+    from scipy.optimize import minimize
+
+    kw = dict(noise=noise, domean=domean, kern=kern)
+
+    def target(hyp):
+        prev = gp.get_params(**kw)
+        try:
+            gp.set_params(hyp, **kw)
+            gp.update_target()
+            return -gp.target
+        except (_lib.PosDefException, _lib.ArgumentError):
+            gp.set_params(prev, **kw)
+            return math.inf
+
+    def grad(hyp):
+        g = np.zeros(len(hyp))
+        for i in range(len(hyp)):
+            hp = np.array(hyp, dtype=float)
+            hm = hp.copy()
+            hp[i] += eps
+            hm[i] -= eps
+            g[i] = (target(hp) - target(hm)) / (2 * eps)
+        return g
+
+    x0 = np.asarray(gp.get_params(**kw), dtype=float)
+    res = minimize(target, x0, jac=grad, method=method, options=options or {"maxiter": 20})
+    gp.set_params(res.x, **kw)
+    gp.update_target()
+    return res

@@ -140,7 +140,8 @@ def assemble(spec, x, log_noise):
     """cov! + nugget of update_cK! (no Cholesky)."""
     x = _colmajor(x)
     d, n = x.shape
-    k = _as_struct(flatten(spec, d))
+    flat = flatten(spec, d)  # keep the arrays alive while C holds pointers into them
+    k = _as_struct(flat)
     ln = np.atleast_1d(np.asarray(log_noise, dtype=np.float64))
     out = np.empty((n, n), order="F")
     lib().oracle_assemble(C.byref(k), d, n, x.ctypes.data, ln.ctypes.data, len(ln), out.ctypes.data)
