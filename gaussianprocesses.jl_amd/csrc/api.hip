@@ -421,10 +421,14 @@ int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
         hipMalloc(&c->d_prog, sizeof(DevProgram)) != hipSuccess ||
         hipHostMalloc(&c->h_prog, sizeof(DevProgram)) != hipSuccess || hipMalloc(&c->d_info, sizeof(int)) != hipSuccess ||
         hipMalloc(&c->d_scal, 8 * sizeof(double)) != hipSuccess ||
-        hipHostMalloc(&c->h_scal, 8 * sizeof(double)) != hipSuccess) {
+        hipHostMalloc(&c->h_scal, 8 * sizeof(double)) != hipSuccess ||
+        hipMalloc(&c->d_queue, 64 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(c->d_queue, 0, 64 * sizeof(unsigned long long)) != hipSuccess) {
         gpmi_ctx_destroy(c);
         return GPMI_EDEVICE;
     }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
     *out = c;
     return GPMI_OK;
 }
@@ -443,6 +447,7 @@ void gpmi_ctx_destroy(gpmi_ctx* c) {
     if (c->d_info) hipFree(c->d_info);
     if (c->d_scal) hipFree(c->d_scal);
     if (c->h_scal) hipHostFree(c->h_scal);
+    if (c->d_queue) hipFree(c->d_queue);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -605,6 +610,15 @@ int gpmi_profile_get(gpmi_ctx* c, int cls, int64_t* launches, double* total_ms, 
     c->prof_ms[cls] = 0;
     c->prof_work[cls] = 0;
     return GPMI_OK;
+}
+
+int gpmi_bench_gemm(gpmi_ctx* c, int dtype, int64_t M, int64_t N, int64_t K, int lower, int variant, int iters,
+                    double* ms_out) {
+    if (!c || !ms_out || (dtype != 64 && dtype != 32) || M <= 0 || N <= 0 || K <= 0 || iters <= 0 || N > M) return GPMI_EARG;
+    if (K % 64 != 0) return GPMI_EARG;
+    GPMI_HIP(c, hipSetDevice(c->device));
+    return dtype == 64 ? gemm_bench<double>(c, M, N, K, lower, variant, iters, ms_out)
+                       : gemm_bench<float>(c, M, N, K, lower, variant, iters, ms_out);
 }
 
 int gpmi_mfma_peak(gpmi_ctx* c, int dtype, double* tflops_out) {

@@ -65,6 +65,9 @@ struct gpmi_ctx {
     int* d_info = nullptr;               // not-PD flag (1-based pivot)
     double* d_scal = nullptr;            // small double outputs (mll, logdet, dot)
     double* h_scal = nullptr;            // pinned
+    unsigned long long* d_queue = nullptr;  // 8 per-XCD tile-queue words, 64 B apart (never reset)
+    unsigned long long queue_base[8] = {0}; // value of each word when the next launch starts
+    int num_cus = 256;
     bool prof_on = false;
     std::vector<gpmi::ProfRec> prof;
     std::vector<hipEvent_t> ev_pool;
@@ -156,6 +159,10 @@ void launch_row_gemv(gpmi_ctx* ctx, const T* R, int64_t ldr, int64_t P, int64_t 
 // var[p] = max(kdiag - sum_j R[p][j]^2, 0)
 template <typename T>
 void launch_row_var(gpmi_ctx* ctx, const T* R, int64_t ldr, int64_t P, int64_t n, double kdiag, T* var);
+
+// isolated timing of the update kernel on random operands (variant 0 = product kernel)
+template <typename T>
+int gemm_bench(gpmi_ctx* ctx, int64_t M, int64_t N, int64_t K, int lower, int variant, int iters, double* ms_out);
 
 // MFMA peak micro-benchmark; returns achieved TFLOP/s
 template <typename T>

@@ -2,8 +2,19 @@
 //
 // This is the Cholesky trailing update (the dpotrf/dsyrk work behind make_posdef!,
 // src/GP.jl:110) and the whiten! update of predict (src/GP.jl:27): in the row-major
-// lower factor both operands have K contiguous ("NT" form), which is exactly the
-// v_mfma_{f64,f32}_16x16x4 operand layout: lane l supplies A[row = l & 15][k = l >> 4].
+// lower factor both operands have K contiguous ("NT" form), which is exactly the MFMA
+// operand layout: lane l supplies A[row = l & 15][k = l >> 4].
+//
+// FP64 instruction choice (measured on this MI355X, tools/mfma_bench.hip, profiles/r01_mfma_*):
+//   v_mfma_f64_16x16x4_f64      tops out at 48 TFLOP/s chip-wide (~105 cycles / instruction / SIMD);
+//   v_mfma_f64_4x4x4_4b_f64     sustains 75-76 TFLOP/s (97 % of the 78.6 TF FP64-matrix spec).
+// The 4x4x4 form multiplies four independent 4x4 blocks: block b of A (rows 4b..4b+3 of the
+// 16-row fragment) meets block b of B.  Its cbsz/abid broadcast controls are ignored for f64
+// (probed: tools/mfma_probe.hip), so a full 16 x 16 x 4 product is built from FOUR of them with
+// the B fragment rotated by 0/4/8/12 lanes inside each 16-lane row (v_mov_b32_dpp row_ror — VALU
+// work that issues in the shadow of the MFMAs):
+//   acc[r][lane = j + 4b + 16i]  =  C[row 4b + i][col 4((b + r) & 3) + j],   r = 0..3.
+// FP32 uses v_mfma_f32_16x16x4_f32 directly (149.5 TF measured, 95 % of peak).
 //
 // Structure per 256-thread workgroup (4 wavefronts, 2 x 2):
 //   128 x 128 output tile, each wavefront a 64 x 64 sub-tile = 4 x 4 MFMA tiles whose
@@ -13,10 +24,14 @@
 //   fragments are read with ds_read_b128 (E consecutive k per lane — the k permutation is
 //   identical for A and B, so the dot products are unchanged);
 //   2 workgroups per CU (launch_bounds(256, 2)): one group's epilogue / global loads hide
-//   under the other's MFMA stream, which is the only busy pipe (64 MFMAs per slab per wave).
+//   under the other's MFMA stream, which is the only busy pipe.
 // Tile order is XCD-aware: block b runs on XCD b % 8, so each XCD gets a contiguous run of
 // 8 x 8 super-tiles (64 concurrent tiles share 16 operand panels in that XCD's 4 MiB L2).
+#include <algorithm>
+#include <vector>
+
 #include "common.h"
+#include "tile_order.h"
 
 namespace gpmi {
 
@@ -24,210 +39,410 @@ namespace {
 
 template <typename T>
 struct Mfma;
+template <int CTRL>
+__device__ __forceinline__ double dpp_rot(double x) {
+    // rotate within each 16-lane row; row_ror:n gives out[l] = in[(l - n) & 15]  (probed, tools/dpp_probe.hip)
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
 template <>
 struct Mfma<double> {
-    using Acc = double __attribute__((ext_vector_type(4)));
     using Vec = double __attribute__((ext_vector_type(2)));
     static constexpr int E = 2;
     static constexpr int BK = 16;
-    static __device__ __forceinline__ Acc mma(double a, double b, Acc c) {
-        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    static constexpr int NR = 4;  // accumulator registers per 16 x 16 tile
+    struct Acc {
+        double v[4];
+    };
+    // one 16 x 16 x 4 product = four 4x4x4 (4-block) MFMAs against B rotated by r blocks
+    static __device__ __forceinline__ void rotations(double b, double (&br)[4]) {
+        br[0] = b;
+        br[1] = dpp_rot<0x12C>(b);  // row_ror:12 -> lane l reads l + 4  (block b + 1)
+        br[2] = dpp_rot<0x128>(b);  // row_ror:8                        (block b + 2)
+        br[3] = dpp_rot<0x124>(b);  // row_ror:4  -> lane l reads l + 12 (block b + 3)
     }
-    // v_mfma_f64_16x16x4_f64 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
-    static __device__ __forceinline__ int row_of(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+    static __device__ __forceinline__ void mma(double a, const double (&br)[4], Acc& c) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c.v[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, br[r], c.v[r], 0, 0, 0);
+    }
+    // acc register r of lane (j + 4b + 16i) holds C[row 4b + i][col 4((b + r) & 3) + j]
+    static __device__ __forceinline__ int row_of(int lane, int) { return ((lane >> 2) & 3) * 4 + (lane >> 4); }
+    static __device__ __forceinline__ int col_of(int lane, int r) { return ((((lane >> 2) & 3) + r) & 3) * 4 + (lane & 3); }
 };
 template <>
 struct Mfma<float> {
-    using Acc = float __attribute__((ext_vector_type(4)));
     using Vec = float __attribute__((ext_vector_type(4)));
     static constexpr int E = 4;
     static constexpr int BK = 32;
-    static __device__ __forceinline__ Acc mma(float a, float b, Acc c) {
-        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    static constexpr int NR = 4;
+    using V4 = float __attribute__((ext_vector_type(4)));
+    struct Acc {
+        V4 v;
+    };
+    static __device__ __forceinline__ void rotations(float b, float (&br)[4]) { br[0] = b; }
+    static __device__ __forceinline__ void mma(float a, const float (&br)[4], Acc& c) {
+        c.v = __builtin_amdgcn_mfma_f32_16x16x4f32(a, br[0], c.v, 0, 0, 0);
     }
     // v_mfma_f32_16x16x4_f32 C/D map: col = lane & 15, row = 4 * (lane >> 4) + reg
     static __device__ __forceinline__ int row_of(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+    static __device__ __forceinline__ int col_of(int lane, int) { return lane & 15; }
+};
+template <typename T>
+__device__ __forceinline__ T acc_get(const typename Mfma<T>::Acc& a, int r);
+template <>
+__device__ __forceinline__ double acc_get<double>(const Mfma<double>::Acc& a, int r) { return a.v[r]; }
+template <>
+__device__ __forceinline__ float acc_get<float>(const Mfma<float>::Acc& a, int r) { return a.v[r]; }
+
+// VARIANT bits are ablation switches used only by gpmi_bench_gemm (0 = the product kernel):
+//   1 no C read in the epilogue   2 no epilogue at all   4 no global loads inside the K loop
+//   8 no DPP rotations            16 no LDS fragment reads inside the K loop
+//
+// PERSISTENT kernel: the grid is at most 2 workgroups per CU.  Tiles are numbered in the order of
+// tile_order.h and split into 8 contiguous chunks, one per XCD (workgroup b runs on XCD b % 8 — an
+// observed placement used for L2 locality only: any other placement is just slower).  A workgroup
+// takes its first tile statically and every further one from its XCD's queue word (one relaxed
+// atomicAdd per ~100 us tile), so the 64 tiles in flight on an XCD are 8 rows x 8 columns of one
+// strip and share 16 operand panels in that XCD's 4 MiB L2.  Queue words are never reset: a launch
+// owns the index range starting at `qbase[x]`, every workgroup over-pulls exactly once, and the
+// word advances by exactly the chunk length, which is what the host adds to its copy.  Launches with no more
+// tiles than workgroups do not touch the queue at all.
+struct QueueArgs {
+    unsigned long long base[8];  // per-XCD value of the queue word at launch
+    int64_t start[9];            // chunk x = tiles [start[x], start[x+1])
+    int use_queue;
 };
 
-template <typename T>
+template <typename T, int VARIANT>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int64_t ldc, const T* __restrict__ A,
                                                          int64_t lda, const T* __restrict__ B, int64_t ldb, int64_t M,
-                                                         int64_t N, int64_t K, int lower, int ntm, int ntn, int nsj,
-                                                         int64_t total_lin, const int* __restrict__ info) {
+                                                         int64_t N, int64_t K, int lower, int ntm, int ntn,
+                                                         unsigned long long* __restrict__ queue, QueueArgs qa,
+                                                         const int* __restrict__ info) {
     using MF = Mfma<T>;
     using Vec = typename MF::Vec;
     using Acc = typename MF::Acc;
     constexpr int E = MF::E;
     constexpr int BK = MF::BK;
-    constexpr int LDS_LD = BK + E;  // +16 B pad per row
     constexpr int BM = GEMM_BM, BN = GEMM_BN;
 
-    if (info && *info != 0) return;  // an earlier pivot failed: the factorisation is abandoned
-
-    // ---- XCD-aware tile decode -------------------------------------------------------------
-    const int64_t b = blockIdx.x;
-    const int64_t chunk = total_lin >> 3;
-    const int64_t lin = (b & 7) * chunk + (b >> 3);
-    const int64_t u = lin >> 6;
-    const int w = (int)(lin & 63);
-    int64_t SI, SJ;
-    if (lower) {
-        SI = (int64_t)((sqrt(8.0 * (double)u + 1.0) - 1.0) * 0.5);
-        while ((SI + 1) * (SI + 2) / 2 <= u) ++SI;
-        while (SI * (SI + 1) / 2 > u) --SI;
-        SJ = u - SI * (SI + 1) / 2;
-    } else {
-        SI = u / nsj;
-        SJ = u - SI * nsj;
-    }
-    const int64_t ti = SI * SUPER + (w >> 3);
-    const int64_t tj = SJ * SUPER + (w & 7);
-    if (ti >= ntm || tj >= ntn) return;
-    if (lower && tj * BN > ti * BM + BM - 1) return;
-    const int64_t m0 = ti * BM, n0 = tj * BN;
-
-    __shared__ __attribute__((aligned(16))) T As[2][BM * LDS_LD];
-    __shared__ __attribute__((aligned(16))) T Bs[2][BN * LDS_LD];
+    // one 64 KiB LDS array: [A buf0 | A buf1 | B buf0 | B buf1] during the K loop, then four
+    // wave-private 16 KiB transposition buffers for the epilogue
+    __shared__ __attribute__((aligned(16))) T smem[4 * BM * BK];
+    __shared__ long long s_tile;
+    T* const As0 = smem;
+    T* const Bs0 = smem + 2 * BM * BK;
 
     const int tid = threadIdx.x;
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;  // li-th workgroup of its XCD
+    const int nloc = (gridDim.x - xcd + 7) >> 3;           // workgroups on this XCD
+    const int64_t cbeg = qa.start[xcd], cend = qa.start[xcd + 1];
+    if (info && *info != 0) {  // an earlier pivot failed: abandon, but keep the queue arithmetic exact
+        if (qa.use_queue && tid == 0 && li == 0) atomicAdd(queue + 8 * xcd, (unsigned long long)(cend - cbeg));
+        return;
+    }
+
     const int lane = tid & 63;
     const int wv = tid >> 6;
     const int wm = wv >> 1, wn = wv & 1;
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);  // provably wave-uniform (LDS-DMA base goes to M0)
     const int r16 = lane & 15, g = lane >> 4;
-
-    // staging map: 4 x 16-B chunks of A and of B per thread per slab
-    const T* ga[4];
-    const T* gb[4];
-    int so[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = tid + 256 * i;
-        const int row = c >> 3, kc = c & 7;
-        int64_t ra = m0 + row;
-        ra = ra < M ? ra : M - 1;
-        int64_t rb = n0 + row;
-        rb = rb < N ? rb : N - 1;
-        ga[i] = A + ra * lda + kc * E;
-        gb[i] = B + rb * ldb + kc * E;
-        so[i] = row * LDS_LD + kc * E;
-    }
-
-    Acc acc[4][4];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[mi][ni][r] = T(0);
-
-    Vec ra_[4], rb_[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        ra_[i] = *reinterpret_cast<const Vec*>(ga[i]);
-        rb_[i] = *reinterpret_cast<const Vec*>(gb[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<Vec*>(&As[0][so[i]]) = ra_[i];
-        *reinterpret_cast<Vec*>(&Bs[0][so[i]]) = rb_[i];
-    }
-    __syncthreads();
-
     const int nk = (int)(K / BK);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            const int64_t ko = (int64_t)(kt + 1) * BK;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ra_[i] = *reinterpret_cast<const Vec*>(ga[i] + ko);
-                rb_[i] = *reinterpret_cast<const Vec*>(gb[i] + ko);
-            }
-        }
-        const T* as = &As[cur][(wm * 64 + r16) * LDS_LD + g * E];
-        const T* bs = &Bs[cur][(wn * 64 + r16) * LDS_LD + g * E];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            Vec af[4], bf[4];
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) af[mi] = *reinterpret_cast<const Vec*>(as + mi * 16 * LDS_LD + h * (BK / 2));
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) bf[ni] = *reinterpret_cast<const Vec*>(bs + ni * 16 * LDS_LD + h * (BK / 2));
-#pragma unroll
-            for (int e = 0; e < E; ++e)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = MF::mma(af[mi][e], bf[ni][e], acc[mi][ni]);
-        }
-        if (kt + 1 < nk) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<Vec*>(&As[cur ^ 1][so[i]]) = ra_[i];
-                *reinterpret_cast<Vec*>(&Bs[cur ^ 1][so[i]]) = rb_[i];
-            }
-        }
-        __syncthreads();
-    }
+    // fragment read offsets inside a row for the two k-halves: logical chunk 4h + g, swizzled by the row
+    const int fo[2] = {((g) ^ (r16 & 7)) * E, ((4 + g) ^ (r16 & 7)) * E};
 
-    // ---- epilogue: C -= acc ------------------------------------------------------------------
+    bool first = true;
+    for (;;) {
+        int64_t t;
+        if (first) {  // static first round
+            first = false;
+            t = cbeg + li;
+            __syncthreads();  // (the epilogue buffers of the previous tile do not exist yet; keeps the loop uniform)
+        } else {
+            if (!qa.use_queue) break;
+            if (tid == 0) s_tile = (long long)(atomicAdd(queue + 8 * xcd, 1ull) - qa.base[xcd]) + cbeg + nloc;
+            __syncthreads();  // also: every wave has left the epilogue's LDS buffers
+            const long long tl = s_tile;
+            __syncthreads();
+            t = __builtin_amdgcn_readfirstlane((int)tl);  // scalar: the decode runs on the SALU
+        }
+        if (t >= cend) break;
+        int ti, tj;
+        tile_decode(t, ntm, ntn, lower, &ti, &tj);
+        const int64_t m0 = (int64_t)ti * BM, n0 = (int64_t)tj * BN;
+
+        // Staging: every thread moves 4 x 16-B chunks of A and of B per slab straight from global
+        // memory into LDS (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass).  The LDS
+        // image of a slab is [128 rows][8 chunks] with NO padding (the DMA writes lane-linear);
+        // bank conflicts are avoided by an XOR swizzle applied on the SOURCE side: position p of
+        // row r holds global chunk p ^ (r & 7), and the fragment reads apply the same involution.
+        const T* __restrict__ Ab = A + m0 * lda;
+        const T* __restrict__ Bb = B + n0 * ldb;
+        const int mrem = (int)((M - m0 < BM ? M - m0 : BM) - 1);  // last valid local row
+        const int nrem = (int)((N - n0 < BN ? N - n0 : BN) - 1);
+        int oa[4], ob[4];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i;
+            const int row = c >> 3, kc = (c & 7) ^ (row & 7);
+            const int ra = row < mrem ? row : mrem;  // rows past M / N re-read the last valid row; never stored
+            const int rb = row < nrem ? row : nrem;
+            oa[i] = (int)(ra * lda) + kc * E;
+            ob[i] = (int)(rb * ldb) + kc * E;
+        }
+        auto stage = [&](int buf, int ko) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t row = m0 + wm * 64 + mi * 16 + MF::row_of(lane, r);
-            if (row < M) {
-                T* crow = C + row * ldc + n0 + wn * 64 + r16;
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ab + oa[i] + ko),
+                                                 (__attribute__((address_space(3))) void*)(As0 + buf * BM * BK + (wvu * 64 + 256 * i) * E),
+                                                 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bb + ob[i] + ko),
+                                                 (__attribute__((address_space(3))) void*)(Bs0 + buf * BN * BK + (wvu * 64 + 256 * i) * E),
+                                                 16, 0, 0);
+            }
+        };
+
+        Acc acc[4][4];
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    const int64_t col = n0 + wn * 64 + ni * 16 + r16;
-                    if (col < N) crow[ni * 16] -= acc[mi][ni][r];
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mi][ni].v[r] = T(0);
+
+        stage(0, 0);
+        __syncthreads();  // drains the DMA (vmcnt) and publishes the slab
+
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk && !(VARIANT & 4)) stage(cur ^ 1, (kt + 1) * BK);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                Vec af[4], bf[4];
+                if constexpr (VARIANT & 16) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            af[q][e] = T(1) + T(lane) * T(1e-3);
+                            bf[q][e] = T(0.5) + T(q) * T(1e-3);
+                        }
+                        asm volatile("" : "+v"(af[q]), "+v"(bf[q]));
+                    }
+                } else {
+                    const T* as = As0 + cur * BM * BK + (wm * 64 + r16) * BK + fo[h];
+                    const T* bs = Bs0 + cur * BN * BK + (wn * 64 + r16) * BK + fo[h];
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) af[mi] = *reinterpret_cast<const Vec*>(as + mi * 16 * BK);
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) bf[ni] = *reinterpret_cast<const Vec*>(bs + ni * 16 * BK);
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        T br[4];
+                        if constexpr (VARIANT & 8) {
+                            br[0] = br[1] = br[2] = br[3] = bf[ni][e];
+                        } else {
+                            MF::rotations(bf[ni][e], br);
+                        }
+#pragma unroll
+                        for (int mi = 0; mi < 4; ++mi) MF::mma(af[mi][e], br, acc[mi][ni]);
+                    }
+                }
+            }
+            __syncthreads();  // (a) next slab has landed for everyone  (b) everyone is done reading `cur`
+        }
+
+        // ---- epilogue: C -= acc --------------------------------------------------------------
+        if constexpr (VARIANT & 2) {
+            T sacc = T(0);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sacc += acc_get<T>(acc[mi][ni], r);
+            if (sacc == T(-1.2345e300)) C[0] = sacc;
+            continue;
+        }
+        // The accumulators leave in the MFMA lane layout (32-byte row fragments).  They are bounced
+        // through a wave-private LDS buffer, 32 rows x 64 columns at a time, and re-read row-major,
+        // so that C is read-modified-written with 16 bytes per lane and whole 128-byte lines per row
+        // (the fragment-shaped RMW cost 19 % of the kernel: it re-fetched every line four times).
+        {
+            constexpr int VEC = 16 / sizeof(T);  // elements per 16-byte access
+            constexpr int LPR = 64 / VEC;        // lanes per 64-column row
+            constexpr int RPI = 64 / LPR;        // rows per wave instruction
+            constexpr int NIT = 32 / RPI;
+            using VT = T __attribute__((ext_vector_type(VEC)));
+            T* stg = smem + wv * (32 * 64);
+            const int rloc = lane / LPR, cloc = (lane % LPR) * VEC;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            stg[(mi * 16 + MF::row_of(lane, r)) * 64 + ni * 16 + MF::col_of(lane, r)] =
+                                acc_get<T>(acc[2 * hh + mi][ni], r);
+                const int64_t grow0 = m0 + wm * 64 + hh * 32 + rloc;
+                const int64_t gcol = n0 + wn * 64 + cloc;
+                VT cv[NIT];
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int64_t grow = grow0 + it * RPI;
+                    if ((VARIANT & 1) || grow >= M || gcol + VEC > N) {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) cv[it][e] = T(0);
+                    } else {
+                        cv[it] = *reinterpret_cast<const VT*>(C + grow * ldc + gcol);
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int64_t grow = grow0 + it * RPI;
+                    const VT v = *reinterpret_cast<const VT*>(stg + (it * RPI + rloc) * 64 + cloc);
+                    if (grow < M) {
+                        if (gcol + VEC <= N) {
+                            *reinterpret_cast<VT*>(C + grow * ldc + gcol) = cv[it] - v;
+                        } else {  // ragged right edge (only the P x P full_cov update gets here)
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e)
+                                if (gcol + e < N) C[grow * ldc + gcol + e] -= v[e];
+                        }
+                    }
                 }
             }
         }
     }
 }
 
-// ---- peak-rate micro-benchmark: back-to-back MFMAs on 4 independent accumulators ------------
+// ---- peak-rate micro-benchmark: back-to-back MFMAs of the instruction the GEMM uses -----------
 template <typename T>
 __global__ __launch_bounds__(256) void mfma_peak_kernel(T* out, int iters) {
     using MF = Mfma<T>;
     typename MF::Acc a0, a1, a2, a3;
-    for (int r = 0; r < 4; ++r) a0[r] = a1[r] = a2[r] = a3[r] = T(0);
+    for (int r = 0; r < 4; ++r) a0.v[r] = a1.v[r] = a2.v[r] = a3.v[r] = T(0);
     T x = T(threadIdx.x & 7) * T(0.125), y = T(1.0) + T(threadIdx.x & 3) * T(1e-3);
+    T bx[4] = {x, y, x, y}, by[4] = {y, x, y, x};
     for (int i = 0; i < iters; ++i) {
-        a0 = MF::mma(x, y, a0);
-        a1 = MF::mma(y, x, a1);
-        a2 = MF::mma(x, x, a2);
-        a3 = MF::mma(y, y, a3);
+        MF::mma(x, by, a0);
+        MF::mma(y, bx, a1);
+        MF::mma(x, bx, a2);
+        MF::mma(y, by, a3);
     }
     T s = T(0);
-    for (int r = 0; r < 4; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
+    for (int r = 0; r < 4; ++r) s += a0.v[r] + a1.v[r] + a2.v[r] + a3.v[r];
     if (s == T(-1.2345)) out[0] = s;  // keep the chain live
 }
 
 }  // namespace
 
+template <typename T, int V>
+static void launch_persistent(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M,
+                              int64_t N, int64_t K, int lower, const int* info) {
+    const int ntm = (int)((M + GEMM_BM - 1) / GEMM_BM);
+    const int ntn = (int)((N + GEMM_BN - 1) / GEMM_BN);
+    const int64_t ntiles = tile_count(ntm, ntn, lower);
+    const int slots = 2 * ctx->num_cus;
+    // small launches: one workgroup per tile (rounded up to a multiple of 8 so XCD chunks stay contiguous)
+    const int grid = (int)std::min<int64_t>(slots, (ntiles + 7) / 8 * 8);
+    QueueArgs qa;
+    qa.use_queue = ntiles > grid;
+    for (int x = 0; x <= 8; ++x) qa.start[x] = ntiles * x / 8;
+    for (int x = 0; x < 8; ++x) {
+        qa.base[x] = ctx->queue_base[x];
+        // (chunk - nloc) successful pulls + one failing pull per workgroup (or `chunk` failing pulls when
+        // the chunk is smaller than the XCD's workgroup count): the word advances by `chunk` either way
+        if (qa.use_queue) ctx->queue_base[x] += (unsigned long long)(qa.start[x + 1] - qa.start[x]);
+    }
+    hipLaunchKernelGGL((gemm_nt_kernel<T, V>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, C, ldc, A, lda, B, ldb, M, N,
+                       K, lower, ntm, ntn, ctx->d_queue, qa, info);
+}
+
 template <typename T>
 void launch_gemm_nt(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M,
                     int64_t N, int64_t K, int lower, const int* info) {
     if (M <= 0 || N <= 0 || K <= 0) return;
-    const int ntm = (int)((M + GEMM_BM - 1) / GEMM_BM);
-    const int ntn = (int)((N + GEMM_BN - 1) / GEMM_BN);
-    const int nsi = (ntm + SUPER - 1) / SUPER;
-    const int nsj = (ntn + SUPER - 1) / SUPER;
-    int64_t nsuper = lower ? (int64_t)nsi * (nsi + 1) / 2 : (int64_t)nsi * nsj;
-    const int64_t total_lin = nsuper * SUPER * SUPER;
     double entries = lower ? (0.5 * (double)N * ((double)N + 1.0) + (double)(M - N) * (double)N) : (double)M * (double)N;
     ProfScope ps(ctx, lower ? GPMI_PROF_SYRK : GPMI_PROF_PANEL, 2.0 * entries * (double)K);
-    hipLaunchKernelGGL(gemm_nt_kernel<T>, dim3((unsigned)total_lin), dim3(256), 0, ctx->stream, C, ldc, A, lda, B, ldb,
-                       M, N, K, lower, ntm, ntn, nsj, total_lin, info);
+    launch_persistent<T, 0>(ctx, C, ldc, A, lda, B, ldb, M, N, K, lower, info);
 }
 
 template void launch_gemm_nt<double>(gpmi_ctx*, double*, int64_t, const double*, int64_t, const double*, int64_t,
                                      int64_t, int64_t, int64_t, int, const int*);
 template void launch_gemm_nt<float>(gpmi_ctx*, float*, int64_t, const float*, int64_t, const float*, int64_t, int64_t,
                                     int64_t, int64_t, int, const int*);
+
+
+// ---- isolated timing of the update kernel (tools / bench only) ------------------------------
+template <typename T, int V>
+static void launch_variant(gpmi_ctx* ctx, T* C, int64_t ld, const T* A, int64_t M, int64_t N, int64_t K, int lower) {
+    launch_persistent<T, V>(ctx, C, ld, A, ld, A, ld, M, N, K, lower, nullptr);
+}
+
+template <typename T>
+int gemm_bench(gpmi_ctx* ctx, int64_t M, int64_t N, int64_t K, int lower, int variant, int iters, double* ms_out) {
+    // operands: rows of a (M x ld) random matrix; C is its own buffer of the same shape
+    int64_t ld = ((std::max(N, K) + 63) / 64) * 64;
+    if (variant >= 64) {  // experiment: row stride = odd multiple of 256 B (spreads rows over all memory channels)
+        const int64_t q = 256 / sizeof(T);
+        ld = (ld + q - 1) / q * q;
+        if (((ld / q) & 1) == 0) ld += q;
+        variant -= 64;
+    }
+    T *A = nullptr, *C = nullptr;
+    GPMI_HIP(ctx, hipMalloc(&A, (size_t)(M * ld) * sizeof(T)));
+    GPMI_HIP(ctx, hipMalloc(&C, (size_t)(M * ld) * sizeof(T)));
+    std::vector<T> h((size_t)(M * ld));
+    uint64_t st = 88172645463325252ull;
+    for (auto& v : h) {
+        st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+        v = (T)((double)(st >> 11) * (1.0 / 9007199254740992.0) - 0.5);
+    }
+    GPMI_HIP(ctx, hipMemcpy(A, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    GPMI_HIP(ctx, hipMemset(C, 0, h.size() * sizeof(T)));
+    hipEvent_t e0, e1;
+    GPMI_HIP(ctx, hipEventCreate(&e0));
+    GPMI_HIP(ctx, hipEventCreate(&e1));
+    auto go = [&]() {
+        switch (variant) {
+            case 0: launch_variant<T, 0>(ctx, C, ld, A, M, N, K, lower); break;
+            case 1: launch_variant<T, 1>(ctx, C, ld, A, M, N, K, lower); break;
+            case 2: launch_variant<T, 2>(ctx, C, ld, A, M, N, K, lower); break;
+            case 4: launch_variant<T, 4>(ctx, C, ld, A, M, N, K, lower); break;
+            case 6: launch_variant<T, 6>(ctx, C, ld, A, M, N, K, lower); break;
+            case 8: launch_variant<T, 8>(ctx, C, ld, A, M, N, K, lower); break;
+            case 14: launch_variant<T, 14>(ctx, C, ld, A, M, N, K, lower); break;
+            case 22: launch_variant<T, 22>(ctx, C, ld, A, M, N, K, lower); break;
+            case 30: launch_variant<T, 30>(ctx, C, ld, A, M, N, K, lower); break;
+
+            default: break;
+        }
+    };
+    go();
+    GPMI_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    for (int i = 0; i < iters; ++i) go();
+    GPMI_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    GPMI_HIP(ctx, hipEventSynchronize(e1));
+    float ms = 0.f;
+    GPMI_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = (double)ms / iters;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(A);
+    hipFree(C);
+    return GPMI_OK;
+}
+template int gemm_bench<double>(gpmi_ctx*, int64_t, int64_t, int64_t, int, int, int, double*);
+template int gemm_bench<float>(gpmi_ctx*, int64_t, int64_t, int64_t, int, int, int, double*);
 
 template <typename T>
 int mfma_peak(gpmi_ctx* ctx, double* tflops) {
@@ -245,7 +460,7 @@ int mfma_peak(gpmi_ctx* ctx, double* tflops) {
     GPMI_HIP(ctx, hipEventSynchronize(e1));
     float ms = 0.f;
     GPMI_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
-    double flops = (double)blocks * 4.0 /*waves*/ * (double)iters * 4.0 /*mfma per iter*/ * 2.0 * 16 * 16 * 4;
+    double flops = (double)blocks * 4.0 /*waves*/ * (double)iters * 4.0 /*16x16x4 products per iter*/ * 2.0 * 16 * 16 * 4;
     *tflops = flops / ((double)ms * 1e-3) / 1e12;
     hipEventDestroy(e0);
     hipEventDestroy(e1);

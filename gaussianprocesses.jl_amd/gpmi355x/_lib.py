@@ -22,7 +22,7 @@ SYMBOLS = [
     "gpmi_ctx_create", "gpmi_ctx_destroy", "gpmi_last_error", "gpmi_version",
     "gpmi_gp_create", "gpmi_gp_destroy", "gpmi_fit", "gpmi_predict", "gpmi_cov",
     "gpmi_solve", "gpmi_whiten", "gpmi_logdet", "gpmi_factor_to_host",
-    "gpmi_profile_enable", "gpmi_profile_get", "gpmi_mfma_peak",
+    "gpmi_profile_enable", "gpmi_profile_get", "gpmi_mfma_peak", "gpmi_bench_gemm",
 ]
 
 
@@ -86,6 +86,7 @@ def load():
     lib.gpmi_profile_enable.argtypes = [vp, C.c_int]
     lib.gpmi_profile_get.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(dbl), C.POINTER(dbl)]
     lib.gpmi_mfma_peak.argtypes = [vp, C.c_int, C.POINTER(dbl)]
+    lib.gpmi_bench_gemm.argtypes = [vp, C.c_int, i64, i64, i64, C.c_int, C.c_int, C.c_int, C.POINTER(dbl)]
     _lib = lib
     return lib
 
@@ -136,6 +137,11 @@ class Context:
     def mfma_peak(self, dtype=64):
         out = C.c_double()
         self.check(load().gpmi_mfma_peak(self.h, dtype, C.byref(out)))
+        return out.value
+
+    def bench_gemm(self, M, N, K, lower=1, variant=0, iters=5, dtype=64):
+        out = C.c_double()
+        self.check(load().gpmi_bench_gemm(self.h, dtype, M, N, K, lower, variant, iters, C.byref(out)))
         return out.value
 
     def close(self):

@@ -1,0 +1,192 @@
+# GPMI355X.jl — the Julia-side binding a GaussianProcesses.jl maintainer adds to route the
+# exact-GP hot path (update_mll! / predict_f) through libgpmi.so on an MI355X.
+#
+# STATUS: written against include/gpmi.h, NOT executed — the build container has no Julia
+# (SURVEY.md header).  The same ABI is exercised end-to-end by the Python/ctypes host mirror
+# (gaussianprocesses.jl_amd/gpmi355x) and the GPU parity tests, so this file only has to be a
+# thin, reviewable marshaling layer.  It plugs in exactly where the reference's own alternative
+# strategies do (SoR/DTC/FITC/FSA: src/sparse/subsetofregressors.jl:82-113,302-327):
+#   * a CovarianceStrategy subtype selected through the 6-argument GPE constructor (src/GPE.jl:68-71)
+#   * an AbstractPDMat subtype returned by alloc_cK (src/GP.jl:14-20)
+#   * methods for update_cK!, \, logdet, whiten!, predictMVN, predict_f (src/GPE.jl:169-212, src/GP.jl:25-84)
+module GPMI355X
+
+using GaussianProcesses
+using GaussianProcesses: GPE, GPBase, Kernel, Mean, KernelData, EmptyData, CovarianceStrategy,
+    SEIso, SEArd, Mat12Iso, Mat12Ard, Mat32Iso, Mat32Ard, Mat52Iso, Mat52Ard, RQIso, RQArd,
+    Noise, Const, SumKernel, ProdKernel, Masked, FixedKernel, get_value, log2π
+import GaussianProcesses: alloc_cK, update_cK!, update_mll!, predictMVN, predict_f, mat, cholfactors, wrap_cK
+using PDMats
+import PDMats: dim, whiten!, whiten, unwhiten!
+using LinearAlgebra
+import LinearAlgebra: logdet, \, ldiv!
+
+const libgpmi = get(ENV, "LIBGPMI", "libgpmi.so")
+
+# ---- return codes -> Julia exceptions (include/gpmi.h "Conventions") ----------------------
+function check(ctx::Ptr{Cvoid}, rc::Cint, info::Integer=0)
+    rc == 0 && return
+    rc == 1 && throw(LinearAlgebra.PosDefException(info))          # src/GP.jl:110; caught by src/optimize.jl:56-58
+    msg = unsafe_string(ccall((:gpmi_last_error, libgpmi), Cstring, (Ptr{Cvoid},), ctx))
+    rc == 2 && throw(ArgumentError(msg))
+    error("libgpmi: $msg")
+end
+
+const CTX = Ref{Ptr{Cvoid}}(C_NULL)
+function context()
+    if CTX[] == C_NULL
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        dev = Ref{Cint}(parse(Cint, get(ENV, "GPMI_DEVICE", "0")))
+        rc = ccall((:gpmi_ctx_create, libgpmi), Cint, (Cint, Ptr{Cint}, Ptr{Ptr{Cvoid}}), 1, dev, h)
+        rc == 0 || error("libgpmi: no usable MI355X (gpmi_ctx_create rc=$rc); there is no CPU backend")
+        CTX[] = h[]
+    end
+    CTX[]
+end
+
+# ---- kernel tree -> gpmi_kernel postfix descriptor -----------------------------------------
+struct KernelDesc
+    ops::Vector{Int32}; dims_off::Vector{Int32}; dims::Vector{Int32}; params::Vector{Float64}
+end
+KernelDesc() = KernelDesc(Int32[], Int32[0], Int32[], Float64[])
+struct CKernel   # mirrors `struct gpmi_kernel`
+    n_ops::Int32; ops::Ptr{Int32}; dims_off::Ptr{Int32}; dims::Ptr{Int32}; params::Ptr{Float64}; n_params::Int32
+end
+function leaf!(kd, code, active, stored)
+    push!(kd.ops, code)
+    active === nothing || append!(kd.dims, Int32.(active .- 1))      # 0-based on the C side
+    push!(kd.dims_off, length(kd.dims))
+    append!(kd.params, stored)
+end
+flatten!(kd, k::SEIso, a)    = leaf!(kd, 1, a, [k.ℓ2, k.σ2])
+flatten!(kd, k::SEArd, a)    = leaf!(kd, 2, a, [k.iℓ2; k.σ2])
+flatten!(kd, k::Mat12Iso, a) = leaf!(kd, 3, a, [k.ℓ, k.σ2])
+flatten!(kd, k::Mat12Ard, a) = leaf!(kd, 4, a, [k.iℓ2; k.σ2])
+flatten!(kd, k::Mat32Iso, a) = leaf!(kd, 5, a, [k.ℓ, k.σ2])
+flatten!(kd, k::Mat32Ard, a) = leaf!(kd, 6, a, [k.iℓ2; k.σ2])
+flatten!(kd, k::Mat52Iso, a) = leaf!(kd, 7, a, [k.ℓ, k.σ2])
+flatten!(kd, k::Mat52Ard, a) = leaf!(kd, 8, a, [k.iℓ2; k.σ2])
+flatten!(kd, k::RQIso, a)    = leaf!(kd, 9, a, [k.ℓ2, k.σ2, k.α])
+flatten!(kd, k::RQArd, a)    = leaf!(kd, 10, a, [k.iℓ2; k.σ2; k.α])
+flatten!(kd, k::Noise, a)    = leaf!(kd, 11, a, [k.σ2])
+flatten!(kd, k::Const, a)    = leaf!(kd, 12, a, [k.σ2])
+function flatten!(kd, k::Union{SumKernel,ProdKernel}, a)
+    flatten!(kd, k.kleft, a); flatten!(kd, k.kright, a)
+    push!(kd.ops, k isa SumKernel ? 100 : 101); push!(kd.dims_off, length(kd.dims))
+end
+flatten!(kd, k::Masked, a) = flatten!(kd, k.kernel, a === nothing ? collect(k.active_dims) : a[collect(k.active_dims)])
+flatten!(kd, k::FixedKernel, a) = flatten!(kd, k.kernel, a)
+flatten!(kd, k::Kernel, a) = throw(ArgumentError("HIPCovariance: kernel $(typeof(k)) is not on the MI355X path; use FullCovariance"))
+function descriptor(k::Kernel)
+    kd = KernelDesc(); flatten!(kd, k, nothing)
+    isempty(kd.dims) && push!(kd.dims, 0)
+    kd
+end
+withkernel(f, kd::KernelDesc) = GC.@preserve kd f(Ref(CKernel(length(kd.ops), pointer(kd.ops), pointer(kd.dims_off),
+                                                           pointer(kd.dims), pointer(kd.params), length(kd.params))))
+
+# ---- CovarianceStrategy + AbstractPDMat ----------------------------------------------------
+struct HIPCovariance <: CovarianceStrategy end
+GaussianProcesses.KernelData(k::Kernel, X1::AbstractMatrix, X2::AbstractMatrix, ::HIPCovariance) = EmptyData()
+
+mutable struct HIPPDMat <: AbstractPDMat{Float64}
+    handle::Ptr{Cvoid}   # gpmi_gp*
+    n::Int
+    xref::Any            # the x the handle was created for (re-created by update_cK! when it changes)
+    function HIPPDMat(n)
+        a = new(C_NULL, n, nothing)
+        finalizer(a) do a
+            a.handle == C_NULL || ccall((:gpmi_gp_destroy, libgpmi), Cvoid, (Ptr{Cvoid},), a.handle)
+        end
+    end
+end
+alloc_cK(::HIPCovariance, nobs) = HIPPDMat(nobs)                      # replaces src/GP.jl:14-20
+Base.size(a::HIPPDMat) = (a.n, a.n); Base.size(a::HIPPDMat, i::Int) = a.n; dim(a::HIPPDMat) = a.n
+
+function ensure_handle!(a::HIPPDMat, x::Matrix{Float64})
+    if a.handle == C_NULL || a.xref !== x
+        a.handle == C_NULL || ccall((:gpmi_gp_destroy, libgpmi), Cvoid, (Ptr{Cvoid},), a.handle)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        rc = ccall((:gpmi_gp_create, libgpmi), Cint, (Ptr{Cvoid}, Cint, Cint, Int64, Ptr{Float64}, Ptr{Ptr{Cvoid}}),
+                   context(), 64, size(x, 1), size(x, 2), x, h)
+        check(context(), rc); a.handle = h[]; a.xref = x; a.n = size(x, 2)
+    end
+    a
+end
+
+function fit!(a::HIPPDMat, x, kernel, logNoise, ymμ::Vector{Float64}, alpha::Union{Vector{Float64},Nothing})
+    ensure_handle!(a, x)
+    ln = logNoise isa Real ? Float64[logNoise] : Vector{Float64}(logNoise)
+    mll = Ref{Float64}(NaN); info = Ref{Int64}(0)
+    rc = withkernel(descriptor(kernel)) do ck
+        ccall((:gpmi_fit, libgpmi), Cint,
+              (Ptr{Cvoid}, Ref{CKernel}, Ptr{Float64}, Int64, Ptr{Float64}, Ref{Float64}, Ptr{Float64}, Ref{Int64}),
+              a.handle, ck, ln, length(ln), ymμ, mll, alpha === nothing ? C_NULL : alpha, info)
+    end
+    check(context(), rc, info[])
+    mll[]
+end
+
+# update_cK! alone (src/GPE.jl:169-195; callers: GPA with logNoise = -20, ElasticGPE): factor only
+function update_cK!(cK::HIPPDMat, x::AbstractMatrix, kernel::Kernel, logNoise, data::KernelData, ::HIPCovariance)
+    fit!(cK, Matrix{Float64}(x), kernel, logNoise, zeros(size(x, 2)), nothing)
+    cK
+end
+
+# update_mll! (src/GPE.jl:202-212) fused: cov! + nugget + Cholesky + alpha + logdet + mll in one device pass
+function update_mll!(gp::GPE{X,Y,M,K,HIPCovariance}; noise::Bool=true, domean::Bool=true, kern::Bool=true) where {X,Y,M,K}
+    μ = mean(gp.mean, gp.x)
+    ymμ = Vector{Float64}(gp.y - μ)
+    if kern | noise
+        length(gp.alpha) == gp.nobs || (gp.alpha = Vector{Float64}(undef, gp.nobs))
+        gp.mll = fit!(gp.cK, gp.x, gp.kernel, get_value(gp.logNoise), ymμ, gp.alpha)
+    else
+        gp.alpha = gp.cK \ ymμ
+        gp.mll = -(dot(ymμ, gp.alpha) + logdet(gp.cK) + log2π * gp.nobs) / 2
+    end
+    gp
+end
+
+function \(a::HIPPDMat, b::DenseVecOrMat{Float64})                      # PDMats `\`  (src/GPE.jl:208)
+    out = copy(b)
+    check(context(), ccall((:gpmi_solve, libgpmi), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}), a.handle, size(out, 2), out)); out
+end
+ldiv!(a::HIPPDMat, b::DenseVecOrMat{Float64}) =
+    (check(context(), ccall((:gpmi_solve, libgpmi), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}), a.handle, size(b, 2), b)); b)
+whiten!(a::HIPPDMat, b::DenseVecOrMat{Float64}) =                       # src/GP.jl:27
+    (check(context(), ccall((:gpmi_whiten, libgpmi), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}), a.handle, size(b, 2), b)); b)
+whiten(a::HIPPDMat, b::DenseVecOrMat{Float64}) = whiten!(a, copy(b))
+function logdet(a::HIPPDMat)                                            # src/GPE.jl:210
+    out = Ref{Float64}(NaN)
+    check(context(), ccall((:gpmi_logdet, libgpmi), Cint, (Ptr{Cvoid}, Ref{Float64}), a.handle, out)); out[]
+end
+function cholfactors(a::HIPPDMat)                                       # src/GP.jl:89 (lazy host copy)
+    U = Matrix{Float64}(undef, a.n, a.n)
+    check(context(), ccall((:gpmi_factor_to_host, libgpmi), Cint, (Ptr{Cvoid}, Ptr{Float64}), a.handle, U)); U
+end
+Base.Matrix(a::HIPPDMat) = (U = UpperTriangular(cholfactors(a)); Matrix(U' * U))
+mat(a::HIPPDMat) = Matrix(a)                                            # K is regenerated on demand, never resident
+
+# ---- predict: batches the full_cov=false branch (src/GP.jl:69-77 is P separate trsv) -----------
+function hip_predict(gp::GPE, x::AbstractMatrix, full_cov::Bool)
+    size(x, 1) == gp.dim || throw(ArgumentError("Gaussian Process object and input observations do not have consistent dimensions"))
+    xp = Matrix{Float64}(x); P = size(xp, 2)
+    mx = Vector{Float64}(mean(gp.mean, xp)); μ = Vector{Float64}(undef, P)
+    Σ = full_cov ? Matrix{Float64}(undef, P, P) : Vector{Float64}(undef, P)
+    rc = withkernel(descriptor(gp.kernel)) do ck
+        ccall((:gpmi_predict, libgpmi), Cint,
+              (Ptr{Cvoid}, Ref{CKernel}, Int64, Ptr{Float64}, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Float64}),
+              gp.cK.handle, ck, P, xp, mx, full_cov ? 1 : 0, μ, Σ)
+    end
+    check(context(), rc); μ, Σ
+end
+predict_f(gp::GPE{X,Y,M,K,HIPCovariance}, x::AbstractMatrix; full_cov::Bool=false) where {X,Y,M,K} = hip_predict(gp, x, full_cov)
+predictMVN(xpred::AbstractMatrix, xtrain::AbstractMatrix, ytrain::AbstractVector, kernel::Kernel, meanf::Mean,
+           alpha::AbstractVector, ::HIPCovariance, Ktrain::HIPPDMat) =
+    error("predictMVN(::HIPCovariance) is reached through predict_f, which this module overrides")
+
+# convenience constructor, as SoR(...)/FITC(...) are (src/sparse/subsetofregressors.jl:324-327)
+GP_hip(x::AbstractMatrix, y::AbstractVector, m::Mean, k::Kernel, logNoise=-2.0) = GPE(x, y, m, k, logNoise, HIPCovariance())
+
+export HIPCovariance, HIPPDMat, GP_hip
+end # module

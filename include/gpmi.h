@@ -148,6 +148,11 @@ int gpmi_profile_get(gpmi_ctx*, int cls, int64_t* launches, double* total_ms, do
 /* Peak-rate micro-benchmark of v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32:
  * returns measured TFLOP/s with every SIMD issuing back-to-back MFMAs.      */
 int gpmi_mfma_peak(gpmi_ctx*, int dtype, double* tflops_out);
+/* Isolated timing of the trailing-update kernel  C[M x N] -= A[M x K] A[0:N, 0:K]'  on random
+ * operands (lower != 0: SYRK tile set).  variant 0 is the product kernel; other values are
+ * ablations used by tools/gemm_ablate.py.  Returns milliseconds per launch.                  */
+int gpmi_bench_gemm(gpmi_ctx*, int dtype, int64_t M, int64_t N, int64_t K, int lower, int variant, int iters,
+                    double* ms_out);
 
 #ifdef __cplusplus
 }
