@@ -178,11 +178,11 @@ static int upload_program(gpmi_ctx* c, const gpmi_kernel* k, int d) {
 // factored diagonal block of A, then push the update into R's remaining columns:
 //   R[:, k0:kend] <- R[:, k0:kend] * L_kk^-T ;  R[:, kend:npad] -= R[:, k0:kend] * A[kend:npad, k0:kend]'
 template <typename T>
-static void rows_block_solve(gpmi_ctx* c, const T* A, int64_t ld, int64_t npad, T* R, int64_t ldr, int64_t Mr,
-                             int64_t k0, int64_t nbk) {
+static void rows_block_solve(gpmi_ctx* c, const T* A, int64_t ld, const T* invdiag, int64_t npad, T* R, int64_t ldr,
+                             int64_t Mr, int64_t k0, int64_t nbk) {
     const int64_t kend = k0 + nbk;
     for (int64_t j0 = k0; j0 < kend; j0 += IB) {
-        launch_trsm_rows<T>(c, R + j0, ldr, A + j0 * ld + j0, ld, Mr, nullptr);
+        launch_trsm_rows<T>(c, R + j0, ldr, A + j0 * ld + j0, ld, invdiag + j0, Mr, nullptr);
         const int64_t nc = kend - (j0 + IB);
         if (nc > 0)
             launch_gemm_nt<T>(c, R + (j0 + IB), ldr, R + j0, ldr, A + (j0 + IB) * ld + j0, ld, Mr, nc, IB, 0, nullptr);
@@ -192,25 +192,26 @@ static void rows_block_solve(gpmi_ctx* c, const T* A, int64_t ld, int64_t npad, 
 }
 
 template <typename T>
-static void whiten_rows(gpmi_ctx* c, const T* A, int64_t ld, int64_t npad, T* R, int64_t ldr, int64_t Mr) {
-    for (int64_t k0 = 0; k0 < npad; k0 += NB) rows_block_solve<T>(c, A, ld, npad, R, ldr, Mr, k0, std::min<int64_t>(NB, npad - k0));
+static void whiten_rows(gpmi_ctx* c, const T* A, int64_t ld, const T* invdiag, int64_t npad, T* R, int64_t ldr, int64_t Mr) {
+    for (int64_t k0 = 0; k0 < npad; k0 += NB)
+        rows_block_solve<T>(c, A, ld, invdiag, npad, R, ldr, Mr, k0, std::min<int64_t>(NB, npad - k0));
 }
 
 // Blocked right-looking Cholesky of the row-major lower triangle of A (npad x npad), carrying
 // `extra` rows below it (row npad = y) through the panel solves and trailing updates, so that
 // on exit row npad holds z = L^-1 y (the forward half of cK \ y, GPE.jl:208).
 template <typename T>
-static void cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, int64_t npad, int64_t extra, int* d_info) {
+static void cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* invdiag, int64_t npad, int64_t extra, int* d_info) {
     const int64_t Mtot = npad + extra;
     for (int64_t k0 = 0; k0 < npad; k0 += NB) {
         const int64_t nbk = std::min<int64_t>(NB, npad - k0);
         const int64_t kend = k0 + nbk;
         for (int64_t j0 = k0; j0 < kend; j0 += IB) {
-            launch_potf2<T>(c, A + j0 * ld + j0, ld, d_info, j0);
+            launch_potf2<T>(c, A + j0 * ld + j0, ld, invdiag + j0, d_info, j0);
             const int64_t r0 = j0 + IB;
             const int64_t M = Mtot - r0;
             if (M <= 0) continue;
-            launch_trsm_rows<T>(c, A + r0 * ld + j0, ld, A + j0 * ld + j0, ld, M, d_info);
+            launch_trsm_rows<T>(c, A + r0 * ld + j0, ld, A + j0 * ld + j0, ld, invdiag + j0, M, d_info);
             const int64_t nc = kend - r0;
             if (nc > 0)  // in-panel update of the columns still to be factored (K = 64)
                 launch_gemm_nt<T>(c, A + r0 * ld + r0, ld, A + r0 * ld + j0, ld, A + r0 * ld + j0, ld, M, nc, IB, 0, d_info);
@@ -252,7 +253,7 @@ static int fit_t(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int
                   COV_LOWER | COV_NUGGET | COV_PAD_IDENTITY, nugget, d_noise);
     GPMI_HIP(c, hipMemcpyAsync(A + npad * ld, gp->ymu, (size_t)npad * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
 
-    cholesky_lower<T>(c, A, ld, npad, 1, c->d_info);
+    cholesky_lower<T>(c, A, ld, (T*)gp->invdiag, npad, 1, c->d_info);
 
     {
         ProfScope ps(c, GPMI_PROF_SOLVE, (double)npad * (double)npad * 0.5 * sizeof(T));
@@ -316,7 +317,7 @@ static int predict_t(gpmi_gp* gp, const gpmi_kernel* k, int64_t P, const void* x
         // K*' (P x npad, one test point per row): cov(k, xtrain, xpred)', GP.jl:44
         launch_cov<T>(c, xp, P, (const T*)gp->x, n, d, R, ld, P, npad, 0, 0.0, nullptr);
         launch_row_gemv<T>(c, R, ld, P, n, (const T*)gp->alpha, d_mean, d_mu);  // mu = mx + Kfx' alpha, GP.jl:26
-        whiten_rows<T>(c, A, ld, npad, R, ld, P);                               // Lck = whiten!(Kff, Kfx), GP.jl:27
+        whiten_rows<T>(c, A, ld, (const T*)gp->invdiag, npad, R, ld, P);        // Lck = whiten!(Kff, Kfx), GP.jl:27
         if (!full_cov) launch_row_var<T>(c, R, ld, P, npad, kdiag, d_var);
     }
     GPMI_HIP(c, hipMemcpyAsync(mu_out, d_mu, (size_t)P * sizeof(T), hipMemcpyDeviceToHost, c->stream));
@@ -383,7 +384,7 @@ static int solve_t(gpmi_gp* gp, int64_t nrhs, void* b_inout, bool backward) {
     GPMI_HIP(c, hipMemsetAsync(R, 0, (size_t)(nrhs * ld) * sizeof(T), c->stream));
     GPMI_HIP(c, hipMemcpy2DAsync(R, (size_t)ld * sizeof(T), b_inout, (size_t)n * sizeof(T), (size_t)n * sizeof(T),
                                  (size_t)nrhs, hipMemcpyHostToDevice, c->stream));
-    whiten_rows<T>(c, A, ld, npad, R, ld, nrhs);
+    whiten_rows<T>(c, A, ld, (const T*)gp->invdiag, npad, R, ld, nrhs);
     if (backward) {
         T* tmp = (T*)gp->small;
         for (int64_t r = 0; r < nrhs; ++r) {
@@ -474,6 +475,7 @@ int gpmi_gp_create(gpmi_ctx* c, int dtype, int d, int64_t n, const void* x, gpmi
     if (e == hipSuccess) e = hipMalloc(&gp->A, (size_t)((gp->npad + 8) * gp->ld) * es);
     if (e == hipSuccess) e = hipMalloc(&gp->ymu, (size_t)gp->npad * es);
     if (e == hipSuccess) e = hipMalloc(&gp->alpha, (size_t)gp->npad * es);
+    if (e == hipSuccess) e = hipMalloc(&gp->invdiag, (size_t)gp->npad * es);
     if (e == hipSuccess) e = hipMemcpy(gp->x, x, (size_t)(n * d) * es, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset((char*)gp->A + (size_t)(gp->npad * gp->ld) * es, 0, (size_t)(8 * gp->ld) * es);
     if (e != hipSuccess) {
@@ -491,7 +493,7 @@ void gpmi_gp_destroy(gpmi_gp* gp) {
         hipSetDevice(gp->ctx->device);
         hipStreamSynchronize(gp->ctx->stream);
     }
-    void* ptrs[] = {gp->x, gp->A, gp->ymu, gp->alpha, gp->noise, gp->rows, gp->xp, gp->small};
+    void* ptrs[] = {gp->x, gp->A, gp->ymu, gp->alpha, gp->invdiag, gp->noise, gp->rows, gp->xp, gp->small};
     for (void* p : ptrs)
         if (p) hipFree(p);
     delete gp;

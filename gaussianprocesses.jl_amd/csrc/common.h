@@ -87,6 +87,7 @@ struct gpmi_gp {
     void* A = nullptr;       // (npad + 8) x ld; lower triangle holds L (K = L L'), row npad holds z = L^-1 y
     void* ymu = nullptr;     // y - mu, npad elements (zero padded)
     void* alpha = nullptr;   // npad elements
+    void* invdiag = nullptr; // 1 / L_ii, npad elements (written by potf2, read by every later solve)
     double* noise = nullptr; // per-point nugget (heteroscedastic) or nullptr
     bool fitted = false;
     double logdet = 0.0;
@@ -135,13 +136,14 @@ void launch_gemm_nt(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, c
                     int64_t N, int64_t K, int lower, const int* info);
 
 // in-place Cholesky of the 64 x 64 block at A (row-major, ld): lower factor; upper part zeroed.
-// On a non-positive pivot j (0-based) writes *info = pivot_base + j + 1 (if *info == 0).
+// invdiag[0..64) receives 1 / L_jj.  On a non-positive pivot j (0-based) writes *info = pivot_base + j + 1.
 template <typename T>
-void launch_potf2(gpmi_ctx* ctx, T* A, int64_t ld, int* info, int64_t pivot_base);
+void launch_potf2(gpmi_ctx* ctx, T* A, int64_t ld, T* invdiag, int* info, int64_t pivot_base);
 
 // X[M x 64] <- X * L11^-T  (row-wise forward substitution against the 64 x 64 lower L11)
 template <typename T>
-void launch_trsm_rows(gpmi_ctx* ctx, T* X, int64_t ldx, const T* L11, int64_t ldl, int64_t M, const int* info);
+void launch_trsm_rows(gpmi_ctx* ctx, T* X, int64_t ldx, const T* L11, int64_t ldl, const T* invdiag, int64_t M,
+                      const int* info);
 
 // One step of the backward solve  L' alpha = z  for the 64-block starting at j0:
 //   alpha[j0..j0+64) = L_bb^-T z[j0..);  z[0..j0) -= L[j0..j0+64, 0..j0)' alpha_b

@@ -19,17 +19,40 @@ template <>
 __device__ __forceinline__ float tsqrt<float>(float x) { return sqrtf(x); }
 
 // ---------------------------------------------------------------------------------------------
-// potf2: one wavefront; lane i owns row i of the block in registers.  Step j:
-//   pivot d = a_jj (readlane), column j scaled by 1/sqrt(d) (dpotf2 does the same dscal),
-//   the scaled column is exchanged through a double-buffered 64-entry LDS vector and every
-//   lane updates its row: a_ic -= l_ij * l_cj  (c > j).  No workgroup barrier: one wave.
+// potf2: ONE wavefront; lane i owns row i of the 64 x 64 block in registers.  Step j:
+//   pivot d = a_jj by v_readlane (j is a compile-time constant after unrolling);
+//   1/sqrt(d) from v_rsq_f64 + two Newton steps, then sqrt(d) = d * rsqrt(d) and 1/sqrt(d) each
+//   polished by one fused correction (no fp64 divide / sqrt library sequences on the critical path);
+//   column j is scaled in place (dpotf2 does the same dscal by the reciprocal);
+//   every other lane's l_cj is fetched with v_readlane into SGPRs and applied as
+//   a_ic -= l_ij * l_cj (c > j) — no LDS round trip, no barrier, one SGPR operand per v_fma_f64.
+// The reciprocals 1 / L_jj are kept in `invdiag` for the solves that follow (trsm_rows, bsolve).
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(64) void potf2_kernel(T* __restrict__ A, int64_t ld, int* __restrict__ info,
-                                                   int64_t pivot_base) {
+__device__ __forceinline__ T rsqrt_seed(T x);
+template <>
+__device__ __forceinline__ double rsqrt_seed<double>(double x) { return __builtin_amdgcn_rsq(x); }
+template <>
+__device__ __forceinline__ float rsqrt_seed<float>(float x) { return __builtin_amdgcn_rsqf(x); }
+
+template <typename T>
+__device__ __forceinline__ T bcast_lane(T v, int srclane);
+template <>
+__device__ __forceinline__ double bcast_lane<double>(double v, int srclane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+    return __hiloint2double(hi, lo);
+}
+template <>
+__device__ __forceinline__ float bcast_lane<float>(float v, int srclane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srclane));
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void potf2_kernel(T* __restrict__ A, int64_t ld, T* __restrict__ invdiag,
+                                                   int* __restrict__ info, int64_t pivot_base) {
     if (*info != 0) return;
     __shared__ T S[64 * 65];
-    __shared__ T colbuf[2][64];
     const int i = threadIdx.x;
     for (int r = 0; r < 64; ++r) S[r * 65 + i] = A[(int64_t)r * ld + i];  // coalesced rows
     __syncthreads();
@@ -38,26 +61,31 @@ __global__ __launch_bounds__(64) void potf2_kernel(T* __restrict__ A, int64_t ld
     for (int c = 0; c < 64; ++c) a[c] = S[i * 65 + c];
 
     int fail = 0;
+    T myinv = T(0);
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
-        const T d = __shfl(a[j], j, 64);
+        const T d = bcast_lane<T>(a[j], j);
         if (!(d > T(0))) {  // also catches NaN; uniform across the wave
             fail = j + 1;
             break;
         }
-        const T s = tsqrt<T>(d);
-        const T inv = T(1) / s;
-        const T lij = (i == j) ? s : a[j] * inv;
+        T r = rsqrt_seed<T>(d);
+        r = r * (T(1.5) - T(0.5) * d * r * r);
+        r = r * (T(1.5) - T(0.5) * d * r * r);
+        T sq = d * r;
+        sq = sq + (T(0.5) * r) * (d - sq * sq);       // sqrt(d)
+        const T inv = r + r * (T(1) - sq * r);        // 1 / sqrt(d)
+        const T lij = (i == j) ? sq : a[j] * inv;
         a[j] = lij;
-        colbuf[j & 1][i] = lij;
-        __syncthreads();
+        if (i == j) myinv = inv;
 #pragma unroll
-        for (int c = j + 1; c < 64; ++c) a[c] -= lij * colbuf[j & 1][c];
+        for (int c = j + 1; c < 64; ++c) a[c] -= lij * bcast_lane<T>(lij, c);
     }
     if (fail) {
         if (i == 0) *info = (int)(pivot_base + fail);
         return;
     }
+    invdiag[i] = myinv;
     // write back: lower triangle = L, strict upper = 0
     __syncthreads();
 #pragma unroll
@@ -67,13 +95,17 @@ __global__ __launch_bounds__(64) void potf2_kernel(T* __restrict__ A, int64_t ld
 }
 
 // ---------------------------------------------------------------------------------------------
-// trsm_rows: 64 rows per workgroup (one wavefront), lane r owns row r in registers.
-//   x_t = b_t / L_tt ;  b_j -= x_t * L_jt  (j > t)      — right-looking, full ILP over j.
-// L11 is read from LDS as wave-uniform broadcasts.
+// trsm_rows: X <- X * L11^-T, 64 rows per workgroup (one wavefront), lane r owns row r in registers.
+//   x_k = b_k / L_kk ;  b_j -= x_k * L_jk  (j > k)      — right-looking, full ILP over j.
+// L11 is read from LDS as wave-uniform broadcasts; 1 / L_kk comes from `invdiag` (written by potf2).
+// Measured alternatives that were SLOWER on MI355X (profiles/r01_notes): L through the scalar cache
+// (s_load_dwordx16 + SGPR operands: 55 us — 313 waves x 232 dependent loads of the same 16 KiB) and
+// a transposed LDS image shared by two waves (39 us: the transposing store is a 64-way bank conflict).
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(64) void trsm_rows_kernel(T* __restrict__ X, int64_t ldx, const T* __restrict__ L11,
-                                                       int64_t ldl, int64_t M, const int* __restrict__ info) {
+                                                       int64_t ldl, const T* __restrict__ invd_g, int64_t M,
+                                                       const int* __restrict__ info) {
     if (info && *info != 0) return;
     __shared__ T SL[64 * 64];   // L11, row-major, read uniformly
     __shared__ T SX[64 * 65];   // X tile (transposition buffer)
@@ -86,12 +118,11 @@ __global__ __launch_bounds__(64) void trsm_rows_kernel(T* __restrict__ X, int64_
         gr = gr < M ? gr : M - 1;
         SX[r * 65 + t] = X[gr * ldx + t];
     }
+    invd[t] = invd_g[t];
     __syncthreads();
-    invd[t] = T(1) / SL[t * 64 + t];
     T b[64];
 #pragma unroll
     for (int c = 0; c < 64; ++c) b[c] = SX[t * 65 + c];
-    __syncthreads();
 #pragma unroll
     for (int k = 0; k < 64; ++k) {
         const T xk = b[k] * invd[k];
@@ -229,16 +260,17 @@ __global__ __launch_bounds__(256) void row_var_kernel(const T* __restrict__ R, i
 }  // namespace
 
 template <typename T>
-void launch_potf2(gpmi_ctx* ctx, T* A, int64_t ld, int* info, int64_t pivot_base) {
+void launch_potf2(gpmi_ctx* ctx, T* A, int64_t ld, T* invdiag, int* info, int64_t pivot_base) {
     ProfScope ps(ctx, GPMI_PROF_PANEL, 64.0 * 64.0 * 64.0 / 3.0);
-    hipLaunchKernelGGL(potf2_kernel<T>, dim3(1), dim3(64), 0, ctx->stream, A, ld, info, pivot_base);
+    hipLaunchKernelGGL(potf2_kernel<T>, dim3(1), dim3(64), 0, ctx->stream, A, ld, invdiag, info, pivot_base);
 }
 template <typename T>
-void launch_trsm_rows(gpmi_ctx* ctx, T* X, int64_t ldx, const T* L11, int64_t ldl, int64_t M, const int* info) {
+void launch_trsm_rows(gpmi_ctx* ctx, T* X, int64_t ldx, const T* L11, int64_t ldl, const T* invdiag, int64_t M,
+                      const int* info) {
     if (M <= 0) return;
     ProfScope ps(ctx, GPMI_PROF_PANEL, (double)M * 64.0 * 64.0);
     hipLaunchKernelGGL(trsm_rows_kernel<T>, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, ctx->stream, X, ldx, L11, ldl,
-                       M, info);
+                       invdiag, M, info);
 }
 template <typename T>
 void launch_bsolve_step(gpmi_ctx* ctx, const T* A, int64_t ld, int64_t j0, T* z, T* alpha) {
@@ -262,8 +294,8 @@ void launch_row_var(gpmi_ctx* ctx, const T* R, int64_t ldr, int64_t P, int64_t n
 }
 
 #define INST(T)                                                                                                   \
-    template void launch_potf2<T>(gpmi_ctx*, T*, int64_t, int*, int64_t);                                         \
-    template void launch_trsm_rows<T>(gpmi_ctx*, T*, int64_t, const T*, int64_t, int64_t, const int*);            \
+    template void launch_potf2<T>(gpmi_ctx*, T*, int64_t, T*, int*, int64_t);                                     \
+    template void launch_trsm_rows<T>(gpmi_ctx*, T*, int64_t, const T*, int64_t, const T*, int64_t, const int*);  \
     template void launch_bsolve_step<T>(gpmi_ctx*, const T*, int64_t, int64_t, T*, T*);                           \
     template void launch_finalize<T>(gpmi_ctx*, const T*, int64_t, int64_t, const T*, const T*, double*);         \
     template void launch_row_gemv<T>(gpmi_ctx*, const T*, int64_t, int64_t, int64_t, const T*, const T*, T*);     \
