@@ -7,6 +7,11 @@ with x already resident in HBM (uploaded once by GP(), as fit! does) and the hyp
 perturbed every step so nothing can be cached.  Workload at N=1: BASELINE.json configs[1]
 (N=20000, d=8, SEArd, fp64, MeanZero, P=1024 test points, SURVEY §8d hyper-parameters).
 
+N > 1 (one process per GPU, torchrun): by default every rank runs its own fit (the metric's unit is a fit, the
+units are independent: weak scaling, no data-path collective) and, as an extra "sharded_leg", ONE fit of the same
+size is also run row-block sharded over all GPUs with the RCCL panel all-gather (gpmi355x.dist); `--mode sharded`
+makes that the measured workload instead (strong scaling).
+
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     — the dominant kernel (Cholesky trailing update, MFMA-bound): algorithmic flops per
                  launch / mean launch duration, measured live with HIP events on the library's
@@ -81,6 +86,60 @@ def cpu_baseline(n_bench, d, p, ll, n_sample):
     }
 
 
+def _main_json(args, world, elapsed, gp, n, d, p, fl_syrk, ms_syrk, n_syrk, ms_cov, by_cov, ms_pan, ms_sol, ms_pre, t_build,
+               scaling, sharded=False):
+    peak = FP64_MFMA_PEAK_TFLOPS if args.dtype == "f64" else FP32_MFMA_PEAK_TFLOPS
+    achieved = (fl_syrk / max(ms_syrk, 1e-9)) * 1e-9  # flop/ms -> TFLOP/s
+    nfits = args.steps if sharded else world * args.steps
+    if world == 1:
+        par = "single GPU"
+    elif sharded:
+        par = f"ONE fit row-block sharded over {world} GPUs (block-cyclic 256-row blocks, RCCL panel all-gather per step)"
+    else:
+        par = f"{world} independent fits, one per GPU (the metric's unit is a fit: no data-path collective)"
+    return {
+        "metric": "GP fits/sec (update_mll!+predict_f)",
+        "value": nfits / elapsed,
+        "unit": "GP fits/sec",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": scaling,
+        "vs_baseline": None,
+        "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {
+            "workload": f"N={n}, d={d}, SEArd + MeanZero, {args.dtype}, P={p} test points, full_cov=false "
+                        "(BASELINE.json configs[1])",
+            "parallelism": par,
+            "mll": gp.mll,
+        },
+        "roofline": {
+            "kernel": "gemm_nt_kernel (Cholesky trailing update, K=256, v_mfma_f64_4x4x4)",
+            "bound": "mfma",
+            "achieved": achieved,
+            "peak": peak,
+            "unit": "TFLOP/s",
+            "frac": achieved / peak,
+            "traffic": None,
+            "launches": n_syrk,
+            "avg_launch_ms": ms_syrk / max(n_syrk, 1),
+            "algorithmic_flops_per_launch": fl_syrk / max(n_syrk, 1),
+        },
+        "stage_ms_per_step": {
+            "cov": ms_cov / args.steps,
+            "cov_GBps": (by_cov / max(ms_cov, 1e-9)) * 1e-6,
+            "chol_trailing_update": ms_syrk / args.steps,
+            "panel_potf2_trsm_update": ms_pan / args.steps,
+            "alpha_solve_mll": ms_sol / args.steps,
+            "predict": ms_pre / args.steps,
+        },
+        "first_fit_incl_upload_s": t_build,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,6 +151,10 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--cpu-sample-n", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="replicas", choices=["replicas", "sharded"],
+                    help="N>1: independent fits per GPU (default, the metric's unit is a fit) or ONE fit row-block "
+                         "sharded over the GPUs with the RCCL panel all-gather (gpmi355x.dist)")
+    ap.add_argument("--no-sharded-leg", action="store_true", help="N>1 replicas mode: skip the extra sharded measurement")
     args = ap.parse_args()
 
     import torch
@@ -118,7 +181,13 @@ def main():
     log_noise = math.log(0.1)
     ctx = g.Context.default(local_rank)
     t_build0 = time.perf_counter()
-    gp = g.GP(x, y, g.MeanZero(), g.SEArd(ll, 0.0), log_noise, dtype=np_dt, ctx=ctx)  # uploads x, first fit
+    sharded = args.mode == "sharded" and world > 1
+    if sharded:
+        from gpmi355x import dist as gd
+
+        gp = gd.ShardedGPE(x, y, g.MeanZero(), g.SEArd(ll, 0.0), log_noise, dtype=np_dt, comm=gd.TorchDistComm(), ctx=ctx)
+    else:
+        gp = g.GP(x, y, g.MeanZero(), g.SEArd(ll, 0.0), log_noise, dtype=np_dt, ctx=ctx)  # uploads x, first fit
     t_build = time.perf_counter() - t_build0
     base = np.asarray(gp.get_params())
 
@@ -154,56 +223,60 @@ def main():
         elapsed = float(t.item())
 
     assert np.all(np.isfinite(mu)) and np.all(np.isfinite(s2)) and math.isfinite(gp.mll)
+
+    out = None
     if rank == 0:
-        peak = FP64_MFMA_PEAK_TFLOPS if args.dtype == "f64" else FP32_MFMA_PEAK_TFLOPS
-        achieved = (fl_syrk / max(ms_syrk, 1e-9)) * 1e-9  # flop/ms -> TFLOP/s
-        out = {
-            "metric": "GP fits/sec (update_mll!+predict_f)",
-            "value": world * args.steps / elapsed,
-            "unit": "GP fits/sec",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": args.dtype,
-            "data": "synthetic",
-            "config": {
-                "workload": f"N={n}, d={d}, SEArd + MeanZero, {args.dtype}, P={p} test points, full_cov=false "
-                            "(BASELINE.json configs[1])",
-                "parallelism": "single GPU" if world == 1 else f"{world} independent replicas, one per GPU (no collective)",
-                "mll": gp.mll,
-            },
-            "roofline": {
-                "kernel": "gemm_nt_kernel (Cholesky trailing update, K=256)",
-                "bound": "mfma",
-                "achieved": achieved,
-                "peak": peak,
-                "unit": "TFLOP/s",
-                "frac": achieved / peak,
-                "traffic": None,
-                "launches": n_syrk,
-                "avg_launch_ms": ms_syrk / max(n_syrk, 1),
-                "algorithmic_flops_per_launch": fl_syrk / max(n_syrk, 1),
-            },
-            "stage_ms_per_step": {
-                "cov": ms_cov / args.steps,
-                "cov_GBps": (by_cov / max(ms_cov, 1e-9)) * 1e-6,
-                "chol_trailing_update": ms_syrk / args.steps,
-                "panel_potf2_trsm_update": ms_pan / args.steps,
-                "alpha_solve_mll": ms_sol / args.steps,
-                "predict": ms_pre / args.steps,
-            },
-            "first_fit_incl_upload_s": t_build,
-        }
+        out = _main_json(args, world, elapsed, gp, n, d, p, fl_syrk, ms_syrk, n_syrk, ms_cov, by_cov, ms_pan, ms_sol, ms_pre,
+                         t_build, "strong" if sharded else "weak", sharded)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, d, p, ll, min(args.cpu_sample_n, n))
-        print(json.dumps(out))
+
+    # Extra leg (N > 1, replicas mode): the SAME workload as ONE fit row-block sharded over all GPUs, so that the
+    # RCCL panel all-gather path is exercised and timed on real multi-GPU hardware.  It is reported inside the one
+    # JSON line as "sharded_leg"; a failure or a hang there must never cost the main measurement, hence the watchdog.
+    if world > 1 and not sharded and not args.no_sharded_leg:
+        import threading
+
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(240.0):
+                if rank == 0:
+                    out["sharded_leg"] = {"error": "no result within 240 s (watchdog)"}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            from gpmi355x import dist as gd
+
+            sgp = gd.ShardedGPE(x, y, g.MeanZero(), g.SEArd(ll, 0.0), log_noise, dtype=np_dt, comm=gd.TorchDistComm(), ctx=ctx)
+            barrier()
+            ts = time.perf_counter()
+            nrep = 2
+            for i in range(nrep):
+                sgp.set_params(base + 1e-3 * (i + 1) * np.where(np.arange(len(base)) == 0, 0.0, 1.0))
+                sgp.update_mll()
+                smu, ss2 = sgp.predict_f(xpred)
+            barrier()
+            dt = (time.perf_counter() - ts) / nrep
+            leg = {"workload": f"ONE fit+predict of N={n} row-block sharded over {world} GPUs (RCCL panel all-gather)",
+                   "fits_per_sec": 1.0 / dt, "ms_per_step": 1e3 * dt, "mll": sgp.mll,
+                   "finite": bool(np.all(np.isfinite(smu)) and np.all(np.isfinite(ss2)))}
+        except Exception as e:  # noqa: BLE001
+            leg = {"error": repr(e)[:300]}
+        done.set()
+        if rank == 0:
+            out["sharded_leg"] = leg
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 if __name__ == "__main__":

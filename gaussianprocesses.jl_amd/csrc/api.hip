@@ -223,6 +223,32 @@ static void cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* invdiag, int64_t np
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// device-pointer building blocks (row-block sharded path; also what cholesky_lower is made of)
+// ---------------------------------------------------------------------------------------------
+// in-place factorisation of ONE nb x nb diagonal block (nb multiple of 64): potf2 / trsm / update inside the block
+template <typename T>
+static void potrf_block(gpmi_ctx* c, T* A, int64_t ld, int64_t nb, T* invdiag, int64_t pivot_base, int* d_info) {
+    for (int64_t j0 = 0; j0 < nb; j0 += IB) {
+        launch_potf2<T>(c, A + j0 * ld + j0, ld, invdiag + j0, d_info, pivot_base + j0);
+        const int64_t r0 = j0 + IB, M = nb - r0;
+        if (M <= 0) continue;
+        launch_trsm_rows<T>(c, A + r0 * ld + j0, ld, A + j0 * ld + j0, ld, invdiag + j0, M, d_info);
+        launch_gemm_nt<T>(c, A + r0 * ld + r0, ld, A + r0 * ld + j0, ld, A + r0 * ld + j0, ld, M, nb - r0, IB, 0, d_info);
+    }
+}
+// X[M x nb] <- X * L^-T against a factored nb x nb block L (ldl), 64 columns at a time
+template <typename T>
+static void rows_solve_block(gpmi_ctx* c, T* X, int64_t ldx, int64_t M, const T* L, int64_t ldl, const T* invdiag,
+                             int64_t nb, const int* d_info) {
+    for (int64_t j0 = 0; j0 < nb; j0 += IB) {
+        launch_trsm_rows<T>(c, X + j0, ldx, L + j0 * ldl + j0, ldl, invdiag + j0, M, d_info);
+        const int64_t nc = nb - (j0 + IB);
+        if (nc > 0) launch_gemm_nt<T>(c, X + j0 + IB, ldx, X + j0, ldx, L + (j0 + IB) * ldl + j0, ldl, M, nc, IB, 0, d_info);
+    }
+}
+
 template <typename T>
 static int fit_t(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int64_t n_noise, const void* y_minus_mu,
                  double* mll_out, void* alpha_out, int64_t* info_out) {
@@ -258,7 +284,7 @@ static int fit_t(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int
     {
         ProfScope ps(c, GPMI_PROF_SOLVE, (double)npad * (double)npad * 0.5 * sizeof(T));
         for (int64_t j0 = npad - IB; j0 >= 0; j0 -= IB)
-            launch_bsolve_step<T>(c, A, ld, j0, A + npad * ld, (T*)gp->alpha);
+            launch_bsolve_step<T>(c, A + j0 * ld, ld, j0, A + npad * ld, (T*)gp->alpha);
         launch_finalize<T>(c, A, ld, n, (const T*)gp->ymu, (const T*)gp->alpha, c->d_scal);
     }
     int h_info = 0;
@@ -388,7 +414,7 @@ static int solve_t(gpmi_gp* gp, int64_t nrhs, void* b_inout, bool backward) {
     if (backward) {
         T* tmp = (T*)gp->small;
         for (int64_t r = 0; r < nrhs; ++r) {
-            for (int64_t j0 = npad - IB; j0 >= 0; j0 -= IB) launch_bsolve_step<T>(c, A, ld, j0, R + r * ld, tmp);
+            for (int64_t j0 = npad - IB; j0 >= 0; j0 -= IB) launch_bsolve_step<T>(c, A + j0 * ld, ld, j0, R + r * ld, tmp);
             GPMI_HIP(c, hipMemcpyAsync(R + r * ld, tmp, (size_t)npad * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
         }
     }
@@ -627,6 +653,163 @@ int gpmi_mfma_peak(gpmi_ctx* c, int dtype, double* tflops_out) {
     if (!c || !tflops_out || (dtype != 64 && dtype != 32)) return GPMI_EARG;
     GPMI_HIP(c, hipSetDevice(c->device));
     return dtype == 64 ? mfma_peak<double>(c, tflops_out) : mfma_peak<float>(c, tflops_out);
+}
+
+/* ---- device-pointer building blocks of the row-block sharded path --------------------------- */
+int gpmi_dev_set_kernel(gpmi_ctx* c, const gpmi_kernel* k, int d, double* kdiag_out) {
+    if (!c || !k) return GPMI_EARG;
+    GPMI_HIP(c, hipSetDevice(c->device));
+    int rc = upload_program(c, k, d);
+    if (rc == GPMI_OK && kdiag_out) *kdiag_out = c->h_prog->kdiag;
+    return rc;
+}
+
+int gpmi_dev_assemble(gpmi_ctx* c, int dtype, int d, int64_t n, const void* x_dev, int64_t row_off, int64_t nrows,
+                      const double* log_noise, int64_t n_noise, void* A_dev, int64_t ld, int64_t ncols) {
+    if (!c || !x_dev || !A_dev || !log_noise || (n_noise != 1 && n_noise != n) || nrows <= 0) return GPMI_EARG;
+    GPMI_HIP(c, hipSetDevice(c->device));
+    double nugget = 0.0;
+    double* d_noise = nullptr;
+    if (n_noise == 1) {
+        nugget = exp(2.0 * log_noise[0]);
+    } else {
+        std::vector<double> nv((size_t)n);
+        for (int64_t i = 0; i < n; ++i) nv[(size_t)i] = exp(2.0 * log_noise[i]);
+        GPMI_HIP(c, hipMalloc(&d_noise, (size_t)n * sizeof(double)));
+        GPMI_HIP(c, hipMemcpy(d_noise, nv.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    }
+    const int64_t na = std::max<int64_t>(0, std::min<int64_t>(nrows, n - row_off));
+    const int flags = COV_LOWER | COV_NUGGET | COV_PAD_IDENTITY;
+    const int64_t xoff = std::min<int64_t>(row_off, n - 1) * d;
+    if (dtype == 64)
+        launch_cov<double>(c, (const double*)x_dev + xoff, na, (const double*)x_dev, n, d, (double*)A_dev, ld, nrows, ncols,
+                           flags, nugget, d_noise, row_off);
+    else
+        launch_cov<float>(c, (const float*)x_dev + xoff, na, (const float*)x_dev, n, d, (float*)A_dev, ld, nrows, ncols, flags,
+                          nugget, d_noise, row_off);
+    if (d_noise) {
+        GPMI_HIP(c, hipStreamSynchronize(c->stream));
+        hipFree(d_noise);
+    }
+    return GPMI_OK;
+}
+
+int gpmi_dev_cov_rows(gpmi_ctx* c, int dtype, int d, int64_t na, const void* xa_dev, int64_t nb, const void* xb_dev,
+                      void* C_dev, int64_t ldc, int64_t ncols_total) {
+    if (!c || !xa_dev || !xb_dev || !C_dev || na <= 0 || nb <= 0) return GPMI_EARG;
+    GPMI_HIP(c, hipSetDevice(c->device));
+    if (dtype == 64)
+        launch_cov<double>(c, (const double*)xa_dev, na, (const double*)xb_dev, nb, d, (double*)C_dev, ldc, na, ncols_total, 0,
+                           0.0, nullptr);
+    else
+        launch_cov<float>(c, (const float*)xa_dev, na, (const float*)xb_dev, nb, d, (float*)C_dev, ldc, na, ncols_total, 0, 0.0,
+                          nullptr);
+    return GPMI_OK;
+}
+
+int gpmi_dev_potrf_block(gpmi_ctx* c, int dtype, void* A_dev, int64_t ld, int64_t nb, void* invdiag_dev, int64_t pivot_base) {
+    if (!c || !A_dev || !invdiag_dev || nb <= 0 || nb % IB) return GPMI_EARG;
+    GPMI_HIP(c, hipSetDevice(c->device));
+    if (dtype == 64)
+        potrf_block<double>(c, (double*)A_dev, ld, nb, (double*)invdiag_dev, pivot_base, c->d_info);
+    else
+        potrf_block<float>(c, (float*)A_dev, ld, nb, (float*)invdiag_dev, pivot_base, c->d_info);
+    return GPMI_OK;
+}
+
+int gpmi_dev_rows_solve(gpmi_ctx* c, int dtype, void* X_dev, int64_t ldx, int64_t M, const void* L_dev, int64_t ldl,
+                        const void* invdiag_dev, int64_t nb) {
+    if (!c || !X_dev || !L_dev || !invdiag_dev || nb <= 0 || nb % IB) return GPMI_EARG;
+    if (M <= 0) return GPMI_OK;
+    GPMI_HIP(c, hipSetDevice(c->device));
+    if (dtype == 64)
+        rows_solve_block<double>(c, (double*)X_dev, ldx, M, (const double*)L_dev, ldl, (const double*)invdiag_dev, nb, c->d_info);
+    else
+        rows_solve_block<float>(c, (float*)X_dev, ldx, M, (const float*)L_dev, ldl, (const float*)invdiag_dev, nb, c->d_info);
+    return GPMI_OK;
+}
+
+int gpmi_dev_update(gpmi_ctx* c, int dtype, void* C_dev, int64_t ldc, const void* A_dev, int64_t lda, const void* B_dev,
+                    int64_t ldb, int64_t M, int64_t N, int64_t K, int mode, int g0, int G, int nstair_tiles) {
+    if (!c || !C_dev || !A_dev || !B_dev || K <= 0 || K % IB || mode < 0 || mode > 2 || (mode == 2 && G <= 0)) return GPMI_EARG;
+    if (M <= 0 || N <= 0) return GPMI_OK;
+    GPMI_HIP(c, hipSetDevice(c->device));
+    TileShape sh{0, 0, mode, g0, G, nstair_tiles};
+    if (dtype == 64)
+        launch_gemm_shape<double>(c, (double*)C_dev, ldc, (const double*)A_dev, lda, (const double*)B_dev, ldb, M, N, K, sh, c->d_info);
+    else
+        launch_gemm_shape<float>(c, (float*)C_dev, ldc, (const float*)A_dev, lda, (const float*)B_dev, ldb, M, N, K, sh, c->d_info);
+    return GPMI_OK;
+}
+
+int gpmi_dev_bsolve_block(gpmi_ctx* c, int dtype, const void* Lrows_dev, int64_t ld, int64_t c0, int64_t nb, void* z_dev,
+                          void* alpha_dev) {
+    if (!c || !Lrows_dev || !z_dev || !alpha_dev || nb <= 0 || nb % IB) return GPMI_EARG;
+    GPMI_HIP(c, hipSetDevice(c->device));
+    const size_t es = dtype == 64 ? 8 : 4;
+    for (int64_t j = nb - IB; j >= 0; j -= IB) {
+        const char* row = (const char*)Lrows_dev + (size_t)(j * ld) * es;
+        if (dtype == 64)
+            launch_bsolve_step<double>(c, (const double*)row, ld, c0 + j, (double*)z_dev, (double*)alpha_dev);
+        else
+            launch_bsolve_step<float>(c, (const float*)row, ld, c0 + j, (float*)z_dev, (float*)alpha_dev);
+    }
+    return GPMI_OK;
+}
+
+int gpmi_dev_row_gemv(gpmi_ctx* c, int dtype, const void* R_dev, int64_t ldr, int64_t P, int64_t n, const void* v_dev,
+                      const void* add_dev, void* out_dev) {
+    if (!c || !R_dev || !v_dev || !add_dev || !out_dev) return GPMI_EARG;
+    GPMI_HIP(c, hipSetDevice(c->device));
+    if (dtype == 64)
+        launch_row_gemv<double>(c, (const double*)R_dev, ldr, P, n, (const double*)v_dev, (const double*)add_dev, (double*)out_dev);
+    else
+        launch_row_gemv<float>(c, (const float*)R_dev, ldr, P, n, (const float*)v_dev, (const float*)add_dev, (float*)out_dev);
+    return GPMI_OK;
+}
+
+int gpmi_dev_row_var(gpmi_ctx* c, int dtype, const void* R_dev, int64_t ldr, int64_t P, int64_t n, double kdiag, void* out_dev) {
+    if (!c || !R_dev || !out_dev) return GPMI_EARG;
+    GPMI_HIP(c, hipSetDevice(c->device));
+    if (dtype == 64)
+        launch_row_var<double>(c, (const double*)R_dev, ldr, P, n, kdiag, (double*)out_dev);
+    else
+        launch_row_var<float>(c, (const float*)R_dev, ldr, P, n, kdiag, (float*)out_dev);
+    return GPMI_OK;
+}
+
+int gpmi_dev_logdiag_sum(gpmi_ctx* c, int dtype, const void* A_dev, int64_t ld, int64_t nrows, int64_t col_off, double* out) {
+    if (!c || !A_dev || !out || nrows < 0) return GPMI_EARG;
+    GPMI_HIP(c, hipSetDevice(c->device));
+    if (dtype == 64)
+        launch_logdiag<double>(c, (const double*)A_dev, ld, nrows, col_off, c->d_scal);
+    else
+        launch_logdiag<float>(c, (const float*)A_dev, ld, nrows, col_off, c->d_scal);
+    GPMI_HIP(c, hipMemcpyAsync(c->h_scal, c->d_scal, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    GPMI_HIP(c, hipStreamSynchronize(c->stream));
+    *out = c->h_scal[0];
+    return GPMI_OK;
+}
+
+int gpmi_dev_info(gpmi_ctx* c, int reset, int64_t* info_out) {
+    if (!c) return GPMI_EARG;
+    GPMI_HIP(c, hipSetDevice(c->device));
+    if (reset) GPMI_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
+    if (info_out) {
+        int h = 0;
+        GPMI_HIP(c, hipMemcpyAsync(&h, c->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        GPMI_HIP(c, hipStreamSynchronize(c->stream));
+        *info_out = h;
+    }
+    return GPMI_OK;
+}
+
+int gpmi_dev_sync(gpmi_ctx* c) {
+    if (!c) return GPMI_EARG;
+    GPMI_HIP(c, hipSetDevice(c->device));
+    GPMI_HIP(c, hipStreamSynchronize(c->stream));
+    GPMI_HIP(c, hipGetLastError());
+    return GPMI_OK;
 }
 
 }  // extern "C"

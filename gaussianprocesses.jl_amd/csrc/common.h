@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../../include/gpmi.h"
+#include "tile_order.h"
 
 namespace gpmi {
 
@@ -125,15 +126,24 @@ enum CovFlags { COV_LOWER = 1, COV_NUGGET = 2, COV_PAD_IDENTITY = 4 };
 
 // C[i][j] = k(xa_i, xb_j) for i < nrows_total, j < ncols_total (row-major, ld = ldc).
 // rows >= na / cols >= nb are padding: 0, or the identity when COV_PAD_IDENTITY.
+// row_off = global index of local row 0 (diagonal / nugget / lower-skip tests use row_off + i; nugget_vec is
+// indexed by the global row).
 template <typename T>
 void launch_cov(gpmi_ctx* ctx, const T* xa, int64_t na, const T* xb, int64_t nb, int d, T* C, int64_t ldc,
-                int64_t nrows_total, int64_t ncols_total, int flags, double nugget, const double* nugget_vec);
+                int64_t nrows_total, int64_t ncols_total, int flags, double nugget, const double* nugget_vec,
+                int64_t row_off = 0);
 
 // C[M x N] -= A[M x K] * B[N x K]'   (all row-major; K % 16 == 0 for double, % 32 for float)
 // lower != 0: only tiles that intersect {col <= row} are computed (C is a trailing square).
 template <typename T>
 void launch_gemm_nt(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M,
                     int64_t N, int64_t K, int lower, const int* info);
+
+// same kernel with an explicit tile shape (mode 2 = staircase of a row-block-cyclic shard, tile_order.h);
+// shape.ntm / shape.ntn are filled in from M and N
+template <typename T>
+void launch_gemm_shape(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M,
+                       int64_t N, int64_t K, TileShape shape, const int* info);
 
 // in-place Cholesky of the 64 x 64 block at A (row-major, ld): lower factor; upper part zeroed.
 // invdiag[0..64) receives 1 / L_jj.  On a non-positive pivot j (0-based) writes *info = pivot_base + j + 1.
@@ -147,8 +157,9 @@ void launch_trsm_rows(gpmi_ctx* ctx, T* X, int64_t ldx, const T* L11, int64_t ld
 
 // One step of the backward solve  L' alpha = z  for the 64-block starting at j0:
 //   alpha[j0..j0+64) = L_bb^-T z[j0..);  z[0..j0) -= L[j0..j0+64, 0..j0)' alpha_b
+// Arow points at row j0 of the factor (so a shard can pass its local copy of that block-row).
 template <typename T>
-void launch_bsolve_step(gpmi_ctx* ctx, const T* A, int64_t ld, int64_t j0, T* z, T* alpha);
+void launch_bsolve_step(gpmi_ctx* ctx, const T* Arow, int64_t ld, int64_t j0, T* z, T* alpha);
 
 // mll / logdet / y'alpha  ->  out[0] = mll, out[1] = logdet, out[2] = y'alpha
 template <typename T>
@@ -161,6 +172,9 @@ void launch_row_gemv(gpmi_ctx* ctx, const T* R, int64_t ldr, int64_t P, int64_t 
 // var[p] = max(kdiag - sum_j R[p][j]^2, 0)
 template <typename T>
 void launch_row_var(gpmi_ctx* ctx, const T* R, int64_t ldr, int64_t P, int64_t n, double kdiag, T* var);
+
+template <typename T>
+void launch_logdiag(gpmi_ctx* ctx, const T* A, int64_t ld, int64_t nrows, int64_t col_off, double* out);
 
 // isolated timing of the update kernel on random operands (variant 0 = product kernel)
 template <typename T>

@@ -69,7 +69,8 @@ template <typename T, int DMAX>
 __global__ __launch_bounds__(256) void cov_kernel(const T* __restrict__ xa, int64_t na, const T* __restrict__ xb,
                                                   int64_t nb, int d, T* __restrict__ C, int64_t ldc, int64_t nrows,
                                                   int64_t ncols, const DevProgram* __restrict__ prog, int flags,
-                                                  double nugget, const double* __restrict__ nugget_vec) {
+                                                  double nugget, const double* __restrict__ nugget_vec,
+                                                  int64_t row_off) {
     constexpr int VEC = 16 / sizeof(T);
     constexpr int TC = 64 * VEC;
     constexpr int TR = 64;
@@ -80,13 +81,15 @@ __global__ __launch_bounds__(256) void cov_kernel(const T* __restrict__ xa, int6
 
     const int64_t row0 = (int64_t)blockIdx.y * TR;
     const int64_t col0 = (int64_t)blockIdx.x * TC;
-    if ((flags & COV_LOWER) && col0 > row0 + TR - 1) return;  // tile strictly above the diagonal
+    // row_off: global index of local row 0 (a shard assembles only its own block-rows of K)
+    if ((flags & COV_LOWER) && col0 > row_off + row0 + TR - 1) return;  // tile strictly above the diagonal
 
     const int tid = threadIdx.x;
     for (int e = tid; e < TR * d; e += 256) {
         int r = e / d, k = e - r * d;
         int64_t gr = row0 + r;
         gr = gr < na ? gr : na - 1;
+        gr = gr < 0 ? 0 : gr;
         sa[e] = xa[gr * d + k];
     }
     for (int e = tid; e < TC * d; e += 256) {
@@ -230,10 +233,11 @@ __global__ __launch_bounds__(256) void cov_kernel(const T* __restrict__ xa, int6
         for (int q = 0; q < VEC; ++q) {
             const int64_t gcol = gcol0 + q;
             T v = st[0][q];
+            const int64_t gg = row_off + grow;  // global row
             if (grow >= na || gcol >= nb) {
-                v = ((flags & COV_PAD_IDENTITY) && grow == gcol) ? T(1) : T(0);
-            } else if ((flags & COV_NUGGET) && grow == gcol) {
-                v += nugget_vec ? (T)nugget_vec[grow] : (T)nugget;  // GPE.jl:173,181-183 / GP.jl:104-108
+                v = ((flags & COV_PAD_IDENTITY) && gg == gcol) ? T(1) : T(0);
+            } else if ((flags & COV_NUGGET) && gg == gcol) {
+                v += nugget_vec ? (T)nugget_vec[gg] : (T)nugget;  // GPE.jl:173,181-183 / GP.jl:104-108
             }
             out[q] = v;
         }
@@ -243,7 +247,8 @@ __global__ __launch_bounds__(256) void cov_kernel(const T* __restrict__ xa, int6
 
 template <typename T, int DMAX>
 void launch_cov_t(gpmi_ctx* ctx, const T* xa, int64_t na, const T* xb, int64_t nb, int d, T* C, int64_t ldc,
-                  int64_t nrows_total, int64_t ncols_total, int flags, double nugget, const double* nugget_vec) {
+                  int64_t nrows_total, int64_t ncols_total, int flags, double nugget, const double* nugget_vec,
+                  int64_t row_off) {
     constexpr int VEC = 16 / sizeof(T);
     constexpr int TC = 64 * VEC;
     constexpr int TR = 64;
@@ -252,31 +257,32 @@ void launch_cov_t(gpmi_ctx* ctx, const T* xa, int64_t na, const T* xb, int64_t n
     auto kern = cov_kernel<T, DMAX>;
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, xa, na, xb, nb, d, C, ldc, nrows_total, ncols_total,
-                       ctx->d_prog, flags, nugget, nugget_vec);
+                       ctx->d_prog, flags, nugget, nugget_vec, row_off);
 }
 
 }  // namespace
 
 template <typename T>
 void launch_cov(gpmi_ctx* ctx, const T* xa, int64_t na, const T* xb, int64_t nb, int d, T* C, int64_t ldc,
-                int64_t nrows_total, int64_t ncols_total, int flags, double nugget, const double* nugget_vec) {
+                int64_t nrows_total, int64_t ncols_total, int flags, double nugget, const double* nugget_vec,
+                int64_t row_off) {
     // algorithmic bytes: one write per generated entry (lower-triangle tiles only when COV_LOWER)
     double entries = (flags & COV_LOWER) ? 0.5 * (double)nrows_total * ((double)ncols_total + 1.0)
                                          : (double)nrows_total * (double)ncols_total;
     ProfScope ps(ctx, GPMI_PROF_COV, entries * sizeof(T));
     if (d <= 4)
-        launch_cov_t<T, 4>(ctx, xa, na, xb, nb, d, C, ldc, nrows_total, ncols_total, flags, nugget, nugget_vec);
+        launch_cov_t<T, 4>(ctx, xa, na, xb, nb, d, C, ldc, nrows_total, ncols_total, flags, nugget, nugget_vec, row_off);
     else if (d <= 8)
-        launch_cov_t<T, 8>(ctx, xa, na, xb, nb, d, C, ldc, nrows_total, ncols_total, flags, nugget, nugget_vec);
+        launch_cov_t<T, 8>(ctx, xa, na, xb, nb, d, C, ldc, nrows_total, ncols_total, flags, nugget, nugget_vec, row_off);
     else if (d <= 16)
-        launch_cov_t<T, 16>(ctx, xa, na, xb, nb, d, C, ldc, nrows_total, ncols_total, flags, nugget, nugget_vec);
+        launch_cov_t<T, 16>(ctx, xa, na, xb, nb, d, C, ldc, nrows_total, ncols_total, flags, nugget, nugget_vec, row_off);
     else
-        launch_cov_t<T, 0>(ctx, xa, na, xb, nb, d, C, ldc, nrows_total, ncols_total, flags, nugget, nugget_vec);
+        launch_cov_t<T, 0>(ctx, xa, na, xb, nb, d, C, ldc, nrows_total, ncols_total, flags, nugget, nugget_vec, row_off);
 }
 
 template void launch_cov<double>(gpmi_ctx*, const double*, int64_t, const double*, int64_t, int, double*, int64_t,
-                                 int64_t, int64_t, int, double, const double*);
+                                 int64_t, int64_t, int, double, const double*, int64_t);
 template void launch_cov<float>(gpmi_ctx*, const float*, int64_t, const float*, int64_t, int, float*, int64_t, int64_t,
-                                int64_t, int, double, const double*);
+                                int64_t, int, double, const double*, int64_t);
 
 }  // namespace gpmi

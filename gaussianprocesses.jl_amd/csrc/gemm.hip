@@ -119,7 +119,7 @@ struct QueueArgs {
 template <typename T, int VARIANT>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int64_t ldc, const T* __restrict__ A,
                                                          int64_t lda, const T* __restrict__ B, int64_t ldb, int64_t M,
-                                                         int64_t N, int64_t K, int lower, int ntm, int ntn,
+                                                         int64_t N, int64_t K, TileShape shape,
                                                          unsigned long long* __restrict__ queue, QueueArgs qa,
                                                          const int* __restrict__ info) {
     using MF = Mfma<T>;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
         }
         if (t >= cend) break;
         int ti, tj;
-        tile_decode(t, ntm, ntn, lower, &ti, &tj);
+        tile_decode(t, shape, &ti, &tj);
         const int64_t m0 = (int64_t)ti * BM, n0 = (int64_t)tj * BN;
 
         // Staging: every thread moves 4 x 16-B chunks of A and of B per slab straight from global
@@ -347,10 +347,11 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(T* out, int iters) {
 
 template <typename T, int V>
 static void launch_persistent(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M,
-                              int64_t N, int64_t K, int lower, const int* info) {
-    const int ntm = (int)((M + GEMM_BM - 1) / GEMM_BM);
-    const int ntn = (int)((N + GEMM_BN - 1) / GEMM_BN);
-    const int64_t ntiles = tile_count(ntm, ntn, lower);
+                              int64_t N, int64_t K, TileShape shape, const int* info) {
+    shape.ntm = (int)((M + GEMM_BM - 1) / GEMM_BM);
+    shape.ntn = (int)((N + GEMM_BN - 1) / GEMM_BN);
+    const int64_t ntiles = tile_count(shape);
+    if (ntiles <= 0) return;
     const int slots = 2 * ctx->num_cus;
     // small launches: one workgroup per tile (rounded up to a multiple of 8 so XCD chunks stay contiguous)
     const int grid = (int)std::min<int64_t>(slots, (ntiles + 7) / 8 * 8);
@@ -364,18 +365,36 @@ static void launch_persistent(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int6
         if (qa.use_queue) ctx->queue_base[x] += (unsigned long long)(qa.start[x + 1] - qa.start[x]);
     }
     hipLaunchKernelGGL((gemm_nt_kernel<T, V>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, C, ldc, A, lda, B, ldb, M, N,
-                       K, lower, ntm, ntn, ctx->d_queue, qa, info);
+                       K, shape, ctx->d_queue, qa, info);
+}
+
+static double shape_entries(int64_t M, int64_t N, const TileShape& s) {
+    if (s.mode == 0) return (double)M * (double)N;
+    if (s.mode == 1) return 0.5 * (double)N * ((double)N + 1.0) + (double)(M - N) * (double)N;
+    TileShape t = s;  // staircase: count whole tiles
+    t.ntm = (int)((M + GEMM_BM - 1) / GEMM_BM);
+    t.ntn = (int)((N + GEMM_BN - 1) / GEMM_BN);
+    return (double)tile_count(t) * GEMM_BM * GEMM_BN;
+}
+
+template <typename T>
+void launch_gemm_shape(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M,
+                       int64_t N, int64_t K, TileShape shape, const int* info) {
+    if (M <= 0 || N <= 0 || K <= 0) return;
+    ProfScope ps(ctx, shape.mode ? GPMI_PROF_SYRK : GPMI_PROF_PANEL, 2.0 * shape_entries(M, N, shape) * (double)K);
+    launch_persistent<T, 0>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info);
 }
 
 template <typename T>
 void launch_gemm_nt(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M,
                     int64_t N, int64_t K, int lower, const int* info) {
-    if (M <= 0 || N <= 0 || K <= 0) return;
-    double entries = lower ? (0.5 * (double)N * ((double)N + 1.0) + (double)(M - N) * (double)N) : (double)M * (double)N;
-    ProfScope ps(ctx, lower ? GPMI_PROF_SYRK : GPMI_PROF_PANEL, 2.0 * entries * (double)K);
-    launch_persistent<T, 0>(ctx, C, ldc, A, lda, B, ldb, M, N, K, lower, info);
+    launch_gemm_shape<T>(ctx, C, ldc, A, lda, B, ldb, M, N, K, TileShape{0, 0, lower ? 1 : 0, 0, 1, 0}, info);
 }
 
+template void launch_gemm_shape<double>(gpmi_ctx*, double*, int64_t, const double*, int64_t, const double*, int64_t, int64_t,
+                                        int64_t, int64_t, TileShape, const int*);
+template void launch_gemm_shape<float>(gpmi_ctx*, float*, int64_t, const float*, int64_t, const float*, int64_t, int64_t,
+                                       int64_t, int64_t, TileShape, const int*);
 template void launch_gemm_nt<double>(gpmi_ctx*, double*, int64_t, const double*, int64_t, const double*, int64_t,
                                      int64_t, int64_t, int64_t, int, const int*);
 template void launch_gemm_nt<float>(gpmi_ctx*, float*, int64_t, const float*, int64_t, const float*, int64_t, int64_t,
@@ -385,7 +404,7 @@ template void launch_gemm_nt<float>(gpmi_ctx*, float*, int64_t, const float*, in
 // ---- isolated timing of the update kernel (tools / bench only) ------------------------------
 template <typename T, int V>
 static void launch_variant(gpmi_ctx* ctx, T* C, int64_t ld, const T* A, int64_t M, int64_t N, int64_t K, int lower) {
-    launch_persistent<T, V>(ctx, C, ld, A, ld, A, ld, M, N, K, lower, nullptr);
+    launch_persistent<T, V>(ctx, C, ld, A, ld, A, ld, M, N, K, TileShape{0, 0, lower ? 1 : 0, 0, 1, 0}, nullptr);
 }
 
 template <typename T>

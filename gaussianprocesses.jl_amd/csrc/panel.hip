@@ -145,12 +145,12 @@ __global__ __launch_bounds__(64) void trsm_rows_kernel(T* __restrict__ X, int64_
 // alpha_b, then all workgroups apply  z[j] -= sum_i L[j0+i][j] * alpha_b[i]  to their 256 columns.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void bsolve_step_kernel(const T* __restrict__ A, int64_t ld, int64_t j0,
+__global__ __launch_bounds__(256) void bsolve_step_kernel(const T* __restrict__ Arow, int64_t ld, int64_t j0,
                                                           T* __restrict__ z, T* __restrict__ alpha) {
     __shared__ T SL[64 * 65];
     __shared__ T sal[64];
     const int tid = threadIdx.x;
-    const T* Lbb = A + j0 * ld + j0;
+    const T* Lbb = Arow + j0;  // Arow = row j0 of the factor
     for (int e = tid; e < 64 * 64; e += 256) {
         const int r = e >> 6, c = e & 63;
         SL[r * 65 + c] = Lbb[(int64_t)r * ld + c];
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void bsolve_step_kernel(const T* __restrict__ 
     __syncthreads();
     const int64_t j = (int64_t)blockIdx.x * 256 + tid;
     if (j < j0) {
-        const T* col = A + j0 * ld + j;
+        const T* col = Arow + j;
         T acc = T(0);
 #pragma unroll 8
         for (int i = 0; i < 64; ++i) acc += col[(int64_t)i * ld] * sal[i];
@@ -214,6 +214,17 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const T* __restrict__ A,
         out[1] = logdet;
         out[2] = dot;
     }
+}
+
+// sum_i log A[i][col_off + i]  (a shard's share of logdet / 2)
+template <typename T>
+__global__ __launch_bounds__(1024) void logdiag_kernel(const T* __restrict__ A, int64_t ld, int64_t nrows, int64_t col_off,
+                                                       double* __restrict__ out) {
+    __shared__ double sh[1024];
+    double sl = 0.0;
+    for (int64_t i = threadIdx.x; i < nrows; i += 1024) sl += log((double)A[i * ld + col_off + i]);
+    const double r = block_sum_1024(sl, sh);
+    if (threadIdx.x == 0) out[0] = r;
 }
 
 template <typename T>
@@ -273,9 +284,9 @@ void launch_trsm_rows(gpmi_ctx* ctx, T* X, int64_t ldx, const T* L11, int64_t ld
                        invdiag, M, info);
 }
 template <typename T>
-void launch_bsolve_step(gpmi_ctx* ctx, const T* A, int64_t ld, int64_t j0, T* z, T* alpha) {
+void launch_bsolve_step(gpmi_ctx* ctx, const T* Arow, int64_t ld, int64_t j0, T* z, T* alpha) {
     const unsigned blocks = (unsigned)(j0 > 0 ? (j0 + 255) / 256 : 1);
-    hipLaunchKernelGGL(bsolve_step_kernel<T>, dim3(blocks), dim3(256), 0, ctx->stream, A, ld, j0, z, alpha);
+    hipLaunchKernelGGL(bsolve_step_kernel<T>, dim3(blocks), dim3(256), 0, ctx->stream, Arow, ld, j0, z, alpha);
 }
 template <typename T>
 void launch_finalize(gpmi_ctx* ctx, const T* A, int64_t ld, int64_t n, const T* y, const T* alpha, double* out) {
@@ -293,13 +304,19 @@ void launch_row_var(gpmi_ctx* ctx, const T* R, int64_t ldr, int64_t P, int64_t n
     hipLaunchKernelGGL(row_var_kernel<T>, dim3((unsigned)P), dim3(256), 0, ctx->stream, R, ldr, n, kdiag, var);
 }
 
+template <typename T>
+void launch_logdiag(gpmi_ctx* ctx, const T* A, int64_t ld, int64_t nrows, int64_t col_off, double* out) {
+    hipLaunchKernelGGL(logdiag_kernel<T>, dim3(1), dim3(1024), 0, ctx->stream, A, ld, nrows, col_off, out);
+}
+
 #define INST(T)                                                                                                   \
     template void launch_potf2<T>(gpmi_ctx*, T*, int64_t, T*, int*, int64_t);                                     \
     template void launch_trsm_rows<T>(gpmi_ctx*, T*, int64_t, const T*, int64_t, const T*, int64_t, const int*);  \
     template void launch_bsolve_step<T>(gpmi_ctx*, const T*, int64_t, int64_t, T*, T*);                           \
     template void launch_finalize<T>(gpmi_ctx*, const T*, int64_t, int64_t, const T*, const T*, double*);         \
     template void launch_row_gemv<T>(gpmi_ctx*, const T*, int64_t, int64_t, int64_t, const T*, const T*, T*);     \
-    template void launch_row_var<T>(gpmi_ctx*, const T*, int64_t, int64_t, int64_t, double, T*);
+    template void launch_row_var<T>(gpmi_ctx*, const T*, int64_t, int64_t, int64_t, double, T*);                  \
+    template void launch_logdiag<T>(gpmi_ctx*, const T*, int64_t, int64_t, int64_t, double*);
 INST(double)
 INST(float)
 

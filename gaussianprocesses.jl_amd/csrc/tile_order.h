@@ -2,9 +2,16 @@
 // (tile count) and the device (tile index -> coordinates).  Plain C++: also compiled by the CPU
 // unit test tests/test_tile_order.py through g++.
 //
-// Order: strips of GROUP tile-rows; inside a strip column-major, so GROUP consecutive tiles share
-// one B panel and the strip's GROUP A panels stay hot while the strip sweeps its columns.
-// lower != 0 keeps only tiles that intersect {col <= row}:  tj <= min(ti, ntn - 1).
+// Which tiles exist is described by TileShape:
+//   ntm x ntn tile grid; row ti keeps columns tj <= cmax(ti) where
+//     mode 0 (rectangle)   cmax = ntn - 1
+//     mode 1 (lower)       cmax = ti                    (C is a trailing square, single GPU)
+//     mode 2 (staircase)   cmax = 2*(g0 + (ti>>1)*G) + (ti&1) for ti < nstair, ntn - 1 beyond
+//                          (row-block-cyclic shard: local 256-row block i is global block g0 + i*G;
+//                           two 128-row tiles per block; rows past the staircase are carried rows)
+//   (mode 1 is mode 2 with g0 = 0, G = 1, nstair = ntm.)
+// Order: strips of GROUP tile-rows.  Modes 0/1: column-major inside a strip, so GROUP consecutive
+// tiles share one B panel and the strip's GROUP A panels stay hot.  Mode 2: row-major inside a strip.
 #pragma once
 #include <stdint.h>
 
@@ -18,40 +25,70 @@ namespace gpmi {
 
 constexpr int TILE_GROUP = 8;
 
-GPMI_HD int64_t strip_count(int s, int ntm, int ntn, int lower) {
-    const int r0 = s * TILE_GROUP;
-    const int h = (ntm - r0 < TILE_GROUP) ? (ntm - r0) : TILE_GROUP;
-    if (!lower) return (int64_t)h * ntn;
-    const int nfull = (r0 + 1 < ntn) ? (r0 + 1) : ntn;
+struct TileShape {
+    int ntm, ntn, mode;
+    int g0, G, nstair;  // mode 2 only
+};
+
+GPMI_HD int stair_cmax(const TileShape& s, int ti) {
+    int c = s.ntn - 1;
+    if (ti < s.nstair) {
+        const int64_t v = 2 * ((int64_t)s.g0 + (int64_t)(ti >> 1) * s.G) + (ti & 1);
+        if (v < c) c = (int)v;
+    }
+    return c;
+}
+
+GPMI_HD int64_t strip_count(int st, const TileShape& s) {
+    const int r0 = st * TILE_GROUP;
+    const int h = (s.ntm - r0 < TILE_GROUP) ? (s.ntm - r0) : TILE_GROUP;
+    if (s.mode == 0) return (int64_t)h * s.ntn;
+    if (s.mode == 2) {
+        int64_t c = 0;
+        for (int i = 0; i < h; ++i) c += stair_cmax(s, r0 + i) + 1;
+        return c;
+    }
+    const int nfull = (r0 + 1 < s.ntn) ? (r0 + 1) : s.ntn;
     int64_t c = (int64_t)h * nfull;
-    const int jmax = (r0 + h - 1 < ntn - 1) ? (r0 + h - 1) : (ntn - 1);
+    const int jmax = (r0 + h - 1 < s.ntn - 1) ? (r0 + h - 1) : (s.ntn - 1);
     for (int tj = r0 + 1; tj <= jmax; ++tj) c += r0 + h - tj;
     return c;
 }
 
-GPMI_HD int64_t tile_count(int ntm, int ntn, int lower) {
+GPMI_HD int64_t tile_count(const TileShape& s) {
     int64_t c = 0;
-    const int ns = (ntm + TILE_GROUP - 1) / TILE_GROUP;
-    for (int s = 0; s < ns; ++s) c += strip_count(s, ntm, ntn, lower);
+    const int ns = (s.ntm + TILE_GROUP - 1) / TILE_GROUP;
+    for (int st = 0; st < ns; ++st) c += strip_count(st, s);
     return c;
 }
 
 // t in [0, tile_count) -> (ti, tj)
-GPMI_HD void tile_decode(int64_t t, int ntm, int ntn, int lower, int* ti, int* tj) {
-    int s = 0;
-    for (;; ++s) {
-        const int64_t c = strip_count(s, ntm, ntn, lower);
+GPMI_HD void tile_decode(int64_t t, const TileShape& s, int* ti, int* tj) {
+    int st = 0;
+    for (;; ++st) {
+        const int64_t c = strip_count(st, s);
         if (t < c) break;
         t -= c;
     }
-    const int r0 = s * TILE_GROUP;
-    const int h = (ntm - r0 < TILE_GROUP) ? (ntm - r0) : TILE_GROUP;
-    if (!lower) {
+    const int r0 = st * TILE_GROUP;
+    const int h = (s.ntm - r0 < TILE_GROUP) ? (s.ntm - r0) : TILE_GROUP;
+    if (s.mode == 0) {
         *tj = (int)(t / h);
         *ti = r0 + (int)(t % h);
         return;
     }
-    const int nfull = (r0 + 1 < ntn) ? (r0 + 1) : ntn;
+    if (s.mode == 2) {
+        for (int i = 0;; ++i) {
+            const int n = stair_cmax(s, r0 + i) + 1;
+            if (t < n) {
+                *ti = r0 + i;
+                *tj = (int)t;
+                return;
+            }
+            t -= n;
+        }
+    }
+    const int nfull = (r0 + 1 < s.ntn) ? (r0 + 1) : s.ntn;
     if (t < (int64_t)h * nfull) {
         *tj = (int)(t / h);
         *ti = r0 + (int)(t % h);

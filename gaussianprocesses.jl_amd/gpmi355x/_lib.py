@@ -23,6 +23,9 @@ SYMBOLS = [
     "gpmi_gp_create", "gpmi_gp_destroy", "gpmi_fit", "gpmi_predict", "gpmi_cov",
     "gpmi_solve", "gpmi_whiten", "gpmi_logdet", "gpmi_factor_to_host",
     "gpmi_profile_enable", "gpmi_profile_get", "gpmi_mfma_peak", "gpmi_bench_gemm",
+    "gpmi_dev_set_kernel", "gpmi_dev_assemble", "gpmi_dev_cov_rows", "gpmi_dev_potrf_block", "gpmi_dev_rows_solve",
+    "gpmi_dev_update", "gpmi_dev_bsolve_block", "gpmi_dev_row_gemv", "gpmi_dev_row_var", "gpmi_dev_logdiag_sum",
+    "gpmi_dev_info", "gpmi_dev_sync",
 ]
 
 
@@ -87,6 +90,19 @@ def load():
     lib.gpmi_profile_get.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(dbl), C.POINTER(dbl)]
     lib.gpmi_mfma_peak.argtypes = [vp, C.c_int, C.POINTER(dbl)]
     lib.gpmi_bench_gemm.argtypes = [vp, C.c_int, i64, i64, i64, C.c_int, C.c_int, C.c_int, C.POINTER(dbl)]
+    ci = C.c_int
+    lib.gpmi_dev_set_kernel.argtypes = [vp, C.POINTER(GpmiKernel), ci, C.POINTER(dbl)]
+    lib.gpmi_dev_assemble.argtypes = [vp, ci, ci, i64, vp, i64, i64, C.POINTER(dbl), i64, vp, i64, i64]
+    lib.gpmi_dev_cov_rows.argtypes = [vp, ci, ci, i64, vp, i64, vp, vp, i64, i64]
+    lib.gpmi_dev_potrf_block.argtypes = [vp, ci, vp, i64, i64, vp, i64]
+    lib.gpmi_dev_rows_solve.argtypes = [vp, ci, vp, i64, i64, vp, i64, vp, i64]
+    lib.gpmi_dev_update.argtypes = [vp, ci, vp, i64, vp, i64, vp, i64, i64, i64, i64, ci, ci, ci, ci]
+    lib.gpmi_dev_bsolve_block.argtypes = [vp, ci, vp, i64, i64, i64, vp, vp]
+    lib.gpmi_dev_row_gemv.argtypes = [vp, ci, vp, i64, i64, i64, vp, vp, vp]
+    lib.gpmi_dev_row_var.argtypes = [vp, ci, vp, i64, i64, i64, dbl, vp]
+    lib.gpmi_dev_logdiag_sum.argtypes = [vp, ci, vp, i64, i64, i64, C.POINTER(dbl)]
+    lib.gpmi_dev_info.argtypes = [vp, ci, C.POINTER(i64)]
+    lib.gpmi_dev_sync.argtypes = [vp]
     _lib = lib
     return lib
 

@@ -11,23 +11,42 @@ SRC = r"""
 #include <set>
 #include <utility>
 #include "tile_order.h"
+using gpmi::TileShape;
+static int check(const TileShape& s) {
+    std::set<std::pair<int,int>> want, got;
+    for (int i = 0; i < s.ntm; ++i)
+        for (int j = 0; j < s.ntn; ++j) {
+            bool ok = true;
+            if (s.mode == 1) ok = j <= i;
+            if (s.mode == 2 && i < s.nstair) ok = j <= 2 * (s.g0 + (i >> 1) * s.G) + (i & 1);
+            if (ok) want.insert({i, j});
+        }
+    int64_t n = gpmi::tile_count(s);
+    if (n != (int64_t)want.size()) return 1;
+    for (int64_t t = 0; t < n; ++t) { int ti, tj; gpmi::tile_decode(t, s, &ti, &tj); got.insert({ti, tj}); }
+    return got != want;
+}
 int main() {
     int bad = 0, cases = 0;
-    for (int lower = 0; lower <= 1; ++lower)
+    for (int mode = 0; mode <= 1; ++mode)
         for (int ntm = 1; ntm <= 41; ++ntm)
-            for (int ntn = 1; ntn <= (lower ? ntm : 41); ++ntn) {
-                ++cases;
-                std::set<std::pair<int,int>> want, got;
-                for (int i = 0; i < ntm; ++i) for (int j = 0; j < ntn; ++j) if (!lower || j <= i) want.insert({i, j});
-                int64_t n = gpmi::tile_count(ntm, ntn, lower);
-                if (n != (int64_t)want.size()) { ++bad; continue; }
-                for (int64_t t = 0; t < n; ++t) { int ti, tj; gpmi::tile_decode(t, ntm, ntn, lower, &ti, &tj); got.insert({ti, tj}); }
-                if (got != want) ++bad;
-            }
-    // locality: 8 consecutive tiles of a full interior strip share one column
+            for (int ntn = 1; ntn <= (mode ? ntm : 41); ++ntn) { ++cases; bad += check(TileShape{ntm, ntn, mode, 0, 1, 0}); }
+    // staircase (row-block-cyclic shards): G ranks, first owned block g0, carried rows past the staircase
+    for (int G = 1; G <= 4; ++G)
+        for (int g0 = 0; g0 < G + 2; ++g0)
+            for (int nblk = 0; nblk <= 9; ++nblk)
+                for (int extra = 0; extra <= 2; ++extra) {
+                    int ntm = 2 * nblk + extra; if (ntm == 0) continue;
+                    int ntn = 2 * (g0 + (nblk ? (nblk - 1) * G : 0)) + 2 + 3;   // wider than the last stair
+                    for (int cut = 0; cut <= 4; cut += 2) { ++cases; bad += check(TileShape{ntm, ntn - cut > 0 ? ntn - cut : 1, 2, g0, G, 2 * nblk}); }
+                }
+    // mode 1 == mode 2 with (g0, G, nstair) = (0, 1, ntm): same tile SET
+    for (int ntm = 1; ntm <= 20; ++ntm) { ++cases; bad += gpmi::tile_count(TileShape{ntm, ntm, 1, 0, 1, 0}) != gpmi::tile_count(TileShape{ntm, ntm, 2, 0, 1, ntm}); }
+    // locality: 8 consecutive tiles of a full interior strip share one column (mode 1)
     int ti0, tj0, ti7, tj7;
-    int64_t base = 0; for (int s = 0; s < 3; ++s) base += gpmi::strip_count(s, 64, 64, 1);
-    gpmi::tile_decode(base, 64, 64, 1, &ti0, &tj0); gpmi::tile_decode(base + 7, 64, 64, 1, &ti7, &tj7);
+    TileShape s{64, 64, 1, 0, 1, 0};
+    int64_t base = 0; for (int st = 0; st < 3; ++st) base += gpmi::strip_count(st, s);
+    gpmi::tile_decode(base, s, &ti0, &tj0); gpmi::tile_decode(base + 7, s, &ti7, &tj7);
     if (!(tj0 == 0 && tj7 == 0 && ti0 == 24 && ti7 == 31)) ++bad;
     std::printf("%d cases, %d bad\n", cases, bad);
     return bad != 0;
