@@ -181,11 +181,12 @@ def main():
     log_noise = math.log(0.1)
     ctx = g.Context.default(local_rank)
     t_build0 = time.perf_counter()
-    sharded = args.mode == "sharded" and world > 1
+    sharded = args.mode == "sharded"
     if sharded:
         from gpmi355x import dist as gd
 
-        gp = gd.ShardedGPE(x, y, g.MeanZero(), g.SEArd(ll, 0.0), log_noise, dtype=np_dt, comm=gd.TorchDistComm(), ctx=ctx)
+        comm = gd.TorchDistComm() if dist is not None else gd.SingleComm()
+        gp = gd.ShardedGPE(x, y, g.MeanZero(), g.SEArd(ll, 0.0), log_noise, dtype=np_dt, comm=comm, ctx=ctx)
     else:
         gp = g.GP(x, y, g.MeanZero(), g.SEArd(ll, 0.0), log_noise, dtype=np_dt, ctx=ctx)  # uploads x, first fit
     t_build = time.perf_counter() - t_build0

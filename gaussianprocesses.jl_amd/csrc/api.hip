@@ -174,47 +174,41 @@ static int upload_program(gpmi_ctx* c, const gpmi_kernel* k, int d) {
     return GPMI_OK;
 }
 
-// Solve the block-column [k0, k0+nbk) of a row matrix R (Mr rows) against the already
-// factored diagonal block of A, then push the update into R's remaining columns:
+// Solve the block-column [k0, k0+nbk) of a row matrix R (Mr rows) against the already factored diagonal block
+// of A (64-column steps: left-looking update + multiplication by the stored inverse, one launch each), then push
+// the update into R's remaining columns:
 //   R[:, k0:kend] <- R[:, k0:kend] * L_kk^-T ;  R[:, kend:npad] -= R[:, k0:kend] * A[kend:npad, k0:kend]'
 template <typename T>
-static void rows_block_solve(gpmi_ctx* c, const T* A, int64_t ld, const T* invdiag, int64_t npad, T* R, int64_t ldr,
+static void rows_block_solve(gpmi_ctx* c, const T* A, int64_t ld, const T* linv, int64_t npad, T* R, int64_t ldr,
                              int64_t Mr, int64_t k0, int64_t nbk) {
     const int64_t kend = k0 + nbk;
-    for (int64_t j0 = k0; j0 < kend; j0 += IB) {
-        launch_trsm_rows<T>(c, R + j0, ldr, A + j0 * ld + j0, ld, invdiag + j0, Mr, nullptr);
-        const int64_t nc = kend - (j0 + IB);
-        if (nc > 0)
-            launch_gemm_nt<T>(c, R + (j0 + IB), ldr, R + j0, ldr, A + (j0 + IB) * ld + j0, ld, Mr, nc, IB, 0, nullptr);
-    }
+    for (int64_t j0 = k0; j0 < kend; j0 += IB)
+        launch_rows64<T>(c, R + k0, ldr, Mr, (int)(j0 - k0), A + j0 * ld + k0, ld, linv + (j0 / IB) * IB * IB, 0, nullptr);
     if (kend < npad)
         launch_gemm_nt<T>(c, R + kend, ldr, R + k0, ldr, A + kend * ld + k0, ld, Mr, npad - kend, nbk, 0, nullptr);
 }
 
 template <typename T>
-static void whiten_rows(gpmi_ctx* c, const T* A, int64_t ld, const T* invdiag, int64_t npad, T* R, int64_t ldr, int64_t Mr) {
+static void whiten_rows(gpmi_ctx* c, const T* A, int64_t ld, const T* linv, int64_t npad, T* R, int64_t ldr, int64_t Mr) {
     for (int64_t k0 = 0; k0 < npad; k0 += NB)
-        rows_block_solve<T>(c, A, ld, invdiag, npad, R, ldr, Mr, k0, std::min<int64_t>(NB, npad - k0));
+        rows_block_solve<T>(c, A, ld, linv, npad, R, ldr, Mr, k0, std::min<int64_t>(NB, npad - k0));
 }
 
 // Blocked right-looking Cholesky of the row-major lower triangle of A (npad x npad), carrying
 // `extra` rows below it (row npad = y) through the panel solves and trailing updates, so that
 // on exit row npad holds z = L^-1 y (the forward half of cK \ y, GPE.jl:208).
 template <typename T>
-static void cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* invdiag, int64_t npad, int64_t extra, int* d_info) {
+static void cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, int64_t npad, int64_t extra, int* d_info) {
     const int64_t Mtot = npad + extra;
     for (int64_t k0 = 0; k0 < npad; k0 += NB) {
         const int64_t nbk = std::min<int64_t>(NB, npad - k0);
         const int64_t kend = k0 + nbk;
         for (int64_t j0 = k0; j0 < kend; j0 += IB) {
-            launch_potf2<T>(c, A + j0 * ld + j0, ld, invdiag + j0, d_info, j0);
+            T* linv_j = linv + (j0 / IB) * IB * IB;
+            launch_diag64<T>(c, A + j0 * ld + j0, ld, linv_j, invdiag + j0, d_info, j0);
             const int64_t r0 = j0 + IB;
-            const int64_t M = Mtot - r0;
-            if (M <= 0) continue;
-            launch_trsm_rows<T>(c, A + r0 * ld + j0, ld, A + j0 * ld + j0, ld, invdiag + j0, M, d_info);
-            const int64_t nc = kend - r0;
-            if (nc > 0)  // in-panel update of the columns still to be factored (K = 64)
-                launch_gemm_nt<T>(c, A + r0 * ld + r0, ld, A + r0 * ld + j0, ld, A + r0 * ld + j0, ld, M, nc, IB, 0, d_info);
+            // rows below: left-looking panel update + TRSM (as a product with L_jj^-1) + diagonal-block updates
+            launch_rows64<T>(c, A + r0 * ld + k0, ld, Mtot - r0, (int)(j0 - k0), A + j0 * ld + k0, ld, linv_j, kend - r0, d_info);
         }
         const int64_t M = Mtot - kend;
         if (M > 0 && kend < npad)  // trailing update (SYRK shape, K = nbk): the MFMA-bound bulk
@@ -223,30 +217,25 @@ static void cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* invdiag, int64_t np
     }
 }
 
-
 // ---------------------------------------------------------------------------------------------
 // device-pointer building blocks (row-block sharded path; also what cholesky_lower is made of)
 // ---------------------------------------------------------------------------------------------
-// in-place factorisation of ONE nb x nb diagonal block (nb multiple of 64): potf2 / trsm / update inside the block
+// in-place factorisation of ONE nb x nb diagonal block (nb multiple of 64); linv gets the nb/64 inverses
 template <typename T>
-static void potrf_block(gpmi_ctx* c, T* A, int64_t ld, int64_t nb, T* invdiag, int64_t pivot_base, int* d_info) {
+static void potrf_block(gpmi_ctx* c, T* A, int64_t ld, int64_t nb, T* linv, T* invdiag, int64_t pivot_base, int* d_info) {
     for (int64_t j0 = 0; j0 < nb; j0 += IB) {
-        launch_potf2<T>(c, A + j0 * ld + j0, ld, invdiag + j0, d_info, pivot_base + j0);
-        const int64_t r0 = j0 + IB, M = nb - r0;
-        if (M <= 0) continue;
-        launch_trsm_rows<T>(c, A + r0 * ld + j0, ld, A + j0 * ld + j0, ld, invdiag + j0, M, d_info);
-        launch_gemm_nt<T>(c, A + r0 * ld + r0, ld, A + r0 * ld + j0, ld, A + r0 * ld + j0, ld, M, nb - r0, IB, 0, d_info);
+        T* linv_j = linv + (j0 / IB) * IB * IB;
+        launch_diag64<T>(c, A + j0 * ld + j0, ld, linv_j, invdiag + j0, d_info, pivot_base + j0);
+        const int64_t r0 = j0 + IB;
+        launch_rows64<T>(c, A + r0 * ld, ld, nb - r0, (int)j0, A + j0 * ld, ld, linv_j, nb - r0, d_info);
     }
 }
-// X[M x nb] <- X * L^-T against a factored nb x nb block L (ldl), 64 columns at a time
+// X[M x nb] <- X * L^-T against a factored nb x nb block L (ldl) with its stored 64 x 64 inverses
 template <typename T>
-static void rows_solve_block(gpmi_ctx* c, T* X, int64_t ldx, int64_t M, const T* L, int64_t ldl, const T* invdiag,
-                             int64_t nb, const int* d_info) {
-    for (int64_t j0 = 0; j0 < nb; j0 += IB) {
-        launch_trsm_rows<T>(c, X + j0, ldx, L + j0 * ldl + j0, ldl, invdiag + j0, M, d_info);
-        const int64_t nc = nb - (j0 + IB);
-        if (nc > 0) launch_gemm_nt<T>(c, X + j0 + IB, ldx, X + j0, ldx, L + (j0 + IB) * ldl + j0, ldl, M, nc, IB, 0, d_info);
-    }
+static void rows_solve_block(gpmi_ctx* c, T* X, int64_t ldx, int64_t M, const T* L, int64_t ldl, const T* linv, int64_t nb,
+                             const int* d_info) {
+    for (int64_t j0 = 0; j0 < nb; j0 += IB)
+        launch_rows64<T>(c, X, ldx, M, (int)j0, L + j0 * ldl, ldl, linv + (j0 / IB) * IB * IB, 0, d_info);
 }
 
 template <typename T>
@@ -279,12 +268,12 @@ static int fit_t(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int
                   COV_LOWER | COV_NUGGET | COV_PAD_IDENTITY, nugget, d_noise);
     GPMI_HIP(c, hipMemcpyAsync(A + npad * ld, gp->ymu, (size_t)npad * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
 
-    cholesky_lower<T>(c, A, ld, (T*)gp->invdiag, npad, 1, c->d_info);
+    cholesky_lower<T>(c, A, ld, (T*)gp->linv, (T*)gp->invdiag, npad, 1, c->d_info);
 
     {
         ProfScope ps(c, GPMI_PROF_SOLVE, (double)npad * (double)npad * 0.5 * sizeof(T));
         for (int64_t j0 = npad - IB; j0 >= 0; j0 -= IB)
-            launch_bsolve_step<T>(c, A + j0 * ld, ld, j0, A + npad * ld, (T*)gp->alpha);
+            launch_bsolve_step<T>(c, A + j0 * ld, ld, j0, (const T*)gp->linv + (j0 / IB) * IB * IB, A + npad * ld, (T*)gp->alpha);
         launch_finalize<T>(c, A, ld, n, (const T*)gp->ymu, (const T*)gp->alpha, c->d_scal);
     }
     int h_info = 0;
@@ -343,7 +332,7 @@ static int predict_t(gpmi_gp* gp, const gpmi_kernel* k, int64_t P, const void* x
         // K*' (P x npad, one test point per row): cov(k, xtrain, xpred)', GP.jl:44
         launch_cov<T>(c, xp, P, (const T*)gp->x, n, d, R, ld, P, npad, 0, 0.0, nullptr);
         launch_row_gemv<T>(c, R, ld, P, n, (const T*)gp->alpha, d_mean, d_mu);  // mu = mx + Kfx' alpha, GP.jl:26
-        whiten_rows<T>(c, A, ld, (const T*)gp->invdiag, npad, R, ld, P);        // Lck = whiten!(Kff, Kfx), GP.jl:27
+        whiten_rows<T>(c, A, ld, (const T*)gp->linv, npad, R, ld, P);           // Lck = whiten!(Kff, Kfx), GP.jl:27
         if (!full_cov) launch_row_var<T>(c, R, ld, P, npad, kdiag, d_var);
     }
     GPMI_HIP(c, hipMemcpyAsync(mu_out, d_mu, (size_t)P * sizeof(T), hipMemcpyDeviceToHost, c->stream));
@@ -410,11 +399,12 @@ static int solve_t(gpmi_gp* gp, int64_t nrhs, void* b_inout, bool backward) {
     GPMI_HIP(c, hipMemsetAsync(R, 0, (size_t)(nrhs * ld) * sizeof(T), c->stream));
     GPMI_HIP(c, hipMemcpy2DAsync(R, (size_t)ld * sizeof(T), b_inout, (size_t)n * sizeof(T), (size_t)n * sizeof(T),
                                  (size_t)nrhs, hipMemcpyHostToDevice, c->stream));
-    whiten_rows<T>(c, A, ld, (const T*)gp->invdiag, npad, R, ld, nrhs);
+    whiten_rows<T>(c, A, ld, (const T*)gp->linv, npad, R, ld, nrhs);
     if (backward) {
         T* tmp = (T*)gp->small;
         for (int64_t r = 0; r < nrhs; ++r) {
-            for (int64_t j0 = npad - IB; j0 >= 0; j0 -= IB) launch_bsolve_step<T>(c, A + j0 * ld, ld, j0, R + r * ld, tmp);
+            for (int64_t j0 = npad - IB; j0 >= 0; j0 -= IB)
+                launch_bsolve_step<T>(c, A + j0 * ld, ld, j0, (const T*)gp->linv + (j0 / IB) * IB * IB, R + r * ld, tmp);
             GPMI_HIP(c, hipMemcpyAsync(R + r * ld, tmp, (size_t)npad * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
         }
     }
@@ -502,6 +492,7 @@ int gpmi_gp_create(gpmi_ctx* c, int dtype, int d, int64_t n, const void* x, gpmi
     if (e == hipSuccess) e = hipMalloc(&gp->ymu, (size_t)gp->npad * es);
     if (e == hipSuccess) e = hipMalloc(&gp->alpha, (size_t)gp->npad * es);
     if (e == hipSuccess) e = hipMalloc(&gp->invdiag, (size_t)gp->npad * es);
+    if (e == hipSuccess) e = hipMalloc(&gp->linv, (size_t)(gp->npad * IB) * es);
     if (e == hipSuccess) e = hipMemcpy(gp->x, x, (size_t)(n * d) * es, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset((char*)gp->A + (size_t)(gp->npad * gp->ld) * es, 0, (size_t)(8 * gp->ld) * es);
     if (e != hipSuccess) {
@@ -519,7 +510,7 @@ void gpmi_gp_destroy(gpmi_gp* gp) {
         hipSetDevice(gp->ctx->device);
         hipStreamSynchronize(gp->ctx->stream);
     }
-    void* ptrs[] = {gp->x, gp->A, gp->ymu, gp->alpha, gp->invdiag, gp->noise, gp->rows, gp->xp, gp->small};
+    void* ptrs[] = {gp->x, gp->A, gp->ymu, gp->alpha, gp->invdiag, gp->linv, gp->noise, gp->rows, gp->xp, gp->small};
     for (void* p : ptrs)
         if (p) hipFree(p);
     delete gp;
@@ -707,25 +698,26 @@ int gpmi_dev_cov_rows(gpmi_ctx* c, int dtype, int d, int64_t na, const void* xa_
     return GPMI_OK;
 }
 
-int gpmi_dev_potrf_block(gpmi_ctx* c, int dtype, void* A_dev, int64_t ld, int64_t nb, void* invdiag_dev, int64_t pivot_base) {
-    if (!c || !A_dev || !invdiag_dev || nb <= 0 || nb % IB) return GPMI_EARG;
+int gpmi_dev_potrf_block(gpmi_ctx* c, int dtype, void* A_dev, int64_t ld, int64_t nb, void* linv_dev, void* invdiag_dev,
+                         int64_t pivot_base) {
+    if (!c || !A_dev || !linv_dev || !invdiag_dev || nb <= 0 || nb % IB) return GPMI_EARG;
     GPMI_HIP(c, hipSetDevice(c->device));
     if (dtype == 64)
-        potrf_block<double>(c, (double*)A_dev, ld, nb, (double*)invdiag_dev, pivot_base, c->d_info);
+        potrf_block<double>(c, (double*)A_dev, ld, nb, (double*)linv_dev, (double*)invdiag_dev, pivot_base, c->d_info);
     else
-        potrf_block<float>(c, (float*)A_dev, ld, nb, (float*)invdiag_dev, pivot_base, c->d_info);
+        potrf_block<float>(c, (float*)A_dev, ld, nb, (float*)linv_dev, (float*)invdiag_dev, pivot_base, c->d_info);
     return GPMI_OK;
 }
 
 int gpmi_dev_rows_solve(gpmi_ctx* c, int dtype, void* X_dev, int64_t ldx, int64_t M, const void* L_dev, int64_t ldl,
-                        const void* invdiag_dev, int64_t nb) {
-    if (!c || !X_dev || !L_dev || !invdiag_dev || nb <= 0 || nb % IB) return GPMI_EARG;
+                        const void* linv_dev, int64_t nb) {
+    if (!c || !X_dev || !L_dev || !linv_dev || nb <= 0 || nb % IB) return GPMI_EARG;
     if (M <= 0) return GPMI_OK;
     GPMI_HIP(c, hipSetDevice(c->device));
     if (dtype == 64)
-        rows_solve_block<double>(c, (double*)X_dev, ldx, M, (const double*)L_dev, ldl, (const double*)invdiag_dev, nb, c->d_info);
+        rows_solve_block<double>(c, (double*)X_dev, ldx, M, (const double*)L_dev, ldl, (const double*)linv_dev, nb, c->d_info);
     else
-        rows_solve_block<float>(c, (float*)X_dev, ldx, M, (const float*)L_dev, ldl, (const float*)invdiag_dev, nb, c->d_info);
+        rows_solve_block<float>(c, (float*)X_dev, ldx, M, (const float*)L_dev, ldl, (const float*)linv_dev, nb, c->d_info);
     return GPMI_OK;
 }
 
@@ -742,17 +734,18 @@ int gpmi_dev_update(gpmi_ctx* c, int dtype, void* C_dev, int64_t ldc, const void
     return GPMI_OK;
 }
 
-int gpmi_dev_bsolve_block(gpmi_ctx* c, int dtype, const void* Lrows_dev, int64_t ld, int64_t c0, int64_t nb, void* z_dev,
-                          void* alpha_dev) {
-    if (!c || !Lrows_dev || !z_dev || !alpha_dev || nb <= 0 || nb % IB) return GPMI_EARG;
+int gpmi_dev_bsolve_block(gpmi_ctx* c, int dtype, const void* Lrows_dev, int64_t ld, int64_t c0, int64_t nb,
+                          const void* linv_dev, void* z_dev, void* alpha_dev) {
+    if (!c || !Lrows_dev || !linv_dev || !z_dev || !alpha_dev || nb <= 0 || nb % IB) return GPMI_EARG;
     GPMI_HIP(c, hipSetDevice(c->device));
     const size_t es = dtype == 64 ? 8 : 4;
     for (int64_t j = nb - IB; j >= 0; j -= IB) {
         const char* row = (const char*)Lrows_dev + (size_t)(j * ld) * es;
+        const char* li = (const char*)linv_dev + (size_t)((j / IB) * IB * IB) * es;
         if (dtype == 64)
-            launch_bsolve_step<double>(c, (const double*)row, ld, c0 + j, (double*)z_dev, (double*)alpha_dev);
+            launch_bsolve_step<double>(c, (const double*)row, ld, c0 + j, (const double*)li, (double*)z_dev, (double*)alpha_dev);
         else
-            launch_bsolve_step<float>(c, (const float*)row, ld, c0 + j, (float*)z_dev, (float*)alpha_dev);
+            launch_bsolve_step<float>(c, (const float*)row, ld, c0 + j, (const float*)li, (float*)z_dev, (float*)alpha_dev);
     }
     return GPMI_OK;
 }

@@ -88,7 +88,8 @@ struct gpmi_gp {
     void* A = nullptr;       // (npad + 8) x ld; lower triangle holds L (K = L L'), row npad holds z = L^-1 y
     void* ymu = nullptr;     // y - mu, npad elements (zero padded)
     void* alpha = nullptr;   // npad elements
-    void* invdiag = nullptr; // 1 / L_ii, npad elements (written by potf2, read by every later solve)
+    void* invdiag = nullptr; // 1 / L_ii, npad elements
+    void* linv = nullptr;    // inverses of the 64 x 64 diagonal blocks, (npad / 64) x 64 x 64 (every later solve is a GEMM)
     double* noise = nullptr; // per-point nugget (heteroscedastic) or nullptr
     bool fitted = false;
     double logdet = 0.0;
@@ -145,10 +146,18 @@ template <typename T>
 void launch_gemm_shape(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M,
                        int64_t N, int64_t K, TileShape shape, const int* info);
 
-// in-place Cholesky of the 64 x 64 block at A (row-major, ld): lower factor; upper part zeroed.
-// invdiag[0..64) receives 1 / L_jj.  On a non-positive pivot j (0-based) writes *info = pivot_base + j + 1.
+// in-place Cholesky of the 64 x 64 block at A (row-major, ld): lower factor, upper part zeroed; linv (64 x 64,
+// row-major, ld 64) receives L^-1 and invdiag[0..64) 1 / L_jj.  On a non-positive pivot j (0-based) writes
+// *info = pivot_base + j + 1.
 template <typename T>
-void launch_potf2(gpmi_ctx* ctx, T* A, int64_t ld, T* invdiag, int* info, int64_t pivot_base);
+void launch_diag64(gpmi_ctx* ctx, T* A, int64_t ld, T* linv, T* invdiag, int* info, int64_t pivot_base);
+
+// Panel step for the rows below column block j of a panel (Xp, Lp point at the panel's first column k0):
+//   X_j <- (X_j - X[:, 0:K1] Lp[0:64, 0:K1]') Linv'   and, for the first diag_rows rows (Cholesky only),
+//   the rows' own 64 x 64 diagonal block -= X_j X_j'.
+template <typename T>
+void launch_rows64(gpmi_ctx* ctx, T* Xp, int64_t ldx, int64_t M, int K1, const T* Lp, int64_t ldl, const T* linv,
+                   int64_t diag_rows, const int* info);
 
 // X[M x 64] <- X * L11^-T  (row-wise forward substitution against the 64 x 64 lower L11)
 template <typename T>
@@ -156,10 +165,10 @@ void launch_trsm_rows(gpmi_ctx* ctx, T* X, int64_t ldx, const T* L11, int64_t ld
                       const int* info);
 
 // One step of the backward solve  L' alpha = z  for the 64-block starting at j0:
-//   alpha[j0..j0+64) = L_bb^-T z[j0..);  z[0..j0) -= L[j0..j0+64, 0..j0)' alpha_b
+//   alpha[j0..j0+64) = Linv_b' z[j0..)  (linv = stored inverse of the diagonal block);  z[0..j0) -= L[j0..j0+64, 0..j0)' alpha_b
 // Arow points at row j0 of the factor (so a shard can pass its local copy of that block-row).
 template <typename T>
-void launch_bsolve_step(gpmi_ctx* ctx, const T* Arow, int64_t ld, int64_t j0, T* z, T* alpha);
+void launch_bsolve_step(gpmi_ctx* ctx, const T* Arow, int64_t ld, int64_t j0, const T* linv, T* z, T* alpha);
 
 // mll / logdet / y'alpha  ->  out[0] = mll, out[1] = logdet, out[2] = y'alpha
 template <typename T>

@@ -31,71 +31,12 @@
 #include <vector>
 
 #include "common.h"
+#include "mfma.h"
 #include "tile_order.h"
 
 namespace gpmi {
 
 namespace {
-
-template <typename T>
-struct Mfma;
-template <int CTRL>
-__device__ __forceinline__ double dpp_rot(double x) {
-    // rotate within each 16-lane row; row_ror:n gives out[l] = in[(l - n) & 15]  (probed, tools/dpp_probe.hip)
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-
-template <>
-struct Mfma<double> {
-    using Vec = double __attribute__((ext_vector_type(2)));
-    static constexpr int E = 2;
-    static constexpr int BK = 16;
-    static constexpr int NR = 4;  // accumulator registers per 16 x 16 tile
-    struct Acc {
-        double v[4];
-    };
-    // one 16 x 16 x 4 product = four 4x4x4 (4-block) MFMAs against B rotated by r blocks
-    static __device__ __forceinline__ void rotations(double b, double (&br)[4]) {
-        br[0] = b;
-        br[1] = dpp_rot<0x12C>(b);  // row_ror:12 -> lane l reads l + 4  (block b + 1)
-        br[2] = dpp_rot<0x128>(b);  // row_ror:8                        (block b + 2)
-        br[3] = dpp_rot<0x124>(b);  // row_ror:4  -> lane l reads l + 12 (block b + 3)
-    }
-    static __device__ __forceinline__ void mma(double a, const double (&br)[4], Acc& c) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) c.v[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, br[r], c.v[r], 0, 0, 0);
-    }
-    // acc register r of lane (j + 4b + 16i) holds C[row 4b + i][col 4((b + r) & 3) + j]
-    static __device__ __forceinline__ int row_of(int lane, int) { return ((lane >> 2) & 3) * 4 + (lane >> 4); }
-    static __device__ __forceinline__ int col_of(int lane, int r) { return ((((lane >> 2) & 3) + r) & 3) * 4 + (lane & 3); }
-};
-template <>
-struct Mfma<float> {
-    using Vec = float __attribute__((ext_vector_type(4)));
-    static constexpr int E = 4;
-    static constexpr int BK = 32;
-    static constexpr int NR = 4;
-    using V4 = float __attribute__((ext_vector_type(4)));
-    struct Acc {
-        V4 v;
-    };
-    static __device__ __forceinline__ void rotations(float b, float (&br)[4]) { br[0] = b; }
-    static __device__ __forceinline__ void mma(float a, const float (&br)[4], Acc& c) {
-        c.v = __builtin_amdgcn_mfma_f32_16x16x4f32(a, br[0], c.v, 0, 0, 0);
-    }
-    // v_mfma_f32_16x16x4_f32 C/D map: col = lane & 15, row = 4 * (lane >> 4) + reg
-    static __device__ __forceinline__ int row_of(int lane, int reg) { return 4 * (lane >> 4) + reg; }
-    static __device__ __forceinline__ int col_of(int lane, int) { return lane & 15; }
-};
-template <typename T>
-__device__ __forceinline__ T acc_get(const typename Mfma<T>::Acc& a, int r);
-template <>
-__device__ __forceinline__ double acc_get<double>(const Mfma<double>::Acc& a, int r) { return a.v[r]; }
-template <>
-__device__ __forceinline__ float acc_get<float>(const Mfma<float>::Acc& a, int r) { return a.v[r]; }
 
 // VARIANT bits are ablation switches used only by gpmi_bench_gemm (0 = the product kernel):
 //   1 no C read in the epilogue   2 no epilogue at all   4 no global loads inside the K loop

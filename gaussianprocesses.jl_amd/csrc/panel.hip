@@ -6,6 +6,7 @@
 //   finalize   logdet (PDMats: 2 sum log U_ii) + y'alpha + mll (src/GPE.jl:210)
 //   row_gemv / row_var   predictive mean / variance reductions (src/GP.jl:26,75)
 #include "common.h"
+#include "mfma.h"
 
 namespace gpmi {
 
@@ -49,49 +50,259 @@ __device__ __forceinline__ float bcast_lane<float>(float v, int srclane) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(64) void potf2_kernel(T* __restrict__ A, int64_t ld, T* __restrict__ invdiag,
-                                                   int* __restrict__ info, int64_t pivot_base) {
+__device__ __forceinline__ void store16(const typename Mfma<T>::Acc& acc, T* C, int ldc, T scale, bool transpose, int lane) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = Mfma<T>::row_of(lane, r), col = Mfma<T>::col_of(lane, r);
+        const T v = scale * acc_get<T>(acc, r);
+        if (transpose)
+            C[col * ldc + row] = v;
+        else
+            C[row * ldc + col] = v;
+    }
+}
+
+// diag64: Cholesky of one 64 x 64 diagonal block AND its explicit inverse, ONE wavefront.
+//   1. potf2 with the rows in registers, blocked by 16 columns (rank-16 updates on the matrix cores);
+//   2. the four 16 x 16 diagonal blocks of L are inverted by per-lane substitution (16 lanes per block);
+//   3. the off-diagonal blocks of L^-1 follow from  X_ib = -Dinv_i * sum_{t=b}^{i-1} L_it X_tb  on the matrix
+//      cores (16 tiny products, LDS-resident operands);
+// so that every later solve against this block (panel TRSM, whiten!, back-substitution) is a GEMM.
+template <typename T>
+__global__ __launch_bounds__(64) void diag64_kernel(T* __restrict__ A, int64_t ld, T* __restrict__ Linv,
+                                                    T* __restrict__ invdiag, int* __restrict__ info, int64_t pivot_base) {
     if (*info != 0) return;
-    __shared__ T S[64 * 65];
+    constexpr int SLD = 65;
+    __shared__ T S[64 * SLD];    // L, row-major
+    __shared__ T XT[64 * SLD];   // XT[n][k] = Linv[k][n]
+    __shared__ T DI[64 * 16];    // DI[16 b + i][c] = (L_bb^-1)[i][c]
+    __shared__ T WT[16 * 17];
+    __shared__ T sinv[64];
     const int i = threadIdx.x;
-    for (int r = 0; r < 64; ++r) S[r * 65 + i] = A[(int64_t)r * ld + i];  // coalesced rows
+    for (int r = 0; r < 64; ++r) S[r * SLD + i] = A[(int64_t)r * ld + i];  // coalesced rows
     __syncthreads();
     T a[64];
 #pragma unroll
-    for (int c = 0; c < 64; ++c) a[c] = S[i * 65 + c];
+    for (int c = 0; c < 64; ++c) a[c] = S[i * SLD + c];
 
+    // Blocked by 16 columns: inside a block the rank-1 updates stay in registers (<= 15 per step); the rank-16
+    // update of everything to the right goes through the matrix cores (panel -> LDS -> P P' tiles -> LDS -> rows).
     int fail = 0;
     T myinv = T(0);
+    using AccP = typename Mfma<T>::Acc;
+    T* PL = XT;  // [64][17] panel image (XT is not needed before the inverse phase)
 #pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        const T d = bcast_lane<T>(a[j], j);
-        if (!(d > T(0))) {  // also catches NaN; uniform across the wave
-            fail = j + 1;
-            break;
+    for (int b = 0; b < 4; ++b) {
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = 16 * b + jj;
+            const T d = bcast_lane<T>(a[j], j);
+            // a non-positive (or NaN) pivot is recorded once; the remaining steps run on garbage and are discarded
+            // (no early exit: every index into a[] must stay a compile-time constant to keep the rows in registers)
+            if (fail == 0 && !(d > T(0))) fail = j + 1;
+            T r = rsqrt_seed<T>(d);
+            r = r * (T(1.5) - T(0.5) * d * r * r);
+            r = r * (T(1.5) - T(0.5) * d * r * r);
+            T sq = d * r;
+            sq = sq + (T(0.5) * r) * (d - sq * sq);       // sqrt(d)
+            const T inv = r + r * (T(1) - sq * r);        // 1 / sqrt(d)
+            const T lij = (i == j) ? sq : a[j] * inv;
+            a[j] = lij;
+            if (i == j) myinv = inv;
+#pragma unroll
+            for (int c = j + 1; c < 16 * b + 16; ++c) a[c] -= lij * bcast_lane<T>(lij, c);
         }
-        T r = rsqrt_seed<T>(d);
-        r = r * (T(1.5) - T(0.5) * d * r * r);
-        r = r * (T(1.5) - T(0.5) * d * r * r);
-        T sq = d * r;
-        sq = sq + (T(0.5) * r) * (d - sq * sq);       // sqrt(d)
-        const T inv = r + r * (T(1) - sq * r);        // 1 / sqrt(d)
-        const T lij = (i == j) ? sq : a[j] * inv;
-        a[j] = lij;
-        if (i == j) myinv = inv;
+        if (b < 3) {
+            __syncthreads();
 #pragma unroll
-        for (int c = j + 1; c < 64; ++c) a[c] -= lij * bcast_lane<T>(lij, c);
+            for (int q = 0; q < 16; ++q) PL[i * 17 + q] = a[16 * b + q];
+            __syncthreads();
+            for (int ri = b + 1; ri < 4; ++ri)
+                for (int ci = b + 1; ci <= ri; ++ci) {
+                    AccP u;
+                    acc_zero<T>(u);
+                    mma16_nt<T>(u, PL + 16 * ri * 17, 17, PL + 16 * ci * 17, 17, 16, i);
+                    store16<T>(u, S + (16 * ri) * SLD + 16 * ci, SLD, T(1), false, i);
+                }
+            __syncthreads();
+#pragma unroll
+            for (int ci = b + 1; ci < 4; ++ci) {
+                if (ci <= (i >> 4)) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) a[16 * ci + q] -= S[i * SLD + 16 * ci + q];
+                }
+            }
+        }
     }
     if (fail) {
         if (i == 0) *info = (int)(pivot_base + fail);
         return;
     }
     invdiag[i] = myinv;
-    // write back: lower triangle = L, strict upper = 0
+    sinv[i] = myinv;
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < 64; ++c) S[i * 65 + c] = (c <= i) ? a[c] : T(0);
+    for (int c = 0; c < 64; ++c) {
+        S[i * SLD + c] = (c <= i) ? a[c] : T(0);
+        XT[i * SLD + c] = T(0);
+    }
     __syncthreads();
-    for (int r = 0; r < 64; ++r) A[(int64_t)r * ld + i] = S[r * 65 + i];
+    for (int r = 0; r < 64; ++r) A[(int64_t)r * ld + i] = S[r * SLD + i];  // lower triangle = L, strict upper = 0
+
+    // ---- 16 x 16 diagonal inverses: lane (b, c) computes column c of (L_bb)^-1 ----------------------------
+    {
+        const int b = i >> 4, c = i & 15;
+        T x[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            T sacc = (q == c) ? T(1) : T(0);
+#pragma unroll
+            for (int t = 0; t < q; ++t) sacc -= S[(16 * b + q) * SLD + 16 * b + t] * x[t];
+            x[q] = sacc * sinv[16 * b + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            DI[(16 * b + q) * 16 + c] = x[q];
+            XT[(16 * b + c) * SLD + 16 * b + q] = x[q];
+        }
+    }
+    __syncthreads();
+    // ---- off-diagonal blocks, by distance from the diagonal ---------------------------------------------
+    using Acc = typename Mfma<T>::Acc;
+    for (int dist = 1; dist < 4; ++dist) {
+        for (int b = 0; b + dist < 4; ++b) {
+            const int ib = b + dist;
+            Acc w;
+            acc_zero<T>(w);
+            for (int t = b; t < ib; ++t)  // W = sum_t L_it X_tb ;  B operand rows n: XT[16 b + n][16 t + k]
+                mma16_nt<T>(w, S + (16 * ib) * SLD + 16 * t, SLD, XT + (16 * b) * SLD + 16 * t, SLD, 16, i);
+            store16<T>(w, WT, 17, T(1), true, i);  // WT[n][k] = W[k][n]
+            __syncthreads();
+            Acc xacc;
+            acc_zero<T>(xacc);
+            mma16_nt<T>(xacc, DI + (16 * ib) * 16, 16, WT, 17, 16, i);  // Dinv_i * W
+            store16<T>(xacc, XT + (16 * b) * SLD + 16 * ib, SLD, T(-1), true, i);  // XT[16b + n][16 ib + row] = -X[row][n]
+            __syncthreads();
+        }
+    }
+    for (int k = 0; k < 64; ++k) Linv[k * 64 + i] = XT[i * SLD + k];  // Linv[k][n] = XT[n][k]
+}
+
+// rows64: the panel step for every row below a 64-wide column block j of a 256-wide panel, 64 rows per workgroup.
+//   phase 1 (left-looking)  T = X_j - sum_{s<j} X_s L_js'          K1 = j0 - k0 columns of the same rows
+//   phase 2                 X_j <- T * Linv_j'                      the TRSM as a K = 64 product
+//   phase 3 (only rows that belong to the panel's own diagonal region; Cholesky)
+//                           A_mm -= X_j X_j'                        keeps the next diagonal blocks current
+// All products run on the matrix cores from LDS-resident 64 x 64 operands.  Xp / Lp point at COLUMN k0.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void rows64_kernel(T* __restrict__ Xp, int64_t ldx, int64_t M, int K1,
+                                                     const T* __restrict__ Lp, int64_t ldl, const T* __restrict__ Linv,
+                                                     int64_t diag_rows, const int* __restrict__ info) {
+    if (info && *info != 0) return;
+    using MF = Mfma<T>;
+    using Acc = typename MF::Acc;
+    constexpr int LD = 65;
+    constexpr int KS = 32, KLD = 33;
+    __shared__ T buf1[64 * LD];
+    __shared__ T buf2[64 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+
+    Acc acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc_zero<T>(acc[mi][ni]);
+
+    // ---- phase 1 --------------------------------------------------------------------------------------------
+    {
+        const int r = tid >> 2, kq = (tid & 3) * 8;
+        int64_t gr = row0 + r;
+        gr = gr < M ? gr : M - 1;
+        const T* ga = Xp + gr * ldx + kq;
+        const T* gb = Lp + (int64_t)r * ldl + kq;
+        T ra[8], rb[8];
+        if (K1 > 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                ra[q] = ga[q];
+                rb[q] = gb[q];
+            }
+        }
+        for (int ks = 0; ks < K1; ks += KS) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                buf1[r * KLD + kq + q] = ra[q];
+                buf2[r * KLD + kq + q] = rb[q];
+            }
+            __syncthreads();
+            if (ks + KS < K1) {  // next slab in flight while this one is multiplied
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    ra[q] = ga[ks + KS + q];
+                    rb[q] = gb[ks + KS + q];
+                }
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    mma16_nt<T>(acc[mi][ni], buf1 + (wm * 32 + mi * 16) * KLD, KLD, buf2 + (wn * 32 + ni * 16) * KLD, KLD, KS, lane);
+            __syncthreads();
+        }
+    }
+    // ---- phase 2 --------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * 32 + mi * 16 + MF::row_of(lane, r), col = wn * 32 + ni * 16 + MF::col_of(lane, r);
+                int64_t gr = row0 + row;
+                gr = gr < M ? gr : M - 1;
+                buf1[row * LD + col] = Xp[gr * ldx + K1 + col] - acc_get<T>(acc[mi][ni], r);
+            }
+    for (int e = tid; e < 64 * 64; e += 256) buf2[(e >> 6) * LD + (e & 63)] = Linv[e];
+    __syncthreads();
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            acc_zero<T>(acc[mi][ni]);
+            mma16_nt<T>(acc[mi][ni], buf1 + (wm * 32 + mi * 16) * LD, LD, buf2 + (wn * 32 + ni * 16) * LD, LD, 64, lane);
+        }
+    __syncthreads();
+    const bool diag = row0 < diag_rows;  // workgroup-uniform
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * 32 + mi * 16 + MF::row_of(lane, r), col = wn * 32 + ni * 16 + MF::col_of(lane, r);
+                const T v = acc_get<T>(acc[mi][ni], r);
+                if (row0 + row < M) Xp[(row0 + row) * ldx + K1 + col] = v;
+                if (diag) buf1[row * LD + col] = v;
+            }
+    // ---- phase 3 --------------------------------------------------------------------------------------------
+    if (diag) {
+        __syncthreads();
+        T* Dg = Xp + row0 * ldx + (K1 + 64 + row0);  // the 64 x 64 diagonal block of these rows
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                acc_zero<T>(acc[mi][ni]);
+                mma16_nt<T>(acc[mi][ni], buf1 + (wm * 32 + mi * 16) * LD, LD, buf1 + (wn * 32 + ni * 16) * LD, LD, 64, lane);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wm * 32 + mi * 16 + MF::row_of(lane, r), col = wn * 32 + ni * 16 + MF::col_of(lane, r);
+                    Dg[(int64_t)row * ldx + col] -= acc_get<T>(acc[mi][ni], r);
+                }
+            }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -140,39 +351,40 @@ __global__ __launch_bounds__(64) void trsm_rows_kernel(T* __restrict__ X, int64_
 }
 
 // ---------------------------------------------------------------------------------------------
-// bsolve_step: every workgroup redundantly back-substitutes the 64 x 64 diagonal block in its
-// first wavefront (about 1 us, removes a launch from the critical path), workgroup 0 publishes
-// alpha_b, then all workgroups apply  z[j] -= sum_i L[j0+i][j] * alpha_b[i]  to their 256 columns.
+// bsolve_step: one 64-block of the backward solve  L' alpha = z.  With the stored inverse of the diagonal block
+// the block solve is a 64 x 64 mat-vec  alpha_b = Linv_b' z_b  (every workgroup recomputes it — cheaper than an
+// extra launch on the critical path), workgroup 0 publishes alpha_b, then all workgroups apply
+// z[j] -= sum_i L[j0+i][j] * alpha_b[i]  to their 256 columns (coalesced rows of L).
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void bsolve_step_kernel(const T* __restrict__ Arow, int64_t ld, int64_t j0,
-                                                          T* __restrict__ z, T* __restrict__ alpha) {
-    __shared__ T SL[64 * 65];
+                                                          const T* __restrict__ Linv, T* __restrict__ z,
+                                                          T* __restrict__ alpha) {
+    __shared__ T SLI[64 * 65];
+    __shared__ T sz[64];
+    __shared__ T part[4][64];
     __shared__ T sal[64];
     const int tid = threadIdx.x;
-    const T* Lbb = Arow + j0;  // Arow = row j0 of the factor
-    for (int e = tid; e < 64 * 64; e += 256) {
-        const int r = e >> 6, c = e & 63;
-        SL[r * 65 + c] = Lbb[(int64_t)r * ld + c];
+    for (int e = tid; e < 64 * 64; e += 256) SLI[(e >> 6) * 65 + (e & 63)] = Linv[e];
+    if (tid < 64) sz[tid] = z[j0 + tid];
+    __syncthreads();
+    {   // alpha_i = sum_t Linv[t][i] z_t : 4 partial sums over t (one per wavefront)
+        const int i = tid & 63, q = tid >> 6;
+        T s = T(0);
+#pragma unroll
+        for (int t = q * 16; t < q * 16 + 16; ++t) s += SLI[t * 65 + i] * sz[t];
+        part[q][i] = s;
     }
     __syncthreads();
     if (tid < 64) {
-        T zj = z[j0 + tid];
-        const T invd = T(1) / SL[tid * 65 + tid];
-        T aj = T(0);
-        for (int i = 63; i >= 0; --i) {
-            // alpha_i = z_i / L_ii  (z_i already holds the fully updated right-hand side)
-            const T ai = __shfl(zj * invd, i, 64);
-            if (tid == i) aj = ai;
-            if (tid < i) zj -= SL[i * 65 + tid] * ai;  // row i of L, columns < i
-        }
-        sal[tid] = aj;
-        if (blockIdx.x == 0) alpha[j0 + tid] = aj;
+        const T a = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+        sal[tid] = a;
+        if (blockIdx.x == 0) alpha[j0 + tid] = a;
     }
     __syncthreads();
     const int64_t j = (int64_t)blockIdx.x * 256 + tid;
     if (j < j0) {
-        const T* col = Arow + j;
+        const T* col = Arow + j;  // Arow = row j0 of the factor
         T acc = T(0);
 #pragma unroll 8
         for (int i = 0; i < 64; ++i) acc += col[(int64_t)i * ld] * sal[i];
@@ -271,9 +483,17 @@ __global__ __launch_bounds__(256) void row_var_kernel(const T* __restrict__ R, i
 }  // namespace
 
 template <typename T>
-void launch_potf2(gpmi_ctx* ctx, T* A, int64_t ld, T* invdiag, int* info, int64_t pivot_base) {
-    ProfScope ps(ctx, GPMI_PROF_PANEL, 64.0 * 64.0 * 64.0 / 3.0);
-    hipLaunchKernelGGL(potf2_kernel<T>, dim3(1), dim3(64), 0, ctx->stream, A, ld, invdiag, info, pivot_base);
+void launch_diag64(gpmi_ctx* ctx, T* A, int64_t ld, T* linv, T* invdiag, int* info, int64_t pivot_base) {
+    ProfScope ps(ctx, GPMI_PROF_PANEL, 2.0 * 64.0 * 64.0 * 64.0 / 3.0);
+    hipLaunchKernelGGL(diag64_kernel<T>, dim3(1), dim3(64), 0, ctx->stream, A, ld, linv, invdiag, info, pivot_base);
+}
+template <typename T>
+void launch_rows64(gpmi_ctx* ctx, T* Xp, int64_t ldx, int64_t M, int K1, const T* Lp, int64_t ldl, const T* linv,
+                   int64_t diag_rows, const int* info) {
+    if (M <= 0) return;
+    ProfScope ps(ctx, GPMI_PROF_PANEL, 2.0 * (double)M * 64.0 * (double)(K1 + 64));
+    hipLaunchKernelGGL(rows64_kernel<T>, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, ctx->stream, Xp, ldx, M, K1, Lp, ldl,
+                       linv, diag_rows, info);
 }
 template <typename T>
 void launch_trsm_rows(gpmi_ctx* ctx, T* X, int64_t ldx, const T* L11, int64_t ldl, const T* invdiag, int64_t M,
@@ -284,9 +504,9 @@ void launch_trsm_rows(gpmi_ctx* ctx, T* X, int64_t ldx, const T* L11, int64_t ld
                        invdiag, M, info);
 }
 template <typename T>
-void launch_bsolve_step(gpmi_ctx* ctx, const T* Arow, int64_t ld, int64_t j0, T* z, T* alpha) {
+void launch_bsolve_step(gpmi_ctx* ctx, const T* Arow, int64_t ld, int64_t j0, const T* linv, T* z, T* alpha) {
     const unsigned blocks = (unsigned)(j0 > 0 ? (j0 + 255) / 256 : 1);
-    hipLaunchKernelGGL(bsolve_step_kernel<T>, dim3(blocks), dim3(256), 0, ctx->stream, Arow, ld, j0, z, alpha);
+    hipLaunchKernelGGL(bsolve_step_kernel<T>, dim3(blocks), dim3(256), 0, ctx->stream, Arow, ld, j0, linv, z, alpha);
 }
 template <typename T>
 void launch_finalize(gpmi_ctx* ctx, const T* A, int64_t ld, int64_t n, const T* y, const T* alpha, double* out) {
@@ -310,9 +530,11 @@ void launch_logdiag(gpmi_ctx* ctx, const T* A, int64_t ld, int64_t nrows, int64_
 }
 
 #define INST(T)                                                                                                   \
-    template void launch_potf2<T>(gpmi_ctx*, T*, int64_t, T*, int*, int64_t);                                     \
+    template void launch_diag64<T>(gpmi_ctx*, T*, int64_t, T*, T*, int*, int64_t);                                \
+    template void launch_rows64<T>(gpmi_ctx*, T*, int64_t, int64_t, int, const T*, int64_t, const T*, int64_t,    \
+                                   const int*);                                                                   \
     template void launch_trsm_rows<T>(gpmi_ctx*, T*, int64_t, const T*, int64_t, const T*, int64_t, const int*);  \
-    template void launch_bsolve_step<T>(gpmi_ctx*, const T*, int64_t, int64_t, T*, T*);                           \
+    template void launch_bsolve_step<T>(gpmi_ctx*, const T*, int64_t, int64_t, const T*, T*, T*);                 \
     template void launch_finalize<T>(gpmi_ctx*, const T*, int64_t, int64_t, const T*, const T*, double*);         \
     template void launch_row_gemv<T>(gpmi_ctx*, const T*, int64_t, int64_t, int64_t, const T*, const T*, T*);     \
     template void launch_row_var<T>(gpmi_ctx*, const T*, int64_t, int64_t, int64_t, double, T*);                  \

@@ -94,10 +94,10 @@ def load():
     lib.gpmi_dev_set_kernel.argtypes = [vp, C.POINTER(GpmiKernel), ci, C.POINTER(dbl)]
     lib.gpmi_dev_assemble.argtypes = [vp, ci, ci, i64, vp, i64, i64, C.POINTER(dbl), i64, vp, i64, i64]
     lib.gpmi_dev_cov_rows.argtypes = [vp, ci, ci, i64, vp, i64, vp, vp, i64, i64]
-    lib.gpmi_dev_potrf_block.argtypes = [vp, ci, vp, i64, i64, vp, i64]
+    lib.gpmi_dev_potrf_block.argtypes = [vp, ci, vp, i64, i64, vp, vp, i64]
     lib.gpmi_dev_rows_solve.argtypes = [vp, ci, vp, i64, i64, vp, i64, vp, i64]
     lib.gpmi_dev_update.argtypes = [vp, ci, vp, i64, vp, i64, vp, i64, i64, i64, i64, ci, ci, ci, ci]
-    lib.gpmi_dev_bsolve_block.argtypes = [vp, ci, vp, i64, i64, i64, vp, vp]
+    lib.gpmi_dev_bsolve_block.argtypes = [vp, ci, vp, i64, i64, i64, vp, vp, vp]
     lib.gpmi_dev_row_gemv.argtypes = [vp, ci, vp, i64, i64, i64, vp, vp, vp]
     lib.gpmi_dev_row_var.argtypes = [vp, ci, vp, i64, i64, i64, dbl, vp]
     lib.gpmi_dev_logdiag_sum.argtypes = [vp, ci, vp, i64, i64, i64, C.POINTER(dbl)]

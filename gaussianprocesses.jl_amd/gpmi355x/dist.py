@@ -149,22 +149,22 @@ class DeviceOps:
         self.ctx.check(self.lib.gpmi_dev_cov_rows(self.ctx.h, self.bits, d, xa_dev.shape[0], self._p(xa_dev), xb_dev.shape[0],
                                                   self._p(xb_dev), self._p(Cview), self._ld(Cview), ncols_total))
 
-    def potrf_block(self, blk, invd, pivot_base):
+    def potrf_block(self, blk, linv, invd, pivot_base):
         self.ctx.check(self.lib.gpmi_dev_potrf_block(self.ctx.h, self.bits, self._p(blk), self._ld(blk), blk.shape[0],
-                                                     self._p(invd), pivot_base))
+                                                     self._p(linv), self._p(invd), pivot_base))
 
-    def rows_solve(self, X, L, invd):
+    def rows_solve(self, X, L, linv):
         self.ctx.check(self.lib.gpmi_dev_rows_solve(self.ctx.h, self.bits, self._p(X), self._ld(X), X.shape[0], self._p(L),
-                                                    self._ld(L), self._p(invd), L.shape[0]))
+                                                    self._ld(L), self._p(linv), L.shape[0]))
 
     def update(self, Cv, Av, Bv, mode, g0=0, G=1, nstair_tiles=0):
         self.ctx.check(self.lib.gpmi_dev_update(self.ctx.h, self.bits, self._p(Cv), self._ld(Cv), self._p(Av), self._ld(Av),
                                                 self._p(Bv), self._ld(Bv), Cv.shape[0], Cv.shape[1], Av.shape[1], mode, g0, G,
                                                 nstair_tiles))
 
-    def bsolve_block(self, Lrows, c0, z, alpha):
+    def bsolve_block(self, Lrows, c0, linv, z, alpha):
         self.ctx.check(self.lib.gpmi_dev_bsolve_block(self.ctx.h, self.bits, self._p(Lrows), self._ld(Lrows), c0,
-                                                      Lrows.shape[0], self._p(z), self._p(alpha)))
+                                                      Lrows.shape[0], self._p(linv), self._p(z), self._p(alpha)))
 
     def row_gemv(self, R, n, v, add, out):
         self.ctx.check(self.lib.gpmi_dev_row_gemv(self.ctx.h, self.bits, self._p(R), self._ld(R), R.shape[0], n, self._p(v),
@@ -229,9 +229,9 @@ class ShardedGPE:
         self.x_dev = o.from_host(self.x.T)                     # n × d row-major, replicated (N·d·s bytes)
         self.A = o.zeros((self.nown * NBD + 8, self.npad))     # owned block-rows; row nown·NBD carries y − μ
         self.P = o.zeros((self.npad, NBD))                     # the gathered panel, global row order
-        self.D = o.zeros((NBD + 1, NBD))                       # broadcast buffer: L_kk and 1/diag
-        self.Ldiag = o.zeros((self.nblk, NBD, NBD))            # every factored diagonal block, replicated
-        self.invd = o.zeros((self.npad,))
+        # broadcast buffer: rows [0,256) L_kk, rows [256,320) the four 64x64 inverses (contiguous), row 320 1/diag
+        self.D = o.zeros((NBD + NBD // 4 + 1, NBD))
+        self.Dall = o.zeros((self.nblk, NBD + NBD // 4 + 1, NBD))   # every factored diagonal block, replicated
         self.alpha_dev = o.zeros((self.npad,))
         self.alpha = None
         self.mll = float("nan")
@@ -282,19 +282,18 @@ class ShardedGPE:
             if r == owner:
                 lk = (k // G) * NBD
                 blk = self.A[lk:lk + NBD, k0:k0 + NBD]
-                o.potrf_block(blk, self.D[NBD], k0)
+                o.potrf_block(blk, self.D[NBD:NBD + NBD // 4], self.D[NBD + NBD // 4], k0)
                 o.sync()
                 self.D[:NBD].copy_(blk)
                 o.torch_sync()
             comm.broadcast(self.D, owner)
-            self.Ldiag[k].copy_(self.D[:NBD])
-            self.invd[k0:k0 + NBD].copy_(self.D[NBD])
+            self.Dall[k].copy_(self.D)
             o.torch_sync()
             nle = self._n_le(r, k)
             lstart = nle * NBD
             mtot = nown * NBD - lstart + 1                      # owned rows below + the carried y row
             X = self.A[lstart:lstart + mtot, k0:k0 + NBD]
-            o.rows_solve(X, self.Ldiag[k], self.invd[k0:k0 + NBD])
+            o.rows_solve(X, self.Dall[k, :NBD], self.Dall[k, NBD:NBD + NBD // 4])
             o.sync()
             ncols = npad - (k0 + NBD)
             if ncols > 0:
@@ -318,7 +317,7 @@ class ShardedGPE:
             c0, owner = c * NBD, c % G
             if r == owner:
                 lc = (c // G) * NBD
-                o.bsolve_block(self.A[lc:lc + NBD], c0, z, self.alpha_dev)
+                o.bsolve_block(self.A[lc:lc + NBD], c0, self.Dall[c, NBD:NBD + NBD // 4], z, self.alpha_dev)
                 o.sync()
             if G > 1:
                 comm.broadcast(self.alpha_dev[c0:c0 + NBD], owner)
@@ -364,7 +363,7 @@ class ShardedGPE:
         for k in range(nblk):
             k0 = k * NBD
             if pr > 0:
-                o.rows_solve(R[:pr, k0:k0 + NBD], self.Ldiag[k], self.invd[k0:k0 + NBD])
+                o.rows_solve(R[:pr, k0:k0 + NBD], self.Dall[k, :NBD], self.Dall[k, NBD:NBD + NBD // 4])
             if npad - (k0 + NBD) > 0:
                 o.sync()
                 self._gather_panel(k)                           # every rank takes part, with or without test rows

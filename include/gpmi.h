@@ -168,20 +168,22 @@ int gpmi_dev_assemble(gpmi_ctx*, int dtype, int d, int64_t n, const void* x_dev,
 /* C[i][j] = k(xa_i, xb_j), columns >= nb zero-filled up to ncols_total (K*' rows of predict, GP.jl:44) */
 int gpmi_dev_cov_rows(gpmi_ctx*, int dtype, int d, int64_t na, const void* xa_dev, int64_t nb, const void* xb_dev,
                       void* C_dev, int64_t ldc, int64_t ncols_total);
-/* in-place Cholesky of one nb x nb diagonal block (nb % 64 == 0); invdiag gets 1 / L_ii        */
-int gpmi_dev_potrf_block(gpmi_ctx*, int dtype, void* A_dev, int64_t ld, int64_t nb, void* invdiag_dev, int64_t pivot_base);
-/* X[M x nb] <- X * L^-T against a factored diagonal block (panel solve / whiten!)              */
+/* in-place Cholesky of one nb x nb diagonal block (nb % 64 == 0); linv gets the nb/64 inverses of
+ * its 64 x 64 diagonal blocks (64 x 64 row-major each, contiguous), invdiag gets 1 / L_ii       */
+int gpmi_dev_potrf_block(gpmi_ctx*, int dtype, void* A_dev, int64_t ld, int64_t nb, void* linv_dev, void* invdiag_dev,
+                         int64_t pivot_base);
+/* X[M x nb] <- X * L^-T against a factored diagonal block and its linv (panel solve / whiten!)  */
 int gpmi_dev_rows_solve(gpmi_ctx*, int dtype, void* X_dev, int64_t ldx, int64_t M, const void* L_dev, int64_t ldl,
-                        const void* invdiag_dev, int64_t nb);
+                        const void* linv_dev, int64_t nb);
 /* C[M x N] -= A[M x K] B[N x K]'.  mode 0: all tiles; 1: tiles with col <= row; 2: staircase of a
  * block-cyclic shard — local 256-row block i is global block g0 + i*G (relative to C's first
  * column), rows past nstair_tiles*128 are carried rows and get every column.                   */
 int gpmi_dev_update(gpmi_ctx*, int dtype, void* C_dev, int64_t ldc, const void* A_dev, int64_t lda, const void* B_dev,
                     int64_t ldb, int64_t M, int64_t N, int64_t K, int mode, int g0, int G, int nstair_tiles);
 /* backward substitution through ONE block-row [c0, c0+nb) of the factor held at Lrows_dev:
- * alpha[c0..) = L_cc^-T z[c0..);  z[0..c0) -= L[c-rows, 0..c0)' alpha_c                        */
-int gpmi_dev_bsolve_block(gpmi_ctx*, int dtype, const void* Lrows_dev, int64_t ld, int64_t c0, int64_t nb, void* z_dev,
-                          void* alpha_dev);
+ * alpha[c0..) = L_cc^-T z[c0..)  (through the block's linv);  z[0..c0) -= L[c-rows, 0..c0)' alpha_c  */
+int gpmi_dev_bsolve_block(gpmi_ctx*, int dtype, const void* Lrows_dev, int64_t ld, int64_t c0, int64_t nb,
+                          const void* linv_dev, void* z_dev, void* alpha_dev);
 int gpmi_dev_row_gemv(gpmi_ctx*, int dtype, const void* R_dev, int64_t ldr, int64_t P, int64_t n, const void* v_dev,
                       const void* add_dev, void* out_dev);                 /* out[p] = add[p] + R[p,:n] . v       */
 int gpmi_dev_row_var(gpmi_ctx*, int dtype, const void* R_dev, int64_t ldr, int64_t P, int64_t n, double kdiag,

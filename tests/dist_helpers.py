@@ -58,7 +58,7 @@ class FakeOps:
         Cview.zero_()
         Cview[:, :K.shape[1]] = torch.from_numpy(K).to(self.tdtype)
 
-    def potrf_block(self, blk, invd, pivot_base):
+    def potrf_block(self, blk, linv, invd, pivot_base):
         if self._info:
             return
         a = blk.numpy().astype(np.float64)
@@ -73,7 +73,7 @@ class FakeOps:
         blk.copy_(torch.from_numpy(L).to(self.tdtype))
         invd.copy_(torch.from_numpy(1.0 / np.diag(L)).to(self.tdtype))
 
-    def rows_solve(self, X, L, invd):
+    def rows_solve(self, X, L, linv):
         if self._info or X.shape[0] == 0:
             return
         l = np.tril(L.numpy().astype(np.float64))
@@ -88,7 +88,7 @@ class FakeOps:
             return
         Cv -= Av @ Bv[: Cv.shape[1]].T  # full rectangle: a superset of the staircase, the extra part is never read
 
-    def bsolve_block(self, Lrows, c0, z, alpha):
+    def bsolve_block(self, Lrows, c0, linv, z, alpha):
         nb = Lrows.shape[0]
         l = np.tril(Lrows[:, c0:c0 + nb].numpy().astype(np.float64))
         try:
