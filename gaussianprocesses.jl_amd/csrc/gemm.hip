@@ -41,6 +41,7 @@ namespace {
 // VARIANT bits are ablation switches used only by gpmi_bench_gemm (0 = the product kernel):
 //   1 no C read in the epilogue   2 no epilogue at all   4 no global loads inside the K loop
 //   8 no DPP rotations            16 no LDS fragment reads inside the K loop
+//   32 s_setprio(1) around the MFMA cluster (experiment)
 //
 // PERSISTENT kernel: the grid is at most 2 workgroups per CU.  Tiles are numbered in the order of
 // tile_order.h and split into 8 contiguous chunks, one per XCD (workgroup b runs on XCD b % 8 — an
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni) bf[ni] = *reinterpret_cast<const Vec*>(bs + ni * 16 * BK);
                 }
+                if constexpr (VARIANT & 32) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
 #pragma unroll
@@ -195,6 +197,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
                         for (int mi = 0; mi < 4; ++mi) MF::mma(af[mi][e], br, acc[mi][ni]);
                     }
                 }
+                if constexpr (VARIANT & 32) __builtin_amdgcn_s_setprio(0);
             }
             __syncthreads();  // (a) next slab has landed for everyone  (b) everyone is done reading `cur`
         }
@@ -383,6 +386,7 @@ int gemm_bench(gpmi_ctx* ctx, int64_t M, int64_t N, int64_t K, int lower, int va
             case 14: launch_variant<T, 14>(ctx, C, ld, A, M, N, K, lower); break;
             case 22: launch_variant<T, 22>(ctx, C, ld, A, M, N, K, lower); break;
             case 30: launch_variant<T, 30>(ctx, C, ld, A, M, N, K, lower); break;
+            case 32: launch_variant<T, 32>(ctx, C, ld, A, M, N, K, lower); break;
 
             default: break;
         }
