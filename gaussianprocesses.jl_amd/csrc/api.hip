@@ -41,8 +41,10 @@ int digest_kernel(const gpmi_kernel* k, int d, DevProgram* out, std::string* err
     memset(out, 0, sizeof(DevProgram));
     out->n_ops = k->n_ops;
     out->d = d;
-    int pp = 0, depth = 0, wcur = 0;
+    int pp = 0, depth = 0, wcur = 0, hyp = 0;
     double kst[GPMI_MAX_OPS];
+    int nst[GPMI_MAX_OPS];  // node index of each stack entry
+    for (int q = 0; q < GPMI_MAX_OPS * MAX_D; ++q) out->pmap[q] = -1;
     for (int o = 0; o < k->n_ops; ++o) {
         const int op = k->ops[o];
         DevLeaf& lf = out->leaf[o];
@@ -52,7 +54,10 @@ int digest_kernel(const gpmi_kernel* k, int d, DevProgram* out, std::string* err
                 *err = "kernel descriptor: SUM/PROD without two operands";
                 return GPMI_EARG;
             }
+            lf.right = nst[depth - 1];
+            lf.left = nst[depth - 2];
             const double r = kst[--depth], l = kst[--depth];
+            nst[depth] = o;
             kst[depth++] = (op == GPMI_K_SUM) ? l + r : l * r;
             continue;
         }
@@ -83,7 +88,11 @@ int digest_kernel(const gpmi_kernel* k, int d, DevProgram* out, std::string* err
                 return GPMI_EARG;
             }
             w[kk] += is_ard(op) ? par[z] : 1.0;
+            if (is_ard(op)) out->pmap[lf.woff + kk] = (int16_t)z;
         }
+        lf.poff = hyp;
+        lf.nd = nd;
+        hyp += npar;
         if (op == GPMI_K_NOISE || op == GPMI_K_CONST) {
             lf.s2 = par[0];
             if (op == GPMI_K_NOISE) out->has_noise_leaf = 1;
@@ -108,6 +117,7 @@ int digest_kernel(const gpmi_kernel* k, int d, DevProgram* out, std::string* err
             *err = "kernel descriptor: expression stack deeper than 6";
             return GPMI_EARG;
         }
+        nst[depth] = o;
         kst[depth++] = lf.s2;  // every leaf evaluates to s2 at coincident points
     }
     if (depth != 1 || pp != k->n_params) {
@@ -115,6 +125,7 @@ int digest_kernel(const gpmi_kernel* k, int d, DevProgram* out, std::string* err
         return GPMI_EARG;
     }
     out->kdiag = kst[0];
+    out->n_hyp = hyp;
     return GPMI_OK;
 }
 
@@ -291,6 +302,57 @@ static int fit_t(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int
     gp->fitted = true;
     if (mll_out) *mll_out = gp->mll;
     if (alpha_out) GPMI_HIP(c, hipMemcpy(alpha_out, gp->alpha, (size_t)n * sizeof(T), hipMemcpyDeviceToHost));
+    return GPMI_OK;
+}
+
+// gradient of the mll with respect to the kernel hyper-parameters and log-noise (update_dmll!, GPE.jl:298-324)
+template <typename T>
+static int grad_t(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, double* dkern_out, double* dnoise_out) {
+    gpmi_ctx* c = gp->ctx;
+    const int64_t n = gp->n, npad = gp->npad, ld = gp->ld;
+    const T* A = (const T*)gp->A;
+    int rc = upload_program(c, k, gp->d);
+    if (rc != GPMI_OK) return rc;
+    const int n_hyp = c->h_prog->n_hyp;
+    if (c->h_prog->n_ops > GRAD_MAX_NODES || n_hyp > GRAD_MAX_HYP || gp->d > GRAD_MAX_D) {
+        c->err = "gpmi_grad: kernel outside the device gradient path (<= 48 hyper-parameters, d <= 16)";
+        return GPMI_EARG;
+    }
+    const size_t bytes = (size_t)(npad * ld) * sizeof(T);
+    if (!gp->g1) GPMI_HIP(c, hipMalloc(&gp->g1, bytes));
+    if (!gp->g2) GPMI_HIP(c, hipMalloc(&gp->g2, bytes));
+    T* G1 = (T*)gp->g1;
+    T* G2 = (T*)gp->g2;
+    const int64_t nt = (n + 63) / 64;
+    const int64_t need = nt * nt * (n_hyp + 1) * (int64_t)sizeof(double);
+    if (gp->gpart_cap < need) {
+        if (gp->gpart) hipFree(gp->gpart);
+        gp->gpart = nullptr;
+        gp->gpart_cap = 0;
+        GPMI_HIP(c, hipMalloc(&gp->gpart, (size_t)need));
+        gp->gpart_cap = need;
+    }
+    {
+        ProfScope ps(c, GPMI_PROF_SOLVE, 2.0 * (double)npad * (double)npad * (double)npad / 3.0);
+        // rows of L^-T: the whiten sequence applied to the identity; row i is zero left of column i, so panel k
+        // only has to process rows < kend
+        launch_set_identity<T>(c, G1, ld, npad);
+        for (int64_t k0 = 0; k0 < npad; k0 += NB) {
+            const int64_t nbk = std::min<int64_t>(NB, npad - k0);
+            rows_block_solve<T>(c, A, ld, (const T*)gp->linv, npad, G1, ld, k0 + nbk, k0, nbk);
+        }
+        // K^-1 = L^-T L^-1 = G1 G1'  (lower tiles; K loop starts at the tile's first row)
+        launch_gemm_shape<T>(c, G2, ld, G1, ld, G1, ld, npad, npad, npad, TileShape{0, 0, 1, 0, 1, 0}, nullptr,
+                             GEMM_OVERWRITE | GEMM_KSTART_ROW);
+        const int64_t nblocks = launch_dmll<T>(c, (const T*)gp->x, n, gp->d, (const T*)gp->alpha, G2, ld, gp->gpart, n_hyp);
+        launch_reduce_partials(c, gp->gpart, nblocks, n_hyp + 1, (double*)gp->g1);  // g1 is free again: result vector
+    }
+    std::vector<double> h((size_t)n_hyp + 1);
+    GPMI_HIP(c, hipMemcpyAsync(h.data(), gp->g1, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    GPMI_HIP(c, hipStreamSynchronize(c->stream));
+    GPMI_HIP(c, hipGetLastError());
+    for (int p = 0; p < n_hyp; ++p) dkern_out[p] = h[(size_t)p];
+    if (dnoise_out) *dnoise_out = exp(2.0 * log_noise[0]) * h[(size_t)n_hyp];  // GPE.jl:273-275
     return GPMI_OK;
 }
 
@@ -510,7 +572,8 @@ void gpmi_gp_destroy(gpmi_gp* gp) {
         hipSetDevice(gp->ctx->device);
         hipStreamSynchronize(gp->ctx->stream);
     }
-    void* ptrs[] = {gp->x, gp->A, gp->ymu, gp->alpha, gp->invdiag, gp->linv, gp->noise, gp->rows, gp->xp, gp->small};
+    void* ptrs[] = {gp->x, gp->A, gp->ymu, gp->alpha, gp->invdiag, gp->linv, gp->noise, gp->rows, gp->xp, gp->small,
+                    gp->g1, gp->g2, gp->gpart};
     for (void* p : ptrs)
         if (p) hipFree(p);
     delete gp;
@@ -545,6 +608,35 @@ int gpmi_predict(gpmi_gp* gp, const gpmi_kernel* k, int64_t p, const void* xpred
     GPMI_HIP(c, hipSetDevice(c->device));
     return gp->dtype == 64 ? predict_t<double>(gp, k, p, xpred, mean_pred, full_cov, mu_out, var_out)
                            : predict_t<float>(gp, k, p, xpred, mean_pred, full_cov, mu_out, var_out);
+}
+
+int gpmi_grad(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int64_t n_noise, double* dkern_out, int32_t n_kern,
+              double* dnoise_out) {
+    if (!gp) return GPMI_EARG;
+    gpmi_ctx* c = gp->ctx;
+    if (!k || !log_noise || !dkern_out) {
+        c->err = "gpmi_grad: bad argument";
+        return GPMI_EARG;
+    }
+    if (n_noise != 1 && dnoise_out) {
+        c->err = "gpmi_grad: the noise gradient is defined for scalar logNoise only (GPE.jl:313)";
+        return GPMI_EARG;
+    }
+    if (!gp->fitted) {
+        c->err = "gpmi_grad: no valid factorisation (call gpmi_fit first)";
+        return GPMI_EARG;
+    }
+    {   // the caller's buffer must match the kernel's parameter count
+        std::string err;
+        DevProgram* tmp = c->h_prog;
+        if (digest_kernel(k, gp->d, tmp, &err) != GPMI_OK || tmp->n_hyp != n_kern) {
+            c->err = err.empty() ? "gpmi_grad: dkern_out length differs from the kernel's number of parameters" : err;
+            return GPMI_EARG;
+        }
+    }
+    GPMI_HIP(c, hipSetDevice(c->device));
+    return gp->dtype == 64 ? grad_t<double>(gp, k, log_noise, dkern_out, dnoise_out)
+                           : grad_t<float>(gp, k, log_noise, dkern_out, dnoise_out);
 }
 
 int gpmi_cov(gpmi_ctx* c, const gpmi_kernel* k, int dtype, int d, int64_t n1, const void* x1, int64_t n2, const void* x2,

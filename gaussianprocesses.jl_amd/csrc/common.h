@@ -30,8 +30,12 @@ struct DevLeaf {
     int32_t op;     // gpmi_op
     int32_t woff;   // offset of this leaf's d weights inside DevProgram::w (leaf ops only)
     double s2;      // signal variance
-    double p0;      // iso: l2 (SE/RQ) or l (Matern); unused for ARD
+    double p0;      // reciprocal constant: 1/l2 (SE iso), 1/l (Matern iso), 1/(2 a l2) (RQ iso), 0.5/a (RQ ard), 1 otherwise
     double p1;      // RQ: alpha
+    // gradient path (update_dmll!): tree structure and where this node's log-parameters sit in get_params order
+    int32_t left, right;  // children of a SUM / PROD node (indices into leaf[])
+    int32_t poff;         // first hyper-parameter slot of this leaf
+    int32_t nd;           // number of active input rows (ARD leaves own nd length scales, slots poff .. poff+nd-1)
 };
 struct DevProgram {
     int32_t n_ops;
@@ -39,8 +43,11 @@ struct DevProgram {
     int32_t has_noise_leaf;
     int32_t pad_;
     double kdiag;  // k(x,x): the program evaluated with every leaf at r = 0
+    int32_t n_hyp;  // total number of kernel hyper-parameters (get_params order)
+    int32_t pad2_;
     DevLeaf leaf[GPMI_MAX_OPS];
     double w[GPMI_MAX_OPS * MAX_D];
+    int16_t pmap[GPMI_MAX_OPS * MAX_D];  // ARD leaves: slot offset (within the leaf) of input row k, or -1
 };
 
 // digest + validate; returns GPMI_OK / GPMI_EARG and fills err
@@ -89,6 +96,10 @@ struct gpmi_gp {
     void* ymu = nullptr;     // y - mu, npad elements (zero padded)
     void* alpha = nullptr;   // npad elements
     void* invdiag = nullptr; // 1 / L_ii, npad elements
+    void* g1 = nullptr;      // gradient path scratch: L^-T rows, then reused (npad x ld), allocated on first gpmi_grad
+    void* g2 = nullptr;      // gradient path: (K + noise)^-1, lower triangle (npad x ld)
+    double* gpart = nullptr; // gradient path: per-block partial sums
+    int64_t gpart_cap = 0;
     void* linv = nullptr;    // inverses of the 64 x 64 diagonal blocks, (npad / 64) x 64 x 64 (every later solve is a GEMM)
     double* noise = nullptr; // per-point nugget (heteroscedastic) or nullptr
     bool fitted = false;
@@ -144,7 +155,8 @@ void launch_gemm_nt(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, c
 // shape.ntm / shape.ntn are filled in from M and N
 template <typename T>
 void launch_gemm_shape(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M,
-                       int64_t N, int64_t K, TileShape shape, const int* info);
+                       int64_t N, int64_t K, TileShape shape, const int* info, int flags = 0);
+enum GemmFlags { GEMM_OVERWRITE = 1 /* C = A B' instead of C -= A B' */, GEMM_KSTART_ROW = 2 /* A[i][k] = 0 for k < i: start K at the tile's first row */ };
 
 // in-place Cholesky of the 64 x 64 block at A (row-major, ld): lower factor, upper part zeroed; linv (64 x 64,
 // row-major, ld 64) receives L^-1 and invdiag[0..64) 1 / L_jj.  On a non-positive pivot j (0-based) writes
@@ -184,6 +196,21 @@ void launch_row_var(gpmi_ctx* ctx, const T* R, int64_t ldr, int64_t P, int64_t n
 
 template <typename T>
 void launch_logdiag(gpmi_ctx* ctx, const T* A, int64_t ld, int64_t nrows, int64_t col_off, double* out);
+
+// gradient path -------------------------------------------------------------------------------------------
+constexpr int GRAD_MAX_NODES = 32;  // kernel-tree size the device gradient handles (cost grows with leaves^2)
+constexpr int GRAD_MAX_HYP = 48;    // hyper-parameters
+constexpr int GRAD_MAX_D = 16;      // input dimension
+// A[i][i] = 1, everything else 0 (n x n, row-major)
+template <typename T>
+void launch_set_identity(gpmi_ctx* ctx, T* A, int64_t ld, int64_t n);
+// partial[b][0..n_hyp) = sum over block b of (alpha_i alpha_j - Kinv_ij) dK_ij/dtheta_p (diag counted half),
+// partial[b][n_hyp] = block b's share of tr(alpha alpha' - Kinv); returns the number of blocks
+template <typename T>
+int64_t launch_dmll(gpmi_ctx* ctx, const T* x, int64_t n, int d, const T* alpha, const T* Kinv, int64_t ld, double* partial,
+                    int n_hyp);
+// out[s] = sum_b partial[b][s]  (deterministic order)
+void launch_reduce_partials(gpmi_ctx* ctx, const double* partial, int64_t nblocks, int nslots, double* out);
 
 // isolated timing of the update kernel on random operands (variant 0 = product kernel)
 template <typename T>

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
                                                          int64_t lda, const T* __restrict__ B, int64_t ldb, int64_t M,
                                                          int64_t N, int64_t K, TileShape shape,
                                                          unsigned long long* __restrict__ queue, QueueArgs qa,
-                                                         const int* __restrict__ info) {
+                                                         const int* __restrict__ info, int flags) {
     using MF = Mfma<T>;
     using Vec = typename MF::Vec;
     using Acc = typename MF::Acc;
@@ -155,10 +155,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[mi][ni].v[r] = T(0);
 
-        stage(0, 0);
+        // GEMM_KSTART_ROW: A is upper-triangular-by-rows (A[i][k] = 0 for k < i), so the products below the
+        // tile's first row vanish — start the K loop there (this is what makes K^-1 = L^-T L^-1 cost N^3/3)
+        const int kbeg = (flags & GEMM_KSTART_ROW) ? (int)(m0 / BK) : 0;
+        stage(kbeg & 1, kbeg * BK);
         __syncthreads();  // drains the DMA (vmcnt) and publishes the slab
 
-        for (int kt = 0; kt < nk; ++kt) {
+        for (int kt = kbeg; kt < nk; ++kt) {
             const int cur = kt & 1;
             if (kt + 1 < nk && !(VARIANT & 4)) stage(cur ^ 1, (kt + 1) * BK);
 #pragma unroll
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     const int64_t grow = grow0 + it * RPI;
-                    if ((VARIANT & 1) || grow >= M || gcol + VEC > N) {
+                    if ((VARIANT & 1) || (flags & GEMM_OVERWRITE) || grow >= M || gcol + VEC > N) {
 #pragma unroll
                         for (int e = 0; e < VEC; ++e) cv[it][e] = T(0);
                     } else {
@@ -255,11 +258,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
                     const VT v = *reinterpret_cast<const VT*>(stg + (it * RPI + rloc) * 64 + cloc);
                     if (grow < M) {
                         if (gcol + VEC <= N) {
-                            *reinterpret_cast<VT*>(C + grow * ldc + gcol) = cv[it] - v;
+                            *reinterpret_cast<VT*>(C + grow * ldc + gcol) = (flags & GEMM_OVERWRITE) ? v : cv[it] - v;
                         } else {  // ragged right edge (only the P x P full_cov update gets here)
 #pragma unroll
                             for (int e = 0; e < VEC; ++e)
-                                if (gcol + e < N) C[grow * ldc + gcol + e] -= v[e];
+                                if (gcol + e < N) C[grow * ldc + gcol + e] = (flags & GEMM_OVERWRITE) ? v[e] : C[grow * ldc + gcol + e] - v[e];
                         }
                     }
                 }
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(T* out, int iters) {
 
 template <typename T, int V>
 static void launch_persistent(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M,
-                              int64_t N, int64_t K, TileShape shape, const int* info) {
+                              int64_t N, int64_t K, TileShape shape, const int* info, int flags = 0) {
     shape.ntm = (int)((M + GEMM_BM - 1) / GEMM_BM);
     shape.ntn = (int)((N + GEMM_BN - 1) / GEMM_BN);
     const int64_t ntiles = tile_count(shape);
@@ -309,7 +312,7 @@ static void launch_persistent(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int6
         if (qa.use_queue) ctx->queue_base[x] += (unsigned long long)(qa.start[x + 1] - qa.start[x]);
     }
     hipLaunchKernelGGL((gemm_nt_kernel<T, V>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, C, ldc, A, lda, B, ldb, M, N,
-                       K, shape, ctx->d_queue, qa, info);
+                       K, shape, ctx->d_queue, qa, info, flags);
 }
 
 static double shape_entries(int64_t M, int64_t N, const TileShape& s) {
@@ -323,10 +326,10 @@ static double shape_entries(int64_t M, int64_t N, const TileShape& s) {
 
 template <typename T>
 void launch_gemm_shape(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M,
-                       int64_t N, int64_t K, TileShape shape, const int* info) {
+                       int64_t N, int64_t K, TileShape shape, const int* info, int flags) {
     if (M <= 0 || N <= 0 || K <= 0) return;
-    ProfScope ps(ctx, shape.mode ? GPMI_PROF_SYRK : GPMI_PROF_PANEL, 2.0 * shape_entries(M, N, shape) * (double)K);
-    launch_persistent<T, 0>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info);
+    ProfScope ps(ctx, (shape.mode && !flags) ? GPMI_PROF_SYRK : GPMI_PROF_PANEL, 2.0 * shape_entries(M, N, shape) * (double)K);
+    launch_persistent<T, 0>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags);
 }
 
 template <typename T>
@@ -336,9 +339,9 @@ void launch_gemm_nt(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, c
 }
 
 template void launch_gemm_shape<double>(gpmi_ctx*, double*, int64_t, const double*, int64_t, const double*, int64_t, int64_t,
-                                        int64_t, int64_t, TileShape, const int*);
+                                        int64_t, int64_t, TileShape, const int*, int);
 template void launch_gemm_shape<float>(gpmi_ctx*, float*, int64_t, const float*, int64_t, const float*, int64_t, int64_t,
-                                       int64_t, int64_t, TileShape, const int*);
+                                       int64_t, int64_t, TileShape, const int*, int);
 template void launch_gemm_nt<double>(gpmi_ctx*, double*, int64_t, const double*, int64_t, const double*, int64_t,
                                      int64_t, int64_t, int64_t, int, const int*);
 template void launch_gemm_nt<float>(gpmi_ctx*, float*, int64_t, const float*, int64_t, const float*, int64_t, int64_t,

@@ -130,6 +130,42 @@ class GPE:
         self.mll = mll.value
         return self
 
+    # -- update_dmll! : GPE.jl:298-324 -------------------------------------------
+    def update_dmll(self, noise=True, domean=True, kern=True):
+        """Gradient of the mll in the order [logNoise; mean…; kernel…] (the exposed parameters only).
+        Kernel and noise parts come from the device (gpmi_grad); the mean part is dot(grad_mean, alpha)."""
+        if self.alpha is None:
+            raise _lib.ArgumentError("update_dmll needs a fitted model (call update_mll first)")
+        parts = []
+        nfull = self.kernel._full_num_params()
+        if noise or kern:
+            if np.ndim(self.logNoise) != 0 and noise:
+                raise _lib.ArgumentError("the noise gradient needs a scalar logNoise (GPE.jl:313)")
+            ln = np.atleast_1d(np.asarray(self.logNoise, dtype=np.float64))
+            kd, keep = self.kernel.descriptor(self.dim)
+            dk = np.empty(max(nfull, 1), dtype=np.float64)
+            dn = C.c_double()
+            rc = _lib.load().gpmi_grad(self.cK.h, C.byref(kd), ln.ctypes.data_as(C.POINTER(C.c_double)), ln.shape[0],
+                                       dk.ctypes.data_as(C.POINTER(C.c_double)), nfull, C.byref(dn) if noise else None)
+            del keep
+            self.ctx.check(rc)
+        if noise:
+            parts.append([dn.value])
+        if domean and self.mean.num_params() > 0:
+            parts.append(list(self.mean.grad_stack(self.x).T @ np.asarray(self.alpha, dtype=np.float64)))  # GPE.jl:282-288
+        if kern:
+            parts.append([dk[i] for i in self.kernel.grad_slots()])
+        self.dmll = np.asarray([v for p in parts for v in p], dtype=np.float64)
+        self.dtarget = self.dmll
+        return self
+
+    def update_mll_and_dmll(self, **kw):  # GPE.jl:331-334
+        self.update_mll(**kw)
+        self.target = self.mll
+        return self.update_dmll(**kw)
+
+    update_target_and_dtarget = update_mll_and_dmll  # GPE.jl:387-392 (no priors on this path)
+
     def initialise_target(self):  # GPE.jl:346-350 (no priors on this path)
         self.update_mll()
         self.target = self.mll
@@ -231,40 +267,26 @@ def set_params(gp, hyp, **kw):
     return gp.set_params(hyp, **kw)
 
 
-def optimize(gp, noise=True, domean=True, kern=True, method="L-BFGS-B", options=None, eps=1e-5):
-    """optimize!(gp) — src/optimize.jl:19-37 with its error contract (:48-58, :74-83): a
-    PosDefException / ArgumentError during an evaluation restores the previous parameters
-    and the point is reported as infeasible (Inf).
-
-    The analytic gradient path (update_dmll!, src/GPE.jl:298-324) is SURVEY.md §8f-1
-    ("next"); until it is on the device this driver differentiates the device mll by
-    central differences (2·nparams fits per gradient)."""
+def optimize(gp, noise=True, domean=True, kern=True, method="L-BFGS-B", options=None):
+    """optimize!(gp) — src/optimize.jl:19-37 with its error contract (:48-58, :74-83): a PosDefException /
+    ArgumentError during an evaluation restores the previous parameters and the point is reported as infeasible
+    (Inf, zero gradient).  Target and gradient come from the device (update_target_and_dtarget!, GPE.jl:387-392)."""
     from scipy.optimize import minimize
 
     kw = dict(noise=noise, domean=domean, kern=kern)
 
-    def target(hyp):
+    def fg(hyp):
         prev = gp.get_params(**kw)
         try:
             gp.set_params(hyp, **kw)
-            gp.update_target()
-            return -gp.target
+            gp.update_target_and_dtarget(**kw)
+            return -gp.target, -gp.dtarget
         except (_lib.PosDefException, _lib.ArgumentError):
             gp.set_params(prev, **kw)
-            return math.inf
-
-    def grad(hyp):
-        g = np.zeros(len(hyp))
-        for i in range(len(hyp)):
-            hp = np.array(hyp, dtype=float)
-            hm = hp.copy()
-            hp[i] += eps
-            hm[i] -= eps
-            g[i] = (target(hp) - target(hm)) / (2 * eps)
-        return g
+            return math.inf, np.zeros(len(hyp))
 
     x0 = np.asarray(gp.get_params(**kw), dtype=float)
-    res = minimize(target, x0, jac=grad, method=method, options=options or {"maxiter": 20})
+    res = minimize(fg, x0, jac=True, method=method, options=options or {"maxiter": 20})
     gp.set_params(res.x, **kw)
     gp.update_target()
     return res

@@ -77,6 +77,15 @@ class Kernel:
         self._flatten(d, None, ops, dims_off, dims, params)
         return ops, dims_off, dims, params
 
+    def grad_slots(self):
+        """For each exposed parameter (get_params order) the index of the wrapped tree's parameter it is —
+        identity except under FixedKernel (fixed_kernel.jl:63-66).  The device gradient is produced for the
+        full tree; this picks the exposed part."""
+        return list(range(self.num_params()))
+
+    def _full_num_params(self):
+        return self.num_params()
+
 
 class _Leaf(Kernel):
     def _emit(self, d, active, ops, dims_off, dims, params, stored):
@@ -260,6 +269,13 @@ class _Pair(Kernel):
         ops.append(self._op)
         dims_off.append(len(dims))
 
+    def grad_slots(self):
+        off = self.kleft._full_num_params()
+        return self.kleft.grad_slots() + [off + i for i in self.kright.grad_slots()]
+
+    def _full_num_params(self):
+        return self.kleft._full_num_params() + self.kright._full_num_params()
+
 
 class SumKernel(_Pair):
     _op = OP_SUM
@@ -289,6 +305,12 @@ class Masked(Kernel):
                 raise _lib.ArgumentError("Masked: active dimension out of range")
         self.kernel._flatten(d, new_active, ops, dims_off, dims, params)
 
+    def grad_slots(self):
+        return self.kernel.grad_slots()
+
+    def _full_num_params(self):
+        return self.kernel._full_num_params()
+
 
 class FixedKernel(Kernel):
     """FixedKernel(kernel, free): only parameters whose indices are in `free` are exposed
@@ -312,6 +334,13 @@ class FixedKernel(Kernel):
 
     def _flatten(self, d, active, ops, dims_off, dims, params):
         self.kernel._flatten(d, active, ops, dims_off, dims, params)
+
+    def grad_slots(self):
+        inner = self.kernel.grad_slots()
+        return [inner[i] for i in self.free]
+
+    def _full_num_params(self):
+        return self.kernel._full_num_params()
 
 
 def fix(kernel, *fixed_indices):

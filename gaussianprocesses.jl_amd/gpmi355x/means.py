@@ -18,6 +18,10 @@ class Mean:
     def num_params(self):
         return len(self.get_params())
 
+    def grad_stack(self, X):
+        """nobs × num_params matrix of d mean / d parameter (means/means.jl:16-23)."""
+        return np.zeros((np.asarray(X).shape[1], 0))
+
 
 class MeanZero(Mean):  # means/mZero.jl:16
     def mean(self, X):
@@ -30,6 +34,9 @@ class MeanConst(Mean):  # means/mConst.jl:27
 
     def mean(self, X):
         return np.full(np.asarray(X).shape[1], self.beta)
+
+    def grad_stack(self, X):  # mConst.jl:36
+        return np.ones((np.asarray(X).shape[1], 1))
 
     def get_params(self):
         return [self.beta]
@@ -46,6 +53,9 @@ class MeanLin(Mean):  # means/mLin.jl:27   X'β
 
     def mean(self, X):
         return np.asarray(X, dtype=np.float64).T @ self.beta
+
+    def grad_stack(self, X):  # mLin.jl:38
+        return np.asarray(X, dtype=np.float64).T.copy()
 
     def get_params(self):
         return list(self.beta)

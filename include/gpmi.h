@@ -115,6 +115,18 @@ int gpmi_fit(gpmi_gp*, const gpmi_kernel*, const double* log_noise, int64_t n_no
 int gpmi_predict(gpmi_gp*, const gpmi_kernel*, int64_t p, const void* xpred, const void* mean_pred,
                  int full_cov, void* mu_out, void* var_out);
 
+/* ---- gradient: replaces update_dmll! (src/GPE.jl:298-324) for the kernel and noise parts ----
+ * After a successful gpmi_fit with the SAME kernel / log_noise:
+ *   dkern_out[p] = d mll / d theta_p for the kernel's log-scale parameters in get_params order
+ *                  (leaf files' get_params; composites left then right, src/kernels/pair_kernel.jl:15):
+ *                  1/2 sum_ij (alpha alpha' - K^-1)_ij dK_ij/dtheta_p   (dmll_kern!, GPE.jl:219-241)
+ *   dnoise_out   = exp(2 logNoise) tr(alpha alpha' - K^-1)             (dmll_noise, GPE.jl:273-275; may be NULL)
+ * The mean part, dot(grad_mean, alpha) (GPE.jl:282-288), is O(N d) host work on alpha.
+ * n_kern must equal the kernel's parameter count.  Allocates two more n x n device buffers on
+ * first use.  Kernels beyond 48 parameters / d > 16 return GPMI_EARG.          */
+int gpmi_grad(gpmi_gp*, const gpmi_kernel*, const double* log_noise, int64_t n_noise, double* dkern_out, int32_t n_kern,
+              double* dnoise_out);
+
 /* ---- cov: replaces cov / cov! (src/kernels/kernels.jl:31-71) -------------
  * out is n1 x n2 col-major; x2 == NULL selects the symmetric X1 === X2 form. */
 int gpmi_cov(gpmi_ctx*, const gpmi_kernel*, int dtype, int d, int64_t n1, const void* x1,

@@ -378,3 +378,109 @@ def synthetic_inputs(n, d, p=1024, seed=20240501):
     y = f + 0.1 * rng.standard_normal(n)
     xpred = rng.uniform(0.0, 1.0, size=(d, p))
     return x, y, xpred
+
+
+# --------------------------------------------------------------------------
+# gradient path:  update_dmll!  (src/GPE.jl:151-164, 219-241, 273-324) — SURVEY §8(f-1)
+# --------------------------------------------------------------------------
+def grad_cov(spec, X):
+    """K = cov(k, X) and the stack [dK/dθ_p] in get_params order (log-scale parameters).
+
+    Leaf derivatives follow dk_dθp / dKij_dθp of each leaf file:
+      se_iso.jl:41-50  se_ard.jl:45-54  mat12_iso.jl:42 mat12_ard.jl:44  mat32_iso.jl:43-44 mat32_ard.jl:45
+      mat52_iso.jl:42-43 mat52_ard.jl:45-46  mat.jl:5-33 (zero at r = 0 / wdiff = 0)  rq_iso.jl:45-61 rq_ard.jl:48-63
+      noise.jl:47-48  const.jl:40-46;  Sum: sum_kernel.jl:18-51;  Prod: prod_kernel.jl:17-68;
+      Masked: masked_kernel.jl:51-56;  Fixed: fixed_kernel.jl:63-66;  dk_dlσ = 2k: stationary.jl:28."""
+    X = np.asarray(X, dtype=np.float64)
+    name = spec[0]
+    n = X.shape[1]
+    if name == "sum":
+        K1, d1 = grad_cov(spec[1], X)
+        K2, d2 = grad_cov(spec[2], X)
+        return K1 + K2, d1 + d2
+    if name == "prod":
+        K1, d1 = grad_cov(spec[1], X)
+        K2, d2 = grad_cov(spec[2], X)
+        return K1 * K2, [d * K2 for d in d1] + [K1 * d for d in d2]
+    if name == "masked":
+        return grad_cov(spec[1], X[list(spec[2]), :])
+    if name == "fixed":
+        K, d = grad_cov(spec[1], X)
+        return K, [d[i] for i in spec[2]]
+    if name == "noise":
+        K = _leaf(spec, X, X)
+        return K, [2.0 * K]
+    if name == "const":
+        K = _leaf(spec, X, X)
+        return K, [2.0 * K]
+    K = _leaf(spec, X, X)
+    s2 = math.exp(2.0 * float(spec[2]))
+    if name in _ISO:
+        ll = float(spec[1])
+        r = _sqdist(X, X)
+        if name == "se_iso":
+            return K, [r / math.exp(2.0 * ll) * K, 2.0 * K]
+        if name == "rq_iso":
+            al = math.exp(float(spec[3]))
+            s = r / math.exp(2.0 * ll)
+            part = 1.0 + s / (2.0 * al)
+            return K, [s2 * s * part ** (-al - 1.0), 2.0 * K, s2 * part ** (-al) * (s / (2.0 * part) - al * np.log(part))]
+        r = np.sqrt(r)
+        ell = math.exp(ll)
+        if name == "mat12_iso":
+            dll = r / ell * K
+        elif name == "mat32_iso":
+            s = SQRT3 * r / ell
+            dll = s2 * s * s * np.exp(-s)
+        else:
+            s = SQRT5 * r / ell
+            dll = s2 / 3.0 * s * s * (1.0 + s) * np.exp(-s)
+        return K, [np.where(r == 0.0, 0.0, dll), 2.0 * K]
+    lls = np.asarray(spec[1], dtype=np.float64)
+    w = np.exp(-2.0 * lls)
+    r = _sqdist(X, X, w)
+    wd = [(X[k, :, None] - X[k, None, :]) ** 2 * w[k] for k in range(X.shape[0])]
+    if name == "se_ard":
+        return K, [wdk * K for wdk in wd] + [2.0 * K]
+    if name == "rq_ard":
+        al = math.exp(float(spec[3]))
+        part = 1.0 + r / (2.0 * al)
+        return K, [s2 * wdk * part ** (-al - 1.0) for wdk in wd] + [2.0 * K, s2 * part ** (-al) * (r / (2.0 * part) - al * np.log(part))]
+    re = np.sqrt(r)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        if name == "mat12_ard":
+            dl = [np.where(wdk > 0, wdk / re * K, 0.0) for wdk in wd]
+        elif name == "mat32_ard":
+            dl = [np.where(wdk > 0, 3.0 * s2 * wdk * np.exp(-SQRT3 * re), 0.0) for wdk in wd]
+        else:
+            s = SQRT5 * re
+            dl = [np.where(wdk > 0, 5.0 / 3.0 * s2 * wdk * (1.0 + s) * np.exp(-s), 0.0) for wdk in wd]
+    return K, dl + [2.0 * K]
+
+
+def grad_mean(mspec, X):
+    """grad_stack(m, X): nobs × num_params (means/means.jl:16-23; mConst.jl:36, mLin.jl:38)."""
+    X = np.asarray(X, dtype=np.float64)
+    if mspec[0] == "zero":
+        return np.zeros((X.shape[1], 0))
+    if mspec[0] == "const":
+        return np.ones((X.shape[1], 1))
+    if mspec[0] == "lin":
+        return X.T.copy()
+    raise ValueError(mspec[0])
+
+
+def update_dmll(spec, x, y, log_noise, mspec=("zero",), fit=None):
+    """update_dmll! (GPE.jl:298-324): gradient of the mll in the order [logNoise; mean…; kernel…]."""
+    x = np.asarray(x, dtype=np.float64)
+    if fit is None:
+        fit = update_mll(spec, x, y, log_noise, mspec)
+    n = x.shape[1]
+    alpha = fit["alpha"]
+    Kinv = sla.cho_solve((fit["U"], False), np.eye(n))
+    W = np.outer(alpha, alpha) - Kinv  # get_ααinvcKI!, GPE.jl:151-164
+    dnoise = math.exp(2.0 * float(log_noise)) * np.trace(W)  # GPE.jl:273-275
+    dmean = grad_mean(mspec, x).T @ alpha  # GPE.jl:282-288
+    _, dKs = grad_cov(spec, x)
+    dkern = np.array([0.5 * np.sum(W * dK) for dK in dKs])  # GPE.jl:219-241 (diag/2 + strict lower = half the full sum)
+    return {"dmll": np.concatenate([[dnoise], dmean, dkern]), "dnoise": dnoise, "dmean": dmean, "dkern": dkern}

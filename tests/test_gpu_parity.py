@@ -328,10 +328,60 @@ def test_synthetic_workload_n4000_vs_oracle():
     _close(s2, s2_o, 1e-5, 1e-9, "sigma2")
 
 
-def test_optimize_improves_target():
-    """test/optim.jl:20-25: optimize! increases the target."""
-    x, y, _ = G.synthetic_inputs(300, 2, p=4)
-    gp = g.GP(x, y, g.MeanZero(), g.SEIso(0.0, 0.0), -1.0)
+# --------------------------------------------------------------------------------------------
+# gradient path: update_dmll! on the device vs the oracle's restatement of the reference formulas
+# (themselves checked against finite differences, as test/kernels.jl:84-93,148-164 do)
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("spec", ALL, ids=ids(ALL))
+def test_gradient_all_kernels_fp64(spec):
+    rng = np.random.default_rng(21)
+    n = 333
+    x = rng.uniform(size=(D, n))
+    x[:, 7] = x[:, 200]  # coincident pair: r = 0 branches of the Matern derivatives, Noise off-diagonal hit
+    y = np.sin(3 * x.sum(axis=0)) + 0.1 * rng.standard_normal(n)
+    ln = math.log(0.25)
+    gp = g.GP(x, y, g.MeanConst(0.2), g.from_spec(spec), ln)
+    gp.update_dmll()
+    ref = G.update_dmll(spec, x, y, ln, ("const", 0.2))
+    scale = np.abs(ref["dmll"]).max() + 1e-12
+    _close(gp.dmll, ref["dmll"], 1e-7, 1e-9 * scale, "dmll")
+    assert len(gp.dmll) == 1 + 1 + G.num_params(spec)
+
+
+def test_gradient_switches_and_mean_lin():
+    rng = np.random.default_rng(22)
+    n = 700  # spans three outer panels
+    x = rng.uniform(size=(3, n))
+    y = 1.0 + x.T @ np.array([1.0, -2.0, 0.5]) + 0.1 * rng.standard_normal(n)
+    spec = ("prod", ("sum", ("se_ard", [0.1, 0.0, -0.1], 0.3), ("mat32_iso", 0.2, -0.2)), ("rq_iso", 0.5, 0.1, 0.3))
+    gp = g.GP(x, y, g.MeanLin([1.0, -2.0, 0.5]), g.from_spec(spec), -1.0)
+    ref = G.update_dmll(spec, x, y, -1.0, ("lin", [1.0, -2.0, 0.5]))
+    gp.update_dmll()
+    _close(gp.dmll, ref["dmll"], 1e-7, 1e-9 * np.abs(ref["dmll"]).max(), "dmll")
+    gp.update_dmll(noise=False, domean=False)
+    _close(gp.dmll, ref["dkern"], 1e-7, 1e-9 * np.abs(ref["dkern"]).max(), "dmll kern only")
+    gp.update_mll_and_dmll(kern=True, noise=True, domean=True)
+    assert gp.target == gp.mll and len(gp.dtarget) == 1 + 3 + 9
+
+
+def test_gradient_synthetic_d8_n3000():
+    x, y, _ = G.synthetic_inputs(3000, 8, p=4)
+    ll = [math.log(0.5) + 0.05 * k for k in range(8)]
+    spec = ("sum", ("se_ard", ll, 0.0), ("mat52_iso", math.log(0.7), math.log(0.5)))
+    gp = g.GP(x, y, g.MeanZero(), g.from_spec(spec), math.log(0.1))
+    gp.update_dmll()
+    ref = G.update_dmll(spec, x, y, math.log(0.1))
+    _close(gp.dmll, ref["dmll"], 1e-6, 1e-8 * np.abs(ref["dmll"]).max(), "dmll")
+
+
+def test_optimize_with_device_gradient_matches_reference_contract():
+    """test/optim.jl:20-25 (target improves), :54-82 (switched-off parameter groups stay bit-identical)."""
+    x, y, _ = G.synthetic_inputs(400, 2, p=4)
+    gp = g.GP(x, y, g.MeanConst(0.0), g.SEArd([0.0, 0.0], 0.0) + g.Noise(-2.0), -1.0)
     t0 = gp.target
-    g.optimize(gp, options={"maxiter": 5})
-    assert gp.target > t0
+    before = gp.get_params()
+    res = g.optimize(gp, domean=False, options={"maxiter": 8})
+    assert gp.target > t0 + 1.0
+    after = gp.get_params()
+    assert after[1] == before[1]  # the mean parameter was not optimised
+    assert res.nfev < 40           # a gradient-based run, not a finite-difference one

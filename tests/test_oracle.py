@@ -197,3 +197,51 @@ def test_heteroscedastic_noise_path():
     K = G.cov(("se_iso", -0.5, 0.0), x) + np.diag(np.exp(2 * ln))
     np.testing.assert_allclose(K @ fit["alpha"], y, rtol=1e-9, atol=1e-11)
     assert np.isfinite(fit["mll"])  # heteroscedastic.jl:34-48
+
+
+# --- gradient path: test/kernels.jl:84-93,148-164 — analytic dtarget vs finite differences (rtol 1e-3 there) ----
+def _perturb(spec, p, h):
+    """spec with its p-th log-parameter (get_params order) shifted by h; returns (new_spec, consumed)."""
+    name = spec[0]
+    if name in ("sum", "prod"):
+        n1 = G.num_params(spec[1])
+        if p < n1:
+            return (name, _perturb(spec[1], p, h), spec[2])
+        return (name, spec[1], _perturb(spec[2], p - n1, h))
+    if name == "masked":
+        return (name, _perturb(spec[1], p, h), spec[2])
+    if name == "fixed":
+        return (name, _perturb(spec[1], spec[2][p], h), spec[2])
+    if name in ("noise", "const"):
+        return (name, spec[1] + h)
+    if name.endswith("_iso"):
+        vals = list(spec[1:])
+        vals[p] += h
+        return (name, *vals)
+    lls = list(spec[1])
+    rest = list(spec[2:])
+    if p < len(lls):
+        lls[p] += h
+    else:
+        rest[p - len(lls)] += h
+    return (name, lls, *rest)
+
+
+@pytest.mark.parametrize("spec", ALL, ids=ids(ALL))
+def test_oracle_gradient_vs_finite_differences(spec):
+    rng = np.random.default_rng(9)
+    n = 25
+    x = rng.uniform(size=(D, n))
+    x[:, 3] = x[:, 11]  # a coincident pair: exercises the r = 0 branches of the Matern derivatives
+    y = np.sin(3 * x.sum(axis=0)) + 0.1 * rng.standard_normal(n)
+    ln = math.log(0.3)
+    g = G.update_dmll(spec, x, y, ln, ("const", 0.2))
+    h = 1e-6
+    fd_noise = (G.update_mll(spec, x, y, ln + h, ("const", 0.2))["mll"] - G.update_mll(spec, x, y, ln - h, ("const", 0.2))["mll"]) / (2 * h)
+    assert g["dnoise"] == pytest.approx(fd_noise, rel=1e-5, abs=1e-6)
+    fd_mean = (G.update_mll(spec, x, y, ln, ("const", 0.2 + h))["mll"] - G.update_mll(spec, x, y, ln, ("const", 0.2 - h))["mll"]) / (2 * h)
+    assert g["dmean"][0] == pytest.approx(fd_mean, rel=1e-5, abs=1e-6)
+    for p in range(G.num_params(spec)):
+        up = G.update_mll(_perturb(spec, p, h), x, y, ln, ("const", 0.2))["mll"]
+        dn = G.update_mll(_perturb(spec, p, -h), x, y, ln, ("const", 0.2))["mll"]
+        assert g["dkern"][p] == pytest.approx((up - dn) / (2 * h), rel=2e-5, abs=2e-6), f"param {p}"
