@@ -15,7 +15,7 @@ using GaussianProcesses
 using GaussianProcesses: GPE, GPBase, Kernel, Mean, KernelData, EmptyData, CovarianceStrategy,
     SEIso, SEArd, Mat12Iso, Mat12Ard, Mat32Iso, Mat32Ard, Mat52Iso, Mat52Ard, RQIso, RQArd,
     Noise, Const, SumKernel, ProdKernel, Masked, FixedKernel, get_value, log2π
-import GaussianProcesses: alloc_cK, update_cK!, update_mll!, predictMVN, predict_f, mat, cholfactors, wrap_cK
+import GaussianProcesses: alloc_cK, update_cK!, update_mll!, update_dmll!, grad_stack, num_params, predictMVN, predict_f, mat, cholfactors, wrap_cK
 using PDMats
 import PDMats: dim, whiten!, whiten, unwhiten!
 using LinearAlgebra
@@ -144,6 +144,35 @@ function update_mll!(gp::GPE{X,Y,M,K,HIPCovariance}; noise::Bool=true, domean::B
         gp.alpha = gp.cK \ ymμ
         gp.mll = -(dot(ymμ, gp.alpha) + logdet(gp.cK) + log2π * gp.nobs) / 2
     end
+    gp
+end
+
+# update_dmll! (src/GPE.jl:298-324): kernel and noise parts from the device in one pass over ααᵀ − K⁻¹
+# (no N×N ααinvcKI on the host, no per-parameter N² loops); the mean part stays here (src/GPE.jl:282-288).
+full_slots(k::Kernel) = collect(1:num_params(k))
+full_slots(k::FixedKernel) = full_slots(k.kernel)[k.free]
+full_slots(k::Masked) = full_slots(k.kernel)
+full_slots(k::Union{SumKernel,ProdKernel}) = [full_slots(k.kleft); full_nparams(k.kleft) .+ full_slots(k.kright)]
+full_nparams(k::Kernel) = num_params(k)
+full_nparams(k::Union{FixedKernel,Masked}) = full_nparams(k.kernel)
+full_nparams(k::Union{SumKernel,ProdKernel}) = full_nparams(k.kleft) + full_nparams(k.kright)
+function update_dmll!(gp::GPE{X,Y,M,K,HIPCovariance}; noise::Bool=true, domean::Bool=true, kern::Bool=true) where {X,Y,M,K}
+    nfull = full_nparams(gp.kernel)
+    dk = Vector{Float64}(undef, max(nfull, 1)); dn = Ref{Float64}(0.0)
+    ln = Float64[get_value(gp.logNoise)]
+    rc = withkernel(descriptor(gp.kernel)) do ck
+        ccall((:gpmi_grad, libgpmi), Cint, (Ptr{Cvoid}, Ref{CKernel}, Ptr{Float64}, Int64, Ptr{Float64}, Int32, Ref{Float64}),
+              gp.cK.handle, ck, ln, 1, dk, nfull, dn)
+    end
+    check(context(), rc)
+    n_mean = num_params(gp.mean)
+    gp.dmll = Vector{Float64}(undef, noise + domean * n_mean + kern * num_params(gp.kernel))
+    i = 1
+    noise && (gp.dmll[i] = dn[]; i += 1)
+    if domean && n_mean > 0
+        gp.dmll[i:i+n_mean-1] = grad_stack(gp.mean, gp.x)' * gp.alpha; i += n_mean
+    end
+    kern && (gp.dmll[i:end] = dk[full_slots(gp.kernel)])
     gp
 end
 
