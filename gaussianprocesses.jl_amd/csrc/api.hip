@@ -199,6 +199,23 @@ static void rows_block_solve(gpmi_ctx* c, const T* A, int64_t ld, const T* linv,
         launch_gemm_nt<T>(c, R + kend, ldr, R + k0, ldr, A + kend * ld + k0, ld, Mr, npad - kend, nbk, 0, nullptr);
 }
 
+// The same whitening through the explicit NB x NB inverses, out of place: V <- R L^-T with one product per NB columns
+//   V[:, k0:kend] = R[:, k0:kend] * Linv_k' ;  R[:, kend:npad] -= V[:, k0:kend] * A[kend:npad, k0:kend]'
+// (R is consumed).  Out of place because the two 128-column tiles of a block read each other's input columns.
+// rows_upto(kend) gives the number of leading rows that can be non-zero up to column kend (identity right-hand sides).
+template <typename T, typename F>
+static void whiten_rows_inv(gpmi_ctx* c, const T* A, int64_t ld, const T* linv256, int64_t npad, T* R, int64_t ldr, T* V,
+                            int64_t ldv, F rows_upto) {
+    for (int64_t k0 = 0; k0 < npad; k0 += NB) {
+        const int64_t nbk = std::min<int64_t>(NB, npad - k0), kend = k0 + nbk;
+        const int64_t Mr = rows_upto(kend);
+        launch_gemm_shape<T>(c, V + k0, ldv, R + k0, ldr, linv256 + (k0 / NB) * NB * NB, NB, Mr, nbk, nbk,
+                             TileShape{0, 0, 0, 0, 1, 0}, nullptr, GEMM_OVERWRITE);
+        if (kend < npad)
+            launch_gemm_nt<T>(c, R + kend, ldr, V + k0, ldv, A + kend * ld + k0, ld, Mr, npad - kend, nbk, 0, nullptr);
+    }
+}
+
 template <typename T>
 static void whiten_rows(gpmi_ctx* c, const T* A, int64_t ld, const T* linv, int64_t npad, T* R, int64_t ldr, int64_t Mr) {
     for (int64_t k0 = 0; k0 < npad; k0 += NB)
@@ -208,24 +225,122 @@ static void whiten_rows(gpmi_ctx* c, const T* A, int64_t ld, const T* linv, int6
 // Blocked right-looking Cholesky of the row-major lower triangle of A (npad x npad), carrying
 // `extra` rows below it (row npad = y) through the panel solves and trailing updates, so that
 // on exit row npad holds z = L^-1 y (the forward half of cK \ y, GPE.jl:208).
+// one NB-wide panel: per 64 columns diag64 (factor + invert the diagonal block) and rows64 over every row below
+// (left-looking update inside the panel + TRSM as a product with the inverse + diagonal-block updates)
+template <typename T>
+static void factor_panel(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, int64_t k0, int64_t nbk, int64_t Mtot, int* d_info) {
+    const int64_t kend = k0 + nbk;
+    for (int64_t j0 = k0; j0 < kend; j0 += IB) {
+        T* linv_j = linv + (j0 / IB) * IB * IB;
+        launch_diag64<T>(c, A + j0 * ld + j0, ld, linv_j, invdiag + j0, d_info, j0);
+        const int64_t r0 = j0 + IB;
+        launch_rows64<T>(c, A + r0 * ld + k0, ld, Mtot - r0, (int)(j0 - k0), A + j0 * ld + k0, ld, linv_j, kend - r0, d_info);
+    }
+}
+// the same panel in two parts: the serial chain on the nbk x nbk diagonal block (one to three workgroups per launch) ...
+template <typename T>
+static void factor_panel_diag(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, int64_t k0, int64_t nbk, int* d_info) {
+    const int64_t kend = k0 + nbk;
+    for (int64_t j0 = k0; j0 < kend; j0 += IB) {
+        T* linv_j = linv + (j0 / IB) * IB * IB;
+        launch_diag64<T>(c, A + j0 * ld + j0, ld, linv_j, invdiag + j0, d_info, j0);
+        const int64_t r0 = j0 + IB;
+        if (r0 < kend)
+            launch_rows64<T>(c, A + r0 * ld + k0, ld, kend - r0, (int)(j0 - k0), A + j0 * ld + k0, ld, linv_j, kend - r0, d_info);
+    }
+}
+// ... and the rows below it (chip-wide), which only need the finished diagonal block and its inverses
+template <typename T>
+static void factor_panel_below(gpmi_ctx* c, T* A, int64_t ld, const T* linv, int64_t k0, int64_t nbk, int64_t Mtot,
+                               const int* d_info) {
+    const int64_t kend = k0 + nbk;
+    for (int64_t j0 = k0; j0 < kend; j0 += IB)
+        launch_rows64<T>(c, A + kend * ld + k0, ld, Mtot - kend, (int)(j0 - k0), A + j0 * ld + k0, ld,
+                         linv + (j0 / IB) * IB * IB, 0, d_info);
+}
+
+// run launches on another stream of the context (the launchers read ctx->stream / ctx->num_cus)
+struct StreamScope {
+    gpmi_ctx* c;
+    hipStream_t s0;
+    int cus0;
+    StreamScope(gpmi_ctx* ctx, hipStream_t s, int cus) : c(ctx), s0(ctx->stream), cus0(ctx->num_cus) {
+        c->stream = s;
+        c->num_cus = cus;
+    }
+    ~StreamScope() {
+        c->stream = s0;
+        c->num_cus = cus0;
+    }
+};
+static hipEvent_t la_event(gpmi_ctx* c, size_t i) {
+    while (c->la_events.size() <= i) {
+        hipEvent_t e;
+        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        c->la_events.push_back(e);
+    }
+    return c->la_events[i];
+}
+
+// blocked right-looking Cholesky, lower, in place; rows npad .. npad+extra-1 are carried along (forward solve for free).
+//
+// Look-ahead (panel_cus > 0): the serial part of panel k+1 — the diag64 / rows64 chain on its 256 x 256 diagonal block,
+// one to three workgroups per launch — runs on panel_stream (a handful of reserved CUs, hipExtStreamCreateWithCUMask)
+// while the trailing update by panel k occupies the rest of the chip on gemm_stream.  For that the update is split into
+// the NB columns the next panel needs (narrow, first) and the rest (wide).
 template <typename T>
 static void cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, int64_t npad, int64_t extra, int* d_info) {
     const int64_t Mtot = npad + extra;
+    if (c->panel_cus <= 0 || npad <= 4 * NB) {
+        for (int64_t k0 = 0; k0 < npad; k0 += NB) {
+            const int64_t nbk = std::min<int64_t>(NB, npad - k0);
+            const int64_t kend = k0 + nbk;
+            factor_panel<T>(c, A, ld, linv, invdiag, k0, nbk, Mtot, d_info);
+            const int64_t M = Mtot - kend;
+            if (M > 0 && kend < npad)  // trailing update (SYRK shape, K = nbk): the MFMA-bound bulk
+                launch_gemm_nt<T>(c, A + kend * ld + kend, ld, A + kend * ld + k0, ld, A + kend * ld + k0, ld, M, npad - kend,
+                                  nbk, 1, d_info);
+        }
+        return;
+    }
+    hipStream_t user = c->stream, gs = c->gemm_stream, ps = c->panel_stream;
+    const int gemm_cus = c->num_cus - c->panel_cus;
+    size_t ne = 0;
+    hipEvent_t e0 = la_event(c, ne++);
+    (void)hipEventRecord(e0, user);
+    (void)hipStreamWaitEvent(gs, e0, 0);
+    StreamScope main_scope(c, gs, gemm_cus);
+    {
+        const int64_t nb0 = std::min<int64_t>(NB, npad);
+        factor_panel_diag<T>(c, A, ld, linv, invdiag, 0, nb0, d_info);
+        factor_panel_below<T>(c, A, ld, linv, 0, nb0, Mtot, d_info);
+    }
     for (int64_t k0 = 0; k0 < npad; k0 += NB) {
         const int64_t nbk = std::min<int64_t>(NB, npad - k0);
-        const int64_t kend = k0 + nbk;
-        for (int64_t j0 = k0; j0 < kend; j0 += IB) {
-            T* linv_j = linv + (j0 / IB) * IB * IB;
-            launch_diag64<T>(c, A + j0 * ld + j0, ld, linv_j, invdiag + j0, d_info, j0);
-            const int64_t r0 = j0 + IB;
-            // rows below: left-looking panel update + TRSM (as a product with L_jj^-1) + diagonal-block updates
-            launch_rows64<T>(c, A + r0 * ld + k0, ld, Mtot - r0, (int)(j0 - k0), A + j0 * ld + k0, ld, linv_j, kend - r0, d_info);
+        const int64_t k1 = k0 + nbk;
+        if (k1 >= npad) break;
+        const int64_t nb1 = std::min<int64_t>(NB, npad - k1);
+        const int64_t k2 = k1 + nb1;
+        // narrow: block column k1, every row below (the carried rows included)
+        launch_gemm_nt<T>(c, A + k1 * ld + k1, ld, A + k1 * ld + k0, ld, A + k1 * ld + k0, ld, Mtot - k1, nb1, nbk, 0, d_info);
+        hipEvent_t en = la_event(c, ne++);
+        (void)hipEventRecord(en, gs);
+        (void)hipStreamWaitEvent(ps, en, 0);
+        {
+            StreamScope sc(c, ps, c->panel_cus);
+            factor_panel_diag<T>(c, A, ld, linv, invdiag, k1, nb1, d_info);
         }
-        const int64_t M = Mtot - kend;
-        if (M > 0 && kend < npad)  // trailing update (SYRK shape, K = nbk): the MFMA-bound bulk
-            launch_gemm_nt<T>(c, A + kend * ld + kend, ld, A + kend * ld + k0, ld, A + kend * ld + k0, ld, M, npad - kend,
-                              nbk, 1, d_info);
+        hipEvent_t ep = la_event(c, ne++);
+        (void)hipEventRecord(ep, ps);
+        if (k2 < npad)  // wide: everything right of the next panel
+            launch_gemm_nt<T>(c, A + k2 * ld + k2, ld, A + k2 * ld + k0, ld, A + k2 * ld + k0, ld, Mtot - k2, npad - k2, nbk, 1,
+                              d_info);
+        (void)hipStreamWaitEvent(gs, ep, 0);
+        factor_panel_below<T>(c, A, ld, linv, k1, nb1, Mtot, d_info);
     }
+    hipEvent_t ed = la_event(c, ne++);
+    (void)hipEventRecord(ed, gs);
+    (void)hipStreamWaitEvent(user, ed, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -283,8 +398,10 @@ static int fit_t(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int
 
     {
         ProfScope ps(c, GPMI_PROF_SOLVE, (double)npad * (double)npad * 0.5 * sizeof(T));
-        for (int64_t j0 = npad - IB; j0 >= 0; j0 -= IB)
-            launch_bsolve_step<T>(c, A + j0 * ld, ld, j0, (const T*)gp->linv + (j0 / IB) * IB * IB, A + npad * ld, (T*)gp->alpha);
+        launch_linv256<T>(c, A, ld, (const T*)gp->linv, (T*)gp->linv256, npad, c->d_info);
+        for (int64_t k0 = (npad - 1) / NB * NB; k0 >= 0; k0 -= NB)
+            launch_bsolve256<T>(c, A + k0 * ld, ld, k0, (int)std::min<int64_t>(NB, npad - k0),
+                                (const T*)gp->linv256 + (k0 / NB) * NB * NB, A + npad * ld, (T*)gp->alpha);
         launch_finalize<T>(c, A, ld, n, (const T*)gp->ymu, (const T*)gp->alpha, c->d_scal);
     }
     int h_info = 0;
@@ -377,11 +494,12 @@ static int predict_t(gpmi_gp* gp, const gpmi_kernel* k, int64_t P, const void* x
     if (rc != GPMI_OK) return rc;
     const double kdiag = c->h_prog->kdiag;
 
-    int64_t rows_bytes = P * ld * (int64_t)sizeof(T);
+    int64_t rows_bytes = 2 * P * ld * (int64_t)sizeof(T);  // K*' rows and, out of place, their whitened image
     if ((rc = grow(c, &gp->rows, &gp->rows_cap, rows_bytes)) != GPMI_OK) return rc;
     if ((rc = grow(c, &gp->xp, &gp->xp_cap, P * d * (int64_t)sizeof(T))) != GPMI_OK) return rc;
     if ((rc = grow(c, &gp->small, &gp->small_cap, std::max<int64_t>(3 * P, npad) * (int64_t)sizeof(T))) != GPMI_OK) return rc;
     T* R = (T*)gp->rows;
+    T* V = R + P * ld;
     T* xp = (T*)gp->xp;
     T* d_mean = (T*)gp->small;
     T* d_mu = d_mean + P;
@@ -394,8 +512,9 @@ static int predict_t(gpmi_gp* gp, const gpmi_kernel* k, int64_t P, const void* x
         // K*' (P x npad, one test point per row): cov(k, xtrain, xpred)', GP.jl:44
         launch_cov<T>(c, xp, P, (const T*)gp->x, n, d, R, ld, P, npad, 0, 0.0, nullptr);
         launch_row_gemv<T>(c, R, ld, P, n, (const T*)gp->alpha, d_mean, d_mu);  // mu = mx + Kfx' alpha, GP.jl:26
-        whiten_rows<T>(c, A, ld, (const T*)gp->linv, npad, R, ld, P);           // Lck = whiten!(Kff, Kfx), GP.jl:27
-        if (!full_cov) launch_row_var<T>(c, R, ld, P, npad, kdiag, d_var);
+        // Lck = whiten!(Kff, Kfx), GP.jl:27
+        whiten_rows_inv<T>(c, A, ld, (const T*)gp->linv256, npad, R, ld, V, ld, [P](int64_t) { return P; });
+        if (!full_cov) launch_row_var<T>(c, V, ld, P, npad, kdiag, d_var);
     }
     GPMI_HIP(c, hipMemcpyAsync(mu_out, d_mu, (size_t)P * sizeof(T), hipMemcpyDeviceToHost, c->stream));
     if (!full_cov) {
@@ -409,7 +528,7 @@ static int predict_t(gpmi_gp* gp, const gpmi_kernel* k, int64_t P, const void* x
     T* Kpp = nullptr;
     GPMI_HIP(c, hipMalloc(&Kpp, (size_t)(P * ldp) * sizeof(T)));
     launch_cov<T>(c, xp, P, xp, P, d, Kpp, ldp, P, ldp, 0, 0.0, nullptr);
-    launch_gemm_nt<T>(c, Kpp, ldp, R, ld, R, ld, P, P, npad, 0, nullptr);
+    launch_gemm_nt<T>(c, Kpp, ldp, V, ld, V, ld, P, P, npad, 0, nullptr);
     hipError_t e = hipMemcpy2DAsync(var_out, (size_t)P * sizeof(T), Kpp, (size_t)ldp * sizeof(T), (size_t)P * sizeof(T),
                                     (size_t)P, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -501,13 +620,38 @@ int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
         hipHostMalloc(&c->h_prog, sizeof(DevProgram)) != hipSuccess || hipMalloc(&c->d_info, sizeof(int)) != hipSuccess ||
         hipMalloc(&c->d_scal, 8 * sizeof(double)) != hipSuccess ||
         hipHostMalloc(&c->h_scal, 8 * sizeof(double)) != hipSuccess ||
-        hipMalloc(&c->d_queue, 64 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(c->d_queue, 0, 64 * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc(&c->d_queue, (64 + 4 * 1024) * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(c->d_queue, 0, (64 + 4 * 1024) * sizeof(unsigned long long)) != hipSuccess) {
         gpmi_ctx_destroy(c);
         return GPMI_EDEVICE;
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
+    // reserved CUs for the look-ahead panel stream: every s-th CU along a diagonal (i % s == (i / s) % s), which is
+    // balanced across the 8 XCDs whether the runtime numbers CUs XCD-major or XCD-interleaved
+    int want = 0;  // look-ahead is opt-in: measured neutral at N = 20000
+    if (const char* e = getenv("GPMI_PANEL_CUS")) want = atoi(e);
+    if (want > 0 && c->num_cus >= 64 && want * 2 <= c->num_cus) {
+        const int stride = c->num_cus / want;
+        std::vector<uint32_t> pm((size_t)(c->num_cus + 31) / 32, 0u), gm((size_t)(c->num_cus + 31) / 32, 0u);
+        int np = 0;
+        for (int i = 0; i < c->num_cus; ++i) {
+            const bool panel = stride > 0 && (i % stride) == ((i / stride) % stride);
+            (panel ? pm : gm)[(size_t)i / 32] |= 1u << (i % 32);
+            np += panel;
+        }
+        if (hipExtStreamCreateWithCUMask(&c->gemm_stream, (uint32_t)gm.size(), gm.data()) == hipSuccess &&
+            hipExtStreamCreateWithCUMask(&c->panel_stream, (uint32_t)pm.size(), pm.data()) == hipSuccess) {
+            c->panel_cus = np;
+        } else {
+            (void)hipGetLastError();
+            if (c->gemm_stream) hipStreamDestroy(c->gemm_stream);
+            if (c->panel_stream) hipStreamDestroy(c->panel_stream);
+            c->gemm_stream = c->panel_stream = nullptr;
+        }
+    }
+    if (const char* e = getenv("GPMI_GEMM_WGS")) c->gemm_wgs_per_cu = atoi(e) == 1 ? 1 : 2;
+    if (getenv("GPMI_DEBUG")) fprintf(stderr, "[gpmi] device %d: %d CUs, look-ahead panel CUs %d\n", dev, c->num_cus, c->panel_cus);
     *out = c;
     return GPMI_OK;
 }
@@ -521,6 +665,9 @@ void gpmi_ctx_destroy(gpmi_ctx* c) {
         hipEventDestroy(r.b);
     }
     for (auto e : c->ev_pool) hipEventDestroy(e);
+    for (auto e : c->la_events) hipEventDestroy(e);
+    if (c->gemm_stream) hipStreamDestroy(c->gemm_stream);
+    if (c->panel_stream) hipStreamDestroy(c->panel_stream);
     if (c->d_prog) hipFree(c->d_prog);
     if (c->h_prog) hipHostFree(c->h_prog);
     if (c->d_info) hipFree(c->d_info);
@@ -555,6 +702,7 @@ int gpmi_gp_create(gpmi_ctx* c, int dtype, int d, int64_t n, const void* x, gpmi
     if (e == hipSuccess) e = hipMalloc(&gp->alpha, (size_t)gp->npad * es);
     if (e == hipSuccess) e = hipMalloc(&gp->invdiag, (size_t)gp->npad * es);
     if (e == hipSuccess) e = hipMalloc(&gp->linv, (size_t)(gp->npad * IB) * es);
+    if (e == hipSuccess) e = hipMalloc(&gp->linv256, (size_t)((gp->npad + NB - 1) / NB * NB * NB) * es);
     if (e == hipSuccess) e = hipMemcpy(gp->x, x, (size_t)(n * d) * es, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset((char*)gp->A + (size_t)(gp->npad * gp->ld) * es, 0, (size_t)(8 * gp->ld) * es);
     if (e != hipSuccess) {
@@ -572,7 +720,7 @@ void gpmi_gp_destroy(gpmi_gp* gp) {
         hipSetDevice(gp->ctx->device);
         hipStreamSynchronize(gp->ctx->stream);
     }
-    void* ptrs[] = {gp->x, gp->A, gp->ymu, gp->alpha, gp->invdiag, gp->linv, gp->noise, gp->rows, gp->xp, gp->small,
+    void* ptrs[] = {gp->x, gp->A, gp->ymu, gp->alpha, gp->invdiag, gp->linv, gp->linv256, gp->noise, gp->rows, gp->xp, gp->small,
                     gp->g1, gp->g2, gp->gpart};
     for (void* p : ptrs)
         if (p) hipFree(p);

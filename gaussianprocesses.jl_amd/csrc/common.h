@@ -75,7 +75,14 @@ struct gpmi_ctx {
     double* h_scal = nullptr;            // pinned
     unsigned long long* d_queue = nullptr;  // 8 per-XCD tile-queue words, 64 B apart (never reset)
     unsigned long long queue_base[8] = {0}; // value of each word when the next launch starts
-    int num_cus = 256;
+    int gemm_wgs_per_cu = 2;             // tools: GPMI_GEMM_WGS=1 runs one workgroup per CU
+    int num_cus = 256;                   // CUs the persistent GEMM sizes its grid for on the CURRENT stream
+    // look-ahead Cholesky: the trailing update runs on gemm_stream (CU mask = chip minus panel_cus), the next panel's
+    // factorisation concurrently on panel_stream (CU mask = the panel_cus reserved CUs).  panel_cus == 0: serial.
+    hipStream_t gemm_stream = nullptr;
+    hipStream_t panel_stream = nullptr;
+    int panel_cus = 0;
+    std::vector<hipEvent_t> la_events;   // cross-stream dependencies, reused by every factorisation
     bool prof_on = false;
     std::vector<gpmi::ProfRec> prof;
     std::vector<hipEvent_t> ev_pool;
@@ -100,6 +107,7 @@ struct gpmi_gp {
     void* g2 = nullptr;      // gradient path: (K + noise)^-1, lower triangle (npad x ld)
     double* gpart = nullptr; // gradient path: per-block partial sums
     int64_t gpart_cap = 0;
+    void* linv256 = nullptr; // explicit inverses of the NB x NB diagonal blocks, ceil(npad / NB) x NB x NB (linv256_kernel)
     void* linv = nullptr;    // inverses of the 64 x 64 diagonal blocks, (npad / 64) x 64 x 64 (every later solve is a GEMM)
     double* noise = nullptr; // per-point nugget (heteroscedastic) or nullptr
     bool fitted = false;
@@ -183,6 +191,10 @@ template <typename T>
 void launch_bsolve_step(gpmi_ctx* ctx, const T* Arow, int64_t ld, int64_t j0, const T* linv, T* z, T* alpha);
 
 // mll / logdet / y'alpha  ->  out[0] = mll, out[1] = logdet, out[2] = y'alpha
+template <typename T>
+void launch_linv256(gpmi_ctx* ctx, const T* A, int64_t ld, const T* linv64, T* out, int64_t npad, const int* info);
+template <typename T>
+void launch_bsolve256(gpmi_ctx* ctx, const T* Arow, int64_t ld, int64_t k0, int nbk, const T* linv256, T* z, T* alpha);
 template <typename T>
 void launch_finalize(gpmi_ctx* ctx, const T* A, int64_t ld, int64_t n, const T* y, const T* alpha, double* out);
 

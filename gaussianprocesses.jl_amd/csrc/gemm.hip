@@ -87,6 +87,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
         return;
     }
 
+    // Co-residency (tools/slot_probe.hip, tools/gemm_phases.py): the two workgroups of a CU are (b, b + gridDim/2); the
+    // one in wave slot 0 wins the MFMA arbitration (oldest first) and runs its tiles at lone-workgroup speed (68 us at
+    // K = 256), the slot-1 workgroup fills the gaps (135 us per tile).  Anti-phasing the pair with a start delay and
+    // alternating s_setprio per slab were both measured neutral (43.5 TFLOP/s either way), so neither is done.
     const int lane = tid & 63;
     const int wv = tid >> 6;
     const int wm = wv >> 1, wn = wv & 1;
@@ -96,8 +100,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
     // fragment read offsets inside a row for the two k-halves: logical chunk 4h + g, swizzled by the row
     const int fo[2] = {((g) ^ (r16 & 7)) * E, ((4 + g) ^ (r16 & 7)) * E};
 
+    // VARIANT & 128 (tools only): wave 0 accumulates wall-clock ticks (100 MHz) per phase into queue[64 + 4 * blockIdx ...]
+    long long tk_pro = 0, tk_loop = 0, tk_epi = 0, tk_n = 0, tk0 = 0, tk1 = 0, tk2 = 0;
     bool first = true;
     for (;;) {
+        if constexpr (VARIANT & 128) tk0 = wall_clock64();
         int64_t t;
         if (first) {  // static first round
             first = false;
@@ -112,6 +119,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
             t = __builtin_amdgcn_readfirstlane((int)tl);  // scalar: the decode runs on the SALU
         }
         if (t >= cend) break;
+        if constexpr (VARIANT & 128) tk_n += 1;
         int ti, tj;
         tile_decode(t, shape, &ti, &tj);
         const int64_t m0 = (int64_t)ti * BM, n0 = (int64_t)tj * BN;
@@ -160,51 +168,74 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
         const int kbeg = (flags & GEMM_KSTART_ROW) ? (int)(m0 / BK) : 0;
         stage(kbeg & 1, kbeg * BK);
         __syncthreads();  // drains the DMA (vmcnt) and publishes the slab
+        if constexpr (VARIANT & 128) {
+            tk1 = wall_clock64();
+            tk_pro += tk1 - tk0;
+        }
 
         for (int kt = kbeg; kt < nk; ++kt) {
             const int cur = kt & 1;
-            if (kt + 1 < nk && !(VARIANT & 4)) stage(cur ^ 1, (kt + 1) * BK);
+            // All fragments of the slab go to registers FIRST, then the DMA of the next slab is issued, then the 256
+            // MFMAs run.  The compiler cannot tell the DMA's LDS writes (other buffer) from LDS reads and puts
+            // s_waitcnt vmcnt(0) in front of the first LDS read after a global_load_lds: with the reads interleaved
+            // into the MFMA stream (the natural order) every slab waited for the NEXT slab's DMA before computing —
+            // no load/compute overlap inside a workgroup (lone-workgroup K loop 2.9 us per slab against 2.08 us of
+            // MFMA).  In this order the only wait is the one the end-of-slab barrier needs anyway.
+            Vec af[2][4], bf[2][4];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                Vec af[4], bf[4];
                 if constexpr (VARIANT & 16) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
 #pragma unroll
                         for (int e = 0; e < E; ++e) {
-                            af[q][e] = T(1) + T(lane) * T(1e-3);
-                            bf[q][e] = T(0.5) + T(q) * T(1e-3);
+                            af[h][q][e] = T(1) + T(lane) * T(1e-3);
+                            bf[h][q][e] = T(0.5) + T(q) * T(1e-3);
                         }
-                        asm volatile("" : "+v"(af[q]), "+v"(bf[q]));
+                        asm volatile("" : "+v"(af[h][q]), "+v"(bf[h][q]));
                     }
                 } else {
                     const T* as = As0 + cur * BM * BK + (wm * 64 + r16) * BK + fo[h];
                     const T* bs = Bs0 + cur * BN * BK + (wn * 64 + r16) * BK + fo[h];
 #pragma unroll
-                    for (int mi = 0; mi < 4; ++mi) af[mi] = *reinterpret_cast<const Vec*>(as + mi * 16 * BK);
+                    for (int mi = 0; mi < 4; ++mi) af[h][mi] = *reinterpret_cast<const Vec*>(as + mi * 16 * BK);
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) bf[ni] = *reinterpret_cast<const Vec*>(bs + ni * 16 * BK);
+                    for (int ni = 0; ni < 4; ++ni) bf[h][ni] = *reinterpret_cast<const Vec*>(bs + ni * 16 * BK);
                 }
-                if constexpr (VARIANT & 32) __builtin_amdgcn_s_setprio(1);
+            }
+            if constexpr (!(VARIANT & 16)) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(af[h][q]), "+v"(bf[h][q]));  // reads stay above the DMA
+            }
+            if (kt + 1 < nk && !(VARIANT & 4)) stage(cur ^ 1, (kt + 1) * BK);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni) {
                         T br[4];
                         if constexpr (VARIANT & 8) {
-                            br[0] = br[1] = br[2] = br[3] = bf[ni][e];
+                            br[0] = br[1] = br[2] = br[3] = bf[h][ni][e];
                         } else {
-                            MF::rotations(bf[ni][e], br);
+                            MF::rotations(bf[h][ni][e], br);
                         }
 #pragma unroll
-                        for (int mi = 0; mi < 4; ++mi) MF::mma(af[mi][e], br, acc[mi][ni]);
+                        for (int mi = 0; mi < 4; ++mi) MF::mma(af[h][mi][e], br, acc[mi][ni]);
                     }
                 }
-                if constexpr (VARIANT & 32) __builtin_amdgcn_s_setprio(0);
             }
+            __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs above the barrier (they are what hides the DMA)
             __syncthreads();  // (a) next slab has landed for everyone  (b) everyone is done reading `cur`
         }
 
+        if constexpr (VARIANT & 128) {
+            tk2 = wall_clock64();
+            tk_loop += tk2 - tk1;
+        }
         // ---- epilogue: C -= acc --------------------------------------------------------------
         if constexpr (VARIANT & 2) {
             T sacc = T(0);
@@ -268,6 +299,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
                 }
             }
         }
+        if constexpr (VARIANT & 128) {
+            const long long tk3 = wall_clock64();
+            tk_epi += tk3 - tk2;
+            const int half = (int)(gridDim.x >> 1);
+            if (tid == 0 && tk_n <= 24 && (blockIdx.x == 40 || blockIdx.x == 40 + half)) {
+                unsigned long long* st = queue + 64 + 2048 + (blockIdx.x == 40 ? 0 : 96) + 4 * (tk_n - 1);
+                st[0] = (unsigned long long)tk0;
+                st[1] = (unsigned long long)tk1;
+                st[2] = (unsigned long long)tk2;
+                st[3] = (unsigned long long)tk3;
+            }
+        }
+    }
+    if constexpr (VARIANT & 128) {
+        if (tid == 0) {
+            unsigned long long* dbg = queue + 64 + 4 * blockIdx.x;
+            dbg[0] = (unsigned long long)tk_pro;
+            dbg[1] = (unsigned long long)tk_loop;
+            dbg[2] = (unsigned long long)tk_epi;
+            dbg[3] = (unsigned long long)tk_n;
+        }
     }
 }
 
@@ -299,7 +351,7 @@ static void launch_persistent(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int6
     shape.ntn = (int)((N + GEMM_BN - 1) / GEMM_BN);
     const int64_t ntiles = tile_count(shape);
     if (ntiles <= 0) return;
-    const int slots = 2 * ctx->num_cus;
+    const int slots = ctx->gemm_wgs_per_cu * ctx->num_cus;
     // small launches: one workgroup per tile (rounded up to a multiple of 8 so XCD chunks stay contiguous)
     const int grid = (int)std::min<int64_t>(slots, (ntiles + 7) / 8 * 8);
     QueueArgs qa;
@@ -357,13 +409,7 @@ static void launch_variant(gpmi_ctx* ctx, T* C, int64_t ld, const T* A, int64_t 
 template <typename T>
 int gemm_bench(gpmi_ctx* ctx, int64_t M, int64_t N, int64_t K, int lower, int variant, int iters, double* ms_out) {
     // operands: rows of a (M x ld) random matrix; C is its own buffer of the same shape
-    int64_t ld = ((std::max(N, K) + 63) / 64) * 64;
-    if (variant >= 64) {  // experiment: row stride = odd multiple of 256 B (spreads rows over all memory channels)
-        const int64_t q = 256 / sizeof(T);
-        ld = (ld + q - 1) / q * q;
-        if (((ld / q) & 1) == 0) ld += q;
-        variant -= 64;
-    }
+    const int64_t ld = ((std::max(N, K) + 63) / 64) * 64;
     T *A = nullptr, *C = nullptr;
     GPMI_HIP(ctx, hipMalloc(&A, (size_t)(M * ld) * sizeof(T)));
     GPMI_HIP(ctx, hipMalloc(&C, (size_t)(M * ld) * sizeof(T)));
@@ -389,7 +435,7 @@ int gemm_bench(gpmi_ctx* ctx, int64_t M, int64_t N, int64_t K, int lower, int va
             case 14: launch_variant<T, 14>(ctx, C, ld, A, M, N, K, lower); break;
             case 22: launch_variant<T, 22>(ctx, C, ld, A, M, N, K, lower); break;
             case 30: launch_variant<T, 30>(ctx, C, ld, A, M, N, K, lower); break;
-            case 32: launch_variant<T, 32>(ctx, C, ld, A, M, N, K, lower); break;
+            case 128: launch_variant<T, 128>(ctx, C, ld, A, M, N, K, lower); break;
 
             default: break;
         }
@@ -402,6 +448,31 @@ int gemm_bench(gpmi_ctx* ctx, int64_t M, int64_t N, int64_t K, int lower, int va
     float ms = 0.f;
     GPMI_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
     *ms_out = (double)ms / iters;
+    if (variant & 128) {  // per-phase wall-clock split of the last launch (100 MHz ticks), averaged over workgroups
+        std::vector<unsigned long long> dbg(4 * 512);
+        GPMI_HIP(ctx, hipMemcpy(dbg.data(), ctx->d_queue + 64, dbg.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double pro = 0, loop = 0, epi = 0, nt = 0;
+        for (int w = 0; w < 512; ++w) {
+            pro += (double)dbg[4 * w];
+            loop += (double)dbg[4 * w + 1];
+            epi += (double)dbg[4 * w + 2];
+            nt += (double)dbg[4 * w + 3];
+        }
+        {
+            std::vector<unsigned long long> st(192);
+            GPMI_HIP(ctx, hipMemcpy(st.data(), ctx->d_queue + 64 + 2048, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            const unsigned long long z = std::min(st[0], st[96]);
+            for (int w = 0; w < 2; ++w) {
+                fprintf(stderr, "[gemm timeline] WG %s (us: start/kloop/epi/end):", w ? "40+half" : "40");
+                for (int t = 0; t < 10; ++t)
+                    fprintf(stderr, " %.0f/%.0f/%.0f/%.0f", (st[96 * w + 4 * t] - z) * 0.01, (st[96 * w + 4 * t + 1] - z) * 0.01,
+                            (st[96 * w + 4 * t + 2] - z) * 0.01, (st[96 * w + 4 * t + 3] - z) * 0.01);
+                fprintf(stderr, "\n");
+            }
+        }
+        fprintf(stderr, "[gemm phases] tiles %.0f; per tile: pull+prologue %.2f us, K loop %.2f us, epilogue %.2f us; per WG total %.1f us\n",
+                nt, pro / nt * 0.01, loop / nt * 0.01, epi / nt * 0.01, (pro + loop + epi) / 512 * 0.01);
+    }
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     hipFree(A);

@@ -393,6 +393,163 @@ __global__ __launch_bounds__(256) void bsolve_step_kernel(const T* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// linv256: explicit inverse of every NB x NB diagonal block of the factor, assembled from the stored 64 x 64 inverses.
+// Workgroup (b, j) produces column block j of block b's inverse Out = L_bb^-1.  With Wt = Out' this is the whitening
+// recurrence applied to rows j of an identity:
+//     Wt[j][j] = Linv_j' ,   Wt[j][m] = -( sum_{t=j}^{m-1} Wt[j][t] L[m][t]' ) Linv_m'      (m > j)
+// run right-looking: as soon as Wt[j][t] exists its contribution to every later sum is accumulated (registers), so only
+// the current block lives in LDS.  All products are 64 x 64 x 64 on the matrix cores.  With the NB-inverse every later
+// triangular solve against the factor (predict whitening, back-substitution) is ONE product per NB columns.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void linv256_kernel(const T* __restrict__ A, int64_t ld, const T* __restrict__ linv64,
+                                                      T* __restrict__ out, int64_t npad, const int* __restrict__ info) {
+    if (info && *info != 0) return;
+    using MF = Mfma<T>;
+    using Acc = typename MF::Acc;
+    constexpr int LD = 65;
+    __shared__ T bufW[64 * LD];
+    __shared__ T bufL[64 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int b = blockIdx.x >> 2, j = blockIdx.x & 3;
+    const int64_t k0 = (int64_t)b * NB;
+    const int64_t rem = npad - k0;
+    const int nb = (int)((rem < NB ? rem : NB) / 64);
+    if (j >= nb) return;
+    T* O = out + (int64_t)b * NB * NB;  // row-major, leading dimension NB
+    const T* Lj = linv64 + (k0 / 64 + j) * 64 * 64;
+    for (int i = 0; i < j; ++i)
+        for (int e = tid; e < 64 * 64; e += 256) O[(int64_t)(i * 64 + (e >> 6)) * NB + j * 64 + (e & 63)] = T(0);
+    for (int e = tid; e < 64 * 64; e += 256) {
+        const int r = e >> 6, cc = e & 63;
+        const T v = Lj[e];
+        O[(int64_t)(j * 64 + r) * NB + j * 64 + cc] = v;
+        bufW[cc * LD + r] = v;  // Wt[j][j] = Linv_j'
+    }
+    Acc acc[3][2][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc_zero<T>(acc[t][mi][ni]);
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        if (m >= j && m < nb) {  // workgroup-uniform
+            if (m > j) {
+                {
+                    // Wt[j][m] = -(acc_m) Linv_m'
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int row = wm * 32 + mi * 16 + MF::row_of(lane, r), col = wn * 32 + ni * 16 + MF::col_of(lane, r);
+                                bufW[row * LD + col] = acc_get<T>(acc[m > 0 ? m - 1 : 0][mi][ni], r);
+                            }
+                    const T* Lm = linv64 + (k0 / 64 + m) * 64 * 64;
+                    for (int e = tid; e < 64 * 64; e += 256) bufL[(e >> 6) * LD + (e & 63)] = Lm[e];
+                    __syncthreads();
+                    Acc w[2][2];
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+                            acc_zero<T>(w[mi][ni]);
+                            mma16_nt<T>(w[mi][ni], bufW + (wm * 32 + mi * 16) * LD, LD, bufL + (wn * 32 + ni * 16) * LD, LD, 64, lane);
+                        }
+                    __syncthreads();
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int row = wm * 32 + mi * 16 + MF::row_of(lane, r), col = wn * 32 + ni * 16 + MF::col_of(lane, r);
+                                const T v = -acc_get<T>(w[mi][ni], r);
+                                bufW[row * LD + col] = v;                                          // Wt[j][m]
+                                O[(int64_t)(m * 64 + col) * NB + j * 64 + row] = v;               // Out[m][j] = Wt[j][m]'
+                            }
+                    __syncthreads();
+                }
+            }
+#pragma unroll
+            for (int i = m + 1; i < 4; ++i) {
+                if (i < nb) {
+                    const T* Lim = A + (k0 + i * 64) * ld + k0 + m * 64;
+                    for (int e = tid; e < 64 * 64; e += 256) bufL[(e >> 6) * LD + (e & 63)] = Lim[(int64_t)(e >> 6) * ld + (e & 63)];
+                    __syncthreads();
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+                            mma16_nt<T>(acc[i - 1][mi][ni], bufW + (wm * 32 + mi * 16) * LD, LD, bufL + (wn * 32 + ni * 16) * LD, LD, 64, lane);
+                    __syncthreads();
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bsolve256: one NB-block of the backward solve  L' alpha = z  through the block's explicit inverse:
+//   alpha_b = Linv_b' z_b   (every workgroup recomputes it: column-coalesced reads of the 512 KiB inverse from L2),
+//   z[j] -= sum_i L[k0+i][j] alpha_b[i]   on the workgroup's 256 columns left of the block.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void bsolve256_kernel(const T* __restrict__ Arow, int64_t ld, int64_t k0, int nbk,
+                                                         const T* __restrict__ Linv, T* __restrict__ z, T* __restrict__ alpha) {
+    __shared__ T sz[NB];
+    __shared__ T sal[NB];
+    __shared__ T part[4][NB];
+    const int tid = threadIdx.x, c = tid & (NB - 1), q = tid >> 8;  // column c, row quarter q (64 rows, 16 loads in flight)
+    if (tid < NB) sz[tid] = tid < nbk ? z[k0 + tid] : T(0);
+    __syncthreads();
+    const int r_lo = q * 64, r_hi = (r_lo + 64 < nbk) ? r_lo + 64 : nbk;
+    {
+        T s0 = T(0), s1 = T(0), s2 = T(0), s3 = T(0);
+        if (c < nbk && r_hi > c) {  // Linv[r][c] = 0 for r < c: quarters entirely above the diagonal are skipped
+            const T* col = Linv + c;
+#pragma unroll 4
+            for (int r = r_lo; r < r_hi; r += 4) {
+                s0 += col[(int64_t)r * NB] * sz[r];
+                s1 += col[(int64_t)(r + 1) * NB] * sz[r + 1];
+                s2 += col[(int64_t)(r + 2) * NB] * sz[r + 2];
+                s3 += col[(int64_t)(r + 3) * NB] * sz[r + 3];
+            }
+        }
+        part[q][c] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    if (tid < NB) {
+        const T a = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+        sal[tid] = a;
+        if (blockIdx.x == 0 && tid < nbk) alpha[k0 + tid] = a;
+    }
+    __syncthreads();
+    const int64_t j = (int64_t)blockIdx.x * NB + c;
+    {
+        T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
+        if (j < k0) {
+            const T* col = Arow + j;  // Arow = row k0 of the factor
+#pragma unroll 4
+            for (int i = r_lo; i < r_hi; i += 4) {
+                a0 += col[(int64_t)i * ld] * sal[i];
+                a1 += col[(int64_t)(i + 1) * ld] * sal[i + 1];
+                a2 += col[(int64_t)(i + 2) * ld] * sal[i + 2];
+                a3 += col[(int64_t)(i + 3) * ld] * sal[i + 3];
+            }
+        }
+        part[q][c] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    if (tid < NB && j < k0) z[j] -= (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+}
+
+// ---------------------------------------------------------------------------------------------
 // deterministic single-workgroup reductions (fixed stride order + fixed tree)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double block_sum_1024(double v, double* sh) {
@@ -509,6 +666,16 @@ void launch_bsolve_step(gpmi_ctx* ctx, const T* Arow, int64_t ld, int64_t j0, co
     hipLaunchKernelGGL(bsolve_step_kernel<T>, dim3(blocks), dim3(256), 0, ctx->stream, Arow, ld, j0, linv, z, alpha);
 }
 template <typename T>
+void launch_linv256(gpmi_ctx* ctx, const T* A, int64_t ld, const T* linv64, T* out, int64_t npad, const int* info) {
+    const unsigned nblk = (unsigned)((npad + NB - 1) / NB);
+    hipLaunchKernelGGL(linv256_kernel<T>, dim3(4 * nblk), dim3(256), 0, ctx->stream, A, ld, linv64, out, npad, info);
+}
+template <typename T>
+void launch_bsolve256(gpmi_ctx* ctx, const T* Arow, int64_t ld, int64_t k0, int nbk, const T* linv256, T* z, T* alpha) {
+    const unsigned blocks = (unsigned)(k0 > 0 ? (k0 + 255) / 256 : 1);
+    hipLaunchKernelGGL(bsolve256_kernel<T>, dim3(blocks), dim3(1024), 0, ctx->stream, Arow, ld, k0, nbk, linv256, z, alpha);
+}
+template <typename T>
 void launch_finalize(gpmi_ctx* ctx, const T* A, int64_t ld, int64_t n, const T* y, const T* alpha, double* out) {
     hipLaunchKernelGGL(finalize_kernel<T>, dim3(1), dim3(1024), 0, ctx->stream, A, ld, n, y, alpha, out);
 }
@@ -535,6 +702,8 @@ void launch_logdiag(gpmi_ctx* ctx, const T* A, int64_t ld, int64_t nrows, int64_
                                    const int*);                                                                   \
     template void launch_trsm_rows<T>(gpmi_ctx*, T*, int64_t, const T*, int64_t, const T*, int64_t, const int*);  \
     template void launch_bsolve_step<T>(gpmi_ctx*, const T*, int64_t, int64_t, const T*, T*, T*);                 \
+    template void launch_linv256<T>(gpmi_ctx*, const T*, int64_t, const T*, T*, int64_t, const int*);             \
+    template void launch_bsolve256<T>(gpmi_ctx*, const T*, int64_t, int64_t, int, const T*, T*, T*);              \
     template void launch_finalize<T>(gpmi_ctx*, const T*, int64_t, int64_t, const T*, const T*, double*);         \
     template void launch_row_gemv<T>(gpmi_ctx*, const T*, int64_t, int64_t, int64_t, const T*, const T*, T*);     \
     template void launch_row_var<T>(gpmi_ctx*, const T*, int64_t, int64_t, int64_t, double, T*);                  \
