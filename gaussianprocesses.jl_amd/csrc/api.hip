@@ -284,14 +284,17 @@ static hipEvent_t la_event(gpmi_ctx* c, size_t i) {
 
 // blocked right-looking Cholesky, lower, in place; rows npad .. npad+extra-1 are carried along (forward solve for free).
 //
-// Look-ahead (panel_cus > 0): the serial part of panel k+1 — the diag64 / rows64 chain on its 256 x 256 diagonal block,
-// one to three workgroups per launch — runs on panel_stream (a handful of reserved CUs, hipExtStreamCreateWithCUMask)
-// while the trailing update by panel k occupies the rest of the chip on gemm_stream.  For that the update is split into
-// the NB columns the next panel needs (narrow, first) and the rest (wide).
+// Look-ahead: the serial part of panel k+1 — the diag64 / rows64 chain on its 256 x 256 diagonal block, one to three
+// workgroups per launch, ~150 us — runs on a second (high-priority) stream UNDER the trailing update by panel k.
+// For that the update is split by tiles, not by columns: the three 128 x 128 tiles of the next diagonal block go first
+// on the side stream (a 3-workgroup launch), everything else is one persistent launch on the main stream whose grid
+// leaves `lookahead_slots` workgroup slots of the chip free, which is where the side stream's small kernels land.
+// (Two measured dead ends, tools/cumask_probe.hip + profiles/: splitting off the next panel's 256 COLUMNS costs a
+// single-round GEMM launch as long as the chain it hides; CU-masked streams work but cost the GEMM 4 % for 8 CUs.)
 template <typename T>
 static void cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, int64_t npad, int64_t extra, int* d_info) {
     const int64_t Mtot = npad + extra;
-    if (c->panel_cus <= 0 || npad <= 4 * NB) {
+    if (c->lookahead_slots <= 0 || !c->side_stream || npad <= 4 * NB) {
         for (int64_t k0 = 0; k0 < npad; k0 += NB) {
             const int64_t nbk = std::min<int64_t>(NB, npad - k0);
             const int64_t kend = k0 + nbk;
@@ -303,44 +306,45 @@ static void cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, i
         }
         return;
     }
-    hipStream_t user = c->stream, gs = c->gemm_stream, ps = c->panel_stream;
-    const int gemm_cus = c->num_cus - c->panel_cus;
+    hipStream_t main_s = c->stream, side = c->side_stream;
     size_t ne = 0;
-    hipEvent_t e0 = la_event(c, ne++);
-    (void)hipEventRecord(e0, user);
-    (void)hipStreamWaitEvent(gs, e0, 0);
-    StreamScope main_scope(c, gs, gemm_cus);
-    {
-        const int64_t nb0 = std::min<int64_t>(NB, npad);
-        factor_panel_diag<T>(c, A, ld, linv, invdiag, 0, nb0, d_info);
-        factor_panel_below<T>(c, A, ld, linv, 0, nb0, Mtot, d_info);
-    }
+    bool panel_done = false;  // is panel k0 already factored (by the look-ahead of the previous step)?
     for (int64_t k0 = 0; k0 < npad; k0 += NB) {
         const int64_t nbk = std::min<int64_t>(NB, npad - k0);
         const int64_t k1 = k0 + nbk;
+        if (!panel_done) factor_panel<T>(c, A, ld, linv, invdiag, k0, nbk, Mtot, d_info);
+        panel_done = false;
         if (k1 >= npad) break;
         const int64_t nb1 = std::min<int64_t>(NB, npad - k1);
         const int64_t k2 = k1 + nb1;
-        // narrow: block column k1, every row below (the carried rows included)
-        launch_gemm_nt<T>(c, A + k1 * ld + k1, ld, A + k1 * ld + k0, ld, A + k1 * ld + k0, ld, Mtot - k1, nb1, nbk, 0, d_info);
-        hipEvent_t en = la_event(c, ne++);
-        (void)hipEventRecord(en, gs);
-        (void)hipStreamWaitEvent(ps, en, 0);
+        // the chain takes ~0.4 ms beside the update (contended CUs): look ahead only while the update is longer
+        if (npad - k2 < c->lookahead_min_trailing) {
+            launch_gemm_nt<T>(c, A + k1 * ld + k1, ld, A + k1 * ld + k0, ld, A + k1 * ld + k0, ld, Mtot - k1, npad - k1, nbk, 1,
+                              d_info);
+            continue;
+        }
+        hipEvent_t eb = la_event(c, ne++);  // panel k complete
+        (void)hipEventRecord(eb, main_s);
+        (void)hipStreamWaitEvent(side, eb, 0);
         {
-            StreamScope sc(c, ps, c->panel_cus);
+            StreamScope sc(c, side, c->num_cus);
+            // the next diagonal block's own tiles, then its factorisation chain
+            launch_gemm_shape<T>(c, A + k1 * ld + k1, ld, A + k1 * ld + k0, ld, A + k1 * ld + k0, ld, nb1, nb1, nbk,
+                                 TileShape{0, 0, 1, 0, 1, 0}, d_info, GEMM_AUX);
             factor_panel_diag<T>(c, A, ld, linv, invdiag, k1, nb1, d_info);
         }
-        hipEvent_t ep = la_event(c, ne++);
-        (void)hipEventRecord(ep, ps);
-        if (k2 < npad)  // wide: everything right of the next panel
-            launch_gemm_nt<T>(c, A + k2 * ld + k2, ld, A + k2 * ld + k0, ld, A + k2 * ld + k0, ld, Mtot - k2, npad - k2, nbk, 1,
-                              d_info);
-        (void)hipStreamWaitEvent(gs, ep, 0);
+        hipEvent_t ec = la_event(c, ne++);
+        (void)hipEventRecord(ec, side);
+        // everything below the next diagonal block: rows k2.., columns k1.. up to each row tile's diagonal tile
+        // (lower mode with offset: row tile ti keeps column tiles <= ti + 2)
+        c->gemm_reserve = c->lookahead_slots;
+        launch_gemm_shape<T>(c, A + k2 * ld + k1, ld, A + k2 * ld + k0, ld, A + k1 * ld + k0, ld, Mtot - k2, npad - k1, nbk,
+                             TileShape{0, 0, 1, 2, 1, 0}, d_info, 0);
+        c->gemm_reserve = 0;
+        (void)hipStreamWaitEvent(main_s, ec, 0);
         factor_panel_below<T>(c, A, ld, linv, k1, nb1, Mtot, d_info);
+        panel_done = true;
     }
-    hipEvent_t ed = la_event(c, ne++);
-    (void)hipEventRecord(ed, gs);
-    (void)hipStreamWaitEvent(user, ed, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -627,31 +631,21 @@ int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
-    // reserved CUs for the look-ahead panel stream: every s-th CU along a diagonal (i % s == (i / s) % s), which is
-    // balanced across the 8 XCDs whether the runtime numbers CUs XCD-major or XCD-interleaved
-    int want = 0;  // look-ahead is opt-in: measured neutral at N = 20000
-    if (const char* e = getenv("GPMI_PANEL_CUS")) want = atoi(e);
-    if (want > 0 && c->num_cus >= 64 && want * 2 <= c->num_cus) {
-        const int stride = c->num_cus / want;
-        std::vector<uint32_t> pm((size_t)(c->num_cus + 31) / 32, 0u), gm((size_t)(c->num_cus + 31) / 32, 0u);
-        int np = 0;
-        for (int i = 0; i < c->num_cus; ++i) {
-            const bool panel = stride > 0 && (i % stride) == ((i / stride) % stride);
-            (panel ? pm : gm)[(size_t)i / 32] |= 1u << (i % 32);
-            np += panel;
-        }
-        if (hipExtStreamCreateWithCUMask(&c->gemm_stream, (uint32_t)gm.size(), gm.data()) == hipSuccess &&
-            hipExtStreamCreateWithCUMask(&c->panel_stream, (uint32_t)pm.size(), pm.data()) == hipSuccess) {
-            c->panel_cus = np;
-        } else {
+    // look-ahead Cholesky: a high-priority side stream for the next panel's serial chain, and how many of the chip's
+    // workgroup slots the main trailing-update launch leaves free for it (GPMI_LOOKAHEAD=0 switches it off)
+    {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = greatest priority (numerically lowest)
+        if (hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, hi) != hipSuccess) {
             (void)hipGetLastError();
-            if (c->gemm_stream) hipStreamDestroy(c->gemm_stream);
-            if (c->panel_stream) hipStreamDestroy(c->panel_stream);
-            c->gemm_stream = c->panel_stream = nullptr;
+            c->side_stream = nullptr;
         }
+        c->lookahead_slots = 8;
+        if (const char* e = getenv("GPMI_LOOKAHEAD")) c->lookahead_slots = atoi(e) / 8 * 8;
+        if (const char* e = getenv("GPMI_LOOKAHEAD_MIN")) c->lookahead_min_trailing = atoll(e);
     }
     if (const char* e = getenv("GPMI_GEMM_WGS")) c->gemm_wgs_per_cu = atoi(e) == 1 ? 1 : 2;
-    if (getenv("GPMI_DEBUG")) fprintf(stderr, "[gpmi] device %d: %d CUs, look-ahead panel CUs %d\n", dev, c->num_cus, c->panel_cus);
+    if (getenv("GPMI_DEBUG")) fprintf(stderr, "[gpmi] device %d: %d CUs, look-ahead slots %d\n", dev, c->num_cus, c->lookahead_slots);
     *out = c;
     return GPMI_OK;
 }
@@ -666,8 +660,7 @@ void gpmi_ctx_destroy(gpmi_ctx* c) {
     }
     for (auto e : c->ev_pool) hipEventDestroy(e);
     for (auto e : c->la_events) hipEventDestroy(e);
-    if (c->gemm_stream) hipStreamDestroy(c->gemm_stream);
-    if (c->panel_stream) hipStreamDestroy(c->panel_stream);
+    if (c->side_stream) hipStreamDestroy(c->side_stream);
     if (c->d_prog) hipFree(c->d_prog);
     if (c->h_prog) hipHostFree(c->h_prog);
     if (c->d_info) hipFree(c->d_info);

@@ -77,11 +77,12 @@ struct gpmi_ctx {
     unsigned long long queue_base[8] = {0}; // value of each word when the next launch starts
     int gemm_wgs_per_cu = 2;             // tools: GPMI_GEMM_WGS=1 runs one workgroup per CU
     int num_cus = 256;                   // CUs the persistent GEMM sizes its grid for on the CURRENT stream
-    // look-ahead Cholesky: the trailing update runs on gemm_stream (CU mask = chip minus panel_cus), the next panel's
-    // factorisation concurrently on panel_stream (CU mask = the panel_cus reserved CUs).  panel_cus == 0: serial.
-    hipStream_t gemm_stream = nullptr;
-    hipStream_t panel_stream = nullptr;
-    int panel_cus = 0;
+    // look-ahead Cholesky (api.hip: cholesky_lower): the next panel's serial chain runs on side_stream under the
+    // trailing update, which leaves lookahead_slots workgroup slots free (gemm_reserve is set around that launch)
+    hipStream_t side_stream = nullptr;
+    int lookahead_slots = 0;
+    int64_t lookahead_min_trailing = 4608;  // trailing size below which the serial order is faster (update < chain)
+    int gemm_reserve = 0;
     std::vector<hipEvent_t> la_events;   // cross-stream dependencies, reused by every factorisation
     bool prof_on = false;
     std::vector<gpmi::ProfRec> prof;
@@ -164,7 +165,8 @@ void launch_gemm_nt(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, c
 template <typename T>
 void launch_gemm_shape(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M,
                        int64_t N, int64_t K, TileShape shape, const int* info, int flags = 0);
-enum GemmFlags { GEMM_OVERWRITE = 1 /* C = A B' instead of C -= A B' */, GEMM_KSTART_ROW = 2 /* A[i][k] = 0 for k < i: start K at the tile's first row */ };
+enum GemmFlags { GEMM_OVERWRITE = 1 /* C = A B' instead of C -= A B' */, GEMM_KSTART_ROW = 2 /* A[i][k] = 0 for k < i: start K at the tile's first row */,
+                 GEMM_AUX = 4 /* no effect on the kernel: account the launch to the panel class, not to the trailing update */ };
 
 // in-place Cholesky of the 64 x 64 block at A (row-major, ld): lower factor, upper part zeroed; linv (64 x 64,
 // row-major, ld 64) receives L^-1 and invdiag[0..64) 1 / L_jj.  On a non-positive pivot j (0-based) writes

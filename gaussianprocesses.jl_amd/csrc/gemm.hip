@@ -91,6 +91,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
     // one in wave slot 0 wins the MFMA arbitration (oldest first) and runs its tiles at lone-workgroup speed (68 us at
     // K = 256), the slot-1 workgroup fills the gaps (135 us per tile).  Anti-phasing the pair with a start delay and
     // alternating s_setprio per slab were both measured neutral (43.5 TFLOP/s either way), so neither is done.
+    if (flags & GEMM_AUX) __builtin_amdgcn_s_setprio(2);  // critical-path side launch next to the persistent update
+
     const int lane = tid & 63;
     const int wv = tid >> 6;
     const int wm = wv >> 1, wn = wv & 1;
@@ -351,7 +353,7 @@ static void launch_persistent(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int6
     shape.ntn = (int)((N + GEMM_BN - 1) / GEMM_BN);
     const int64_t ntiles = tile_count(shape);
     if (ntiles <= 0) return;
-    const int slots = ctx->gemm_wgs_per_cu * ctx->num_cus;
+    const int slots = ctx->gemm_wgs_per_cu * ctx->num_cus - ctx->gemm_reserve;  // both multiples of 8
     // small launches: one workgroup per tile (rounded up to a multiple of 8 so XCD chunks stay contiguous)
     const int grid = (int)std::min<int64_t>(slots, (ntiles + 7) / 8 * 8);
     QueueArgs qa;
@@ -369,7 +371,11 @@ static void launch_persistent(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int6
 
 static double shape_entries(int64_t M, int64_t N, const TileShape& s) {
     if (s.mode == 0) return (double)M * (double)N;
-    if (s.mode == 1) return 0.5 * (double)N * ((double)N + 1.0) + (double)(M - N) * (double)N;
+    if (s.mode == 1) {  // row i keeps columns j <= i + 128 * g0
+        const double off = (double)s.g0 * GEMM_BN;
+        const double tri_rows = std::max(0.0, std::min((double)M, (double)N - off));  // rows still under the diagonal
+        return tri_rows * (off + 0.5 * (tri_rows + 1.0)) + ((double)M - tri_rows) * (double)N;
+    }
     TileShape t = s;  // staircase: count whole tiles
     t.ntm = (int)((M + GEMM_BM - 1) / GEMM_BM);
     t.ntn = (int)((N + GEMM_BN - 1) / GEMM_BN);

@@ -69,9 +69,16 @@ __device__ __forceinline__ void store16(const typename Mfma<T>::Acc& acc, T* C, 
 //      cores (16 tiny products, LDS-resident operands);
 // so that every later solve against this block (panel TRSM, whiten!, back-substitution) is a GEMM.
 template <typename T>
-__global__ __launch_bounds__(64) void diag64_kernel(T* __restrict__ A, int64_t ld, T* __restrict__ Linv,
+__global__ __launch_bounds__(256, 2) void diag64_kernel(T* __restrict__ A, int64_t ld, T* __restrict__ Linv,
                                                     T* __restrict__ invdiag, int* __restrict__ info, int64_t pivot_base) {
+    // Launched with 256 threads of which only wave 0 works: __launch_bounds__(256, 2) is what caps the kernel at 256
+    // registers (with a 64-thread bound the 77 KiB of LDS already limits occupancy and the compiler takes 282), and
+    // under look-ahead the wave must fit beside a 248-register GEMM wave on its SIMD.
+    if (threadIdx.x >= 64) return;
     if (*info != 0) return;
+    // Under look-ahead this wave shares a SIMD with two GEMM waves that always have an MFMA ready; instruction
+    // arbitration is oldest-first, so without a raised priority the chain crawls (measured: 2 ms instead of 25 us).
+    __builtin_amdgcn_s_setprio(3);
     constexpr int SLD = 65;
     __shared__ T S[64 * SLD];    // L, row-major
     __shared__ T XT[64 * SLD];   // XT[n][k] = Linv[k][n]
@@ -199,6 +206,7 @@ __global__ __launch_bounds__(256, 2) void rows64_kernel(T* __restrict__ Xp, int6
                                                      const T* __restrict__ Lp, int64_t ldl, const T* __restrict__ Linv,
                                                      int64_t diag_rows, const int* __restrict__ info) {
     if (info && *info != 0) return;
+    __builtin_amdgcn_s_setprio(3);  // see diag64_kernel
     using MF = Mfma<T>;
     using Acc = typename MF::Acc;
     constexpr int LD = 65;
@@ -642,7 +650,7 @@ __global__ __launch_bounds__(256) void row_var_kernel(const T* __restrict__ R, i
 template <typename T>
 void launch_diag64(gpmi_ctx* ctx, T* A, int64_t ld, T* linv, T* invdiag, int* info, int64_t pivot_base) {
     ProfScope ps(ctx, GPMI_PROF_PANEL, 2.0 * 64.0 * 64.0 * 64.0 / 3.0);
-    hipLaunchKernelGGL(diag64_kernel<T>, dim3(1), dim3(64), 0, ctx->stream, A, ld, linv, invdiag, info, pivot_base);
+    hipLaunchKernelGGL(diag64_kernel<T>, dim3(1), dim3(256), 0, ctx->stream, A, ld, linv, invdiag, info, pivot_base);
 }
 template <typename T>
 void launch_rows64(gpmi_ctx* ctx, T* Xp, int64_t ldx, int64_t M, int K1, const T* Lp, int64_t ldl, const T* linv,

@@ -5,11 +5,11 @@
 // Which tiles exist is described by TileShape:
 //   ntm x ntn tile grid; row ti keeps columns tj <= cmax(ti) where
 //     mode 0 (rectangle)   cmax = ntn - 1
-//     mode 1 (lower)       cmax = ti                    (C is a trailing square, single GPU)
+//     mode 1 (lower)       cmax = ti + g0               (C is a trailing square, single GPU; g0 > 0: the block
+//                                                       starts g0 tile-rows below the square's top)
 //     mode 2 (staircase)   cmax = 2*(g0 + (ti>>1)*G) + (ti&1) for ti < nstair, ntn - 1 beyond
 //                          (row-block-cyclic shard: local 256-row block i is global block g0 + i*G;
 //                           two 128-row tiles per block; rows past the staircase are carried rows)
-//   (mode 1 is mode 2 with g0 = 0, G = 1, nstair = ntm.)
 // Order: strips of GROUP tile-rows.  Modes 0/1: column-major inside a strip, so GROUP consecutive
 // tiles share one B panel and the strip's GROUP A panels stay hot.  Mode 2: row-major inside a strip.
 #pragma once
@@ -48,10 +48,11 @@ GPMI_HD int64_t strip_count(int st, const TileShape& s) {
         for (int i = 0; i < h; ++i) c += stair_cmax(s, r0 + i) + 1;
         return c;
     }
-    const int nfull = (r0 + 1 < s.ntn) ? (r0 + 1) : s.ntn;
+    const int off = s.g0;
+    const int nfull = (r0 + off + 1 < s.ntn) ? (r0 + off + 1) : s.ntn;
     int64_t c = (int64_t)h * nfull;
-    const int jmax = (r0 + h - 1 < s.ntn - 1) ? (r0 + h - 1) : (s.ntn - 1);
-    for (int tj = r0 + 1; tj <= jmax; ++tj) c += r0 + h - tj;
+    const int jmax = (r0 + h - 1 + off < s.ntn - 1) ? (r0 + h - 1 + off) : (s.ntn - 1);
+    for (int tj = nfull; tj <= jmax; ++tj) c += r0 + h - (tj - off);
     return c;
 }
 
@@ -88,18 +89,19 @@ GPMI_HD void tile_decode(int64_t t, const TileShape& s, int* ti, int* tj) {
             t -= n;
         }
     }
-    const int nfull = (r0 + 1 < s.ntn) ? (r0 + 1) : s.ntn;
+    const int off = s.g0;
+    const int nfull = (r0 + off + 1 < s.ntn) ? (r0 + off + 1) : s.ntn;
     if (t < (int64_t)h * nfull) {
         *tj = (int)(t / h);
         *ti = r0 + (int)(t % h);
         return;
     }
     int q = (int)(t - (int64_t)h * nfull);
-    for (int c = r0 + 1;; ++c) {
-        const int n = r0 + h - c;
+    for (int c = nfull;; ++c) {
+        const int n = r0 + h - (c - off);
         if (q < n) {
             *tj = c;
-            *ti = c + q;
+            *ti = c - off + q;
             return;
         }
         q -= n;

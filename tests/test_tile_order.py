@@ -17,7 +17,7 @@ static int check(const TileShape& s) {
     for (int i = 0; i < s.ntm; ++i)
         for (int j = 0; j < s.ntn; ++j) {
             bool ok = true;
-            if (s.mode == 1) ok = j <= i;
+            if (s.mode == 1) ok = j <= i + s.g0;
             if (s.mode == 2 && i < s.nstair) ok = j <= 2 * (s.g0 + (i >> 1) * s.G) + (i & 1);
             if (ok) want.insert({i, j});
         }
@@ -31,6 +31,10 @@ int main() {
     for (int mode = 0; mode <= 1; ++mode)
         for (int ntm = 1; ntm <= 41; ++ntm)
             for (int ntn = 1; ntn <= (mode ? ntm : 41); ++ntn) { ++cases; bad += check(TileShape{ntm, ntn, mode, 0, 1, 0}); }
+    // lower mode with a row offset (the look-ahead update: the block starts `off` tile-rows below the square's top)
+    for (int off = 1; off <= 3; ++off)
+        for (int ntm = 1; ntm <= 30; ++ntm)
+            for (int ntn = 1; ntn <= ntm + off; ++ntn) { ++cases; bad += check(TileShape{ntm, ntn, 1, off, 1, 0}); }
     // staircase (row-block-cyclic shards): G ranks, first owned block g0, carried rows past the staircase
     for (int G = 1; G <= 4; ++G)
         for (int g0 = 0; g0 < G + 2; ++g0)
