@@ -37,6 +37,23 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (v_mfma_f64_16x16x4_f64): 25
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: Peak FP32 (matrix)
 
 
+def _pmc_traffic(args, n, d, p):
+    """HBM bytes per launch of the roofline kernel.  PMC counters cannot be read from inside the timed process, so the
+    number comes from the committed summary of the separate rocprofv3 --pmc passes over THIS command
+    (tools/gpu_pmc_bench.sh -> profiles/r01_bench_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE in their own passes, the
+    gfx950 x2 read correction of MI355X_MICROARCH.md applied).  It only applies to the default workload; anything
+    else reports null."""
+    path = os.path.join(ROOT, "profiles", "r01_bench_pmc_hbm.json")
+    default = (n, d, p, args.dtype) == (20000, 8, 1024, "f64")
+    if not default or not os.path.exists(path):
+        return {"traffic": None}
+    try:
+        j = json.load(open(path))
+        return {"traffic": j["traffic_bytes_per_launch"], "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_bench_pmc_hbm.json)"}
+    except Exception:
+        return {"traffic": None}
+
+
 def synthetic_inputs(n, d, p, seed=20240501):
     """SURVEY.md §8(d) inputs (same generator as oracle.gp_oracle.synthetic_inputs)."""
     rng = np.random.default_rng(seed)
@@ -123,10 +140,12 @@ def _main_json(args, world, elapsed, gp, n, d, p, fl_syrk, ms_syrk, n_syrk, ms_c
             "peak": peak,
             "unit": "TFLOP/s",
             "frac": achieved / peak,
-            "traffic": None,
+            **_pmc_traffic(args, n, d, p),
             "launches": n_syrk,
             "avg_launch_ms": ms_syrk / max(n_syrk, 1),
             "algorithmic_flops_per_launch": fl_syrk / max(n_syrk, 1),
+            # C tile read + write (8 B each) per 2 * 256 flops of an entry; the 256-column panel itself is read once
+            "algorithmic_bytes_per_launch": fl_syrk / max(n_syrk, 1) / (2.0 * 256.0) * 2 * (8 if args.dtype == "f64" else 4),
         },
         "stage_ms_per_step": {
             "cov": ms_cov / args.steps,

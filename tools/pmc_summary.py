@@ -1,0 +1,29 @@
+"""Per-launch HBM traffic of the trailing-update kernel from the two --pmc passes of tools/gpu_pmc_bench.sh.
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB; on gfx950 FETCH_SIZE counts 128-B read requests at 64 B
+(MI355X_MICROARCH.md, HBM section), so reads are doubled.  Prints one JSON object."""
+import csv
+import glob
+import json
+import os
+import sys
+
+root = sys.argv[1]
+KERNEL = "gemm_nt_kernel<double, 0>"
+out = {"kernel": KERNEL, "command": "python bench.py --steps 2 --warmup 1 --no-cpu-baseline", "units": "bytes per launch"}
+for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    vals = {}
+    for f in glob.glob(os.path.join(root, counter, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if KERNEL in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                key = row.get("Dispatch_Id")
+                vals[key] = vals.get(key, 0.0) + float(row["Counter_Value"])
+    n = len(vals)
+    out[counter + "_launches"] = n
+    out[counter + "_KiB_avg"] = (sum(vals.values()) / n) if n else None
+if out.get("FETCH_SIZE_KiB_avg") and out.get("WRITE_SIZE_KiB_avg"):
+    rd = 2.0 * out["FETCH_SIZE_KiB_avg"] * 1024.0
+    wr = out["WRITE_SIZE_KiB_avg"] * 1024.0
+    out["read_bytes_corrected"] = rd
+    out["write_bytes"] = wr
+    out["traffic_bytes_per_launch"] = rd + wr
+print(json.dumps(out))
