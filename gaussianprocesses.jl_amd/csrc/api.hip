@@ -199,20 +199,78 @@ static void rows_block_solve(gpmi_ctx* c, const T* A, int64_t ld, const T* linv,
         launch_gemm_nt<T>(c, R + kend, ldr, R + k0, ldr, A + kend * ld + k0, ld, Mr, npad - kend, nbk, 0, nullptr);
 }
 
+// run launches on another stream of the context (the launchers read ctx->stream / ctx->num_cus)
+struct StreamScope {
+    gpmi_ctx* c;
+    hipStream_t s0;
+    int cus0;
+    StreamScope(gpmi_ctx* ctx, hipStream_t s, int cus) : c(ctx), s0(ctx->stream), cus0(ctx->num_cus) {
+        c->stream = s;
+        c->num_cus = cus;
+    }
+    ~StreamScope() {
+        c->stream = s0;
+        c->num_cus = cus0;
+    }
+};
+static hipEvent_t la_event(gpmi_ctx* c, size_t i) {
+    while (c->la_events.size() <= i) {
+        hipEvent_t e;
+        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        c->la_events.push_back(e);
+    }
+    return c->la_events[i];
+}
+
 // The same whitening through the explicit NB x NB inverses, out of place: V <- R L^-T with one product per NB columns
 //   V[:, k0:kend] = R[:, k0:kend] * Linv_k' ;  R[:, kend:npad] -= V[:, k0:kend] * A[kend:npad, k0:kend]'
 // (R is consumed).  Out of place because the two 128-column tiles of a block read each other's input columns.
 // rows_upto(kend) gives the number of leading rows that can be non-zero up to column kend (identity right-hand sides).
+//
+// Look-ahead, as in cholesky_lower: the product against the inverse is a one-round launch (<= 16 tiles, ~55 us) on the
+// critical path of every block.  While the update by block k is long enough, the NEXT block's columns are updated and
+// solved on the side stream (two small high-priority launches) under the rest of the update.
 template <typename T, typename F>
 static void whiten_rows_inv(gpmi_ctx* c, const T* A, int64_t ld, const T* linv256, int64_t npad, T* R, int64_t ldr, T* V,
                             int64_t ldv, F rows_upto) {
+    const TileShape rect{0, 0, 0, 0, 1, 0};
+    const bool la = c->lookahead_slots > 0 && c->side_stream;
+    hipStream_t main_s = c->stream, side = c->side_stream;
+    size_t ne = 0;
+    bool solved = false;  // is V[:, k0:kend] already there (done by the look-ahead of the previous block)?
     for (int64_t k0 = 0; k0 < npad; k0 += NB) {
-        const int64_t nbk = std::min<int64_t>(NB, npad - k0), kend = k0 + nbk;
-        const int64_t Mr = rows_upto(kend);
-        launch_gemm_shape<T>(c, V + k0, ldv, R + k0, ldr, linv256 + (k0 / NB) * NB * NB, NB, Mr, nbk, nbk,
-                             TileShape{0, 0, 0, 0, 1, 0}, nullptr, GEMM_OVERWRITE);
-        if (kend < npad)
-            launch_gemm_nt<T>(c, R + kend, ldr, V + k0, ldv, A + kend * ld + k0, ld, Mr, npad - kend, nbk, 0, nullptr);
+        const int64_t nbk = std::min<int64_t>(NB, npad - k0), k1 = k0 + nbk;
+        const int64_t Mr = rows_upto(k1);
+        if (!solved)
+            launch_gemm_shape<T>(c, V + k0, ldv, R + k0, ldr, linv256 + (k0 / NB) * NB * NB, NB, Mr, nbk, nbk, rect, nullptr,
+                                 GEMM_OVERWRITE);
+        solved = false;
+        if (k1 >= npad) break;
+        const int64_t nb1 = std::min<int64_t>(NB, npad - k1), k2 = k1 + nb1;
+        const int64_t Mr1 = rows_upto(k2);  // rows the next block's solve covers (>= Mr)
+        // worth it while the rest of the update outlasts the solve it hides (~60 us at 45 TFLOP/s), and only when the
+        // next solve needs no rows the update does not already carry
+        const bool ahead = la && k2 < npad && Mr1 == Mr && (double)Mr * (double)(npad - k2) > 5.3e6;
+        if (!ahead) {
+            launch_gemm_nt<T>(c, R + k1, ldr, V + k0, ldv, A + k1 * ld + k0, ld, Mr, npad - k1, nbk, 0, nullptr);
+            continue;
+        }
+        hipEvent_t ev = la_event(c, ne++);  // V_k complete, R current up to block k - 1
+        (void)hipEventRecord(ev, main_s);
+        (void)hipStreamWaitEvent(side, ev, 0);
+        {
+            StreamScope sc(c, side, c->num_cus);
+            launch_gemm_shape<T>(c, R + k1, ldr, V + k0, ldv, A + k1 * ld + k0, ld, Mr, nb1, nbk, rect, nullptr, GEMM_AUX);
+            launch_gemm_shape<T>(c, V + k1, ldv, R + k1, ldr, linv256 + (k1 / NB) * NB * NB, NB, Mr, nb1, nb1, rect, nullptr,
+                                 GEMM_OVERWRITE | GEMM_AUX);
+        }
+        hipEvent_t es = la_event(c, ne++);
+        (void)hipEventRecord(es, side);
+        c->gemm_reserve = 4 * c->lookahead_slots;
+        launch_gemm_nt<T>(c, R + k2, ldr, V + k0, ldv, A + k2 * ld + k0, ld, Mr, npad - k2, nbk, 0, nullptr);
+        c->gemm_reserve = 0;
+        (void)hipStreamWaitEvent(main_s, es, 0);
+        solved = true;
     }
 }
 
@@ -257,29 +315,6 @@ static void factor_panel_below(gpmi_ctx* c, T* A, int64_t ld, const T* linv, int
     for (int64_t j0 = k0; j0 < kend; j0 += IB)
         launch_rows64<T>(c, A + kend * ld + k0, ld, Mtot - kend, (int)(j0 - k0), A + j0 * ld + k0, ld,
                          linv + (j0 / IB) * IB * IB, 0, d_info);
-}
-
-// run launches on another stream of the context (the launchers read ctx->stream / ctx->num_cus)
-struct StreamScope {
-    gpmi_ctx* c;
-    hipStream_t s0;
-    int cus0;
-    StreamScope(gpmi_ctx* ctx, hipStream_t s, int cus) : c(ctx), s0(ctx->stream), cus0(ctx->num_cus) {
-        c->stream = s;
-        c->num_cus = cus;
-    }
-    ~StreamScope() {
-        c->stream = s0;
-        c->num_cus = cus0;
-    }
-};
-static hipEvent_t la_event(gpmi_ctx* c, size_t i) {
-    while (c->la_events.size() <= i) {
-        hipEvent_t e;
-        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-        c->la_events.push_back(e);
-    }
-    return c->la_events[i];
 }
 
 // blocked right-looking Cholesky, lower, in place; rows npad .. npad+extra-1 are carried along (forward solve for free).
@@ -455,13 +490,10 @@ static int grad_t(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, do
     }
     {
         ProfScope ps(c, GPMI_PROF_SOLVE, 2.0 * (double)npad * (double)npad * (double)npad / 3.0);
-        // rows of L^-T: the whiten sequence applied to the identity; row i is zero left of column i, so panel k
-        // only has to process rows < kend
-        launch_set_identity<T>(c, G1, ld, npad);
-        for (int64_t k0 = 0; k0 < npad; k0 += NB) {
-            const int64_t nbk = std::min<int64_t>(NB, npad - k0);
-            rows_block_solve<T>(c, A, ld, (const T*)gp->linv, npad, G1, ld, k0 + nbk, k0, nbk);
-        }
+        // rows of L^-T: the whiten sequence applied to an identity (in G2, consumed); row i is zero left of column i,
+        // so block k only has to process rows < kend
+        launch_set_identity<T>(c, G2, ld, npad);
+        whiten_rows_inv<T>(c, A, ld, (const T*)gp->linv256, npad, G2, ld, G1, ld, [](int64_t kend) { return kend; });
         // K^-1 = L^-T L^-1 = G1 G1'  (lower tiles; K loop starts at the tile's first row)
         launch_gemm_shape<T>(c, G2, ld, G1, ld, G1, ld, npad, npad, npad, TileShape{0, 0, 1, 0, 1, 0}, nullptr,
                              GEMM_OVERWRITE | GEMM_KSTART_ROW);
