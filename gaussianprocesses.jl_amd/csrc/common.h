@@ -75,6 +75,9 @@ struct gpmi_ctx {
     double* h_scal = nullptr;            // pinned
     unsigned long long* d_queue = nullptr;  // 8 per-XCD tile-queue words, 64 B apart (never reset)
     unsigned long long queue_base[8] = {0}; // value of each word when the next launch starts
+    bool refine_default = false;         // GPMI_REFINE=1: refine everywhere (bring-up / accuracy studies)
+    bool refine_solves = false;          // rows64: one refinement step on every product with a stored inverse
+                                         // (set for factorisations regularised only by a nugget; panel.hip)
     int gemm_wgs_per_cu = 2;             // tools: GPMI_GEMM_WGS=1 runs one workgroup per CU
     int num_cus = 256;                   // CUs the persistent GEMM sizes its grid for on the CURRENT stream
     // look-ahead Cholesky (api.hip: cholesky_lower): the next panel's serial chain runs on side_stream under the
@@ -83,7 +86,8 @@ struct gpmi_ctx {
     int lookahead_slots = 0;
     int64_t lookahead_min_trailing = 4608;  // trailing size below which the serial order is faster (update < chain)
     int gemm_reserve = 0;
-    std::vector<hipEvent_t> la_events;   // cross-stream dependencies, reused by every factorisation
+    std::vector<hipEvent_t> la_events;
+    size_t la_next = 0;   // cross-stream dependencies, reused by every factorisation
     bool prof_on = false;
     std::vector<gpmi::ProfRec> prof;
     std::vector<hipEvent_t> ev_pool;
@@ -142,6 +146,10 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// host helpers defined in api.hip
+int upload_program(gpmi_ctx* c, const gpmi_kernel* k, int d);                 // digest + upload the kernel program
+int grow(gpmi_ctx* c, void** p, int64_t* cap, int64_t need_bytes);            // (re)allocate a device scratch buffer
+
 // kernel launchers (each enqueues on ctx->stream; T = double | float) -------------------------
 enum CovFlags { COV_LOWER = 1, COV_NUGGET = 2, COV_PAD_IDENTITY = 4 };
 
@@ -162,9 +170,15 @@ void launch_gemm_nt(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, c
 
 // same kernel with an explicit tile shape (mode 2 = staircase of a row-block-cyclic shard, tile_order.h);
 // shape.ntm / shape.ntn are filled in from M and N
+// batch != nullptr: `count` independent products in one launch, operands / output of product b offset by b * stride
+// elements (split-K into separate partial outputs: strideA = strideB = K, strideC = one output matrix)
+struct GemmBatch {
+    int count;
+    int64_t strideA, strideB, strideC;
+};
 template <typename T>
 void launch_gemm_shape(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M,
-                       int64_t N, int64_t K, TileShape shape, const int* info, int flags = 0);
+                       int64_t N, int64_t K, TileShape shape, const int* info, int flags = 0, const GemmBatch* batch = nullptr);
 enum GemmFlags { GEMM_OVERWRITE = 1 /* C = A B' instead of C -= A B' */, GEMM_KSTART_ROW = 2 /* A[i][k] = 0 for k < i: start K at the tile's first row */,
                  GEMM_AUX = 4 /* no effect on the kernel: account the launch to the panel class, not to the trailing update */ };
 

@@ -56,6 +56,10 @@ struct QueueArgs {
     unsigned long long base[8];  // per-XCD value of the queue word at launch
     int64_t start[9];            // chunk x = tiles [start[x], start[x+1])
     int use_queue;
+    // batched launch (split-K with separate outputs): work item t is tile t % tiles_per of batch t / tiles_per,
+    // whose operands and output start strideA / strideB / strideC elements further on
+    int64_t tiles_per;
+    int64_t strideA, strideB, strideC;
 };
 
 template <typename T, int VARIANT>
@@ -123,7 +127,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
         if (t >= cend) break;
         if constexpr (VARIANT & 128) tk_n += 1;
         int ti, tj;
-        tile_decode(t, shape, &ti, &tj);
+        const int64_t bi = t / qa.tiles_per;  // 0 unless batched
+        tile_decode(t - bi * qa.tiles_per, shape, &ti, &tj);
+        T* __restrict__ const Ct = C + bi * qa.strideC;
         const int64_t m0 = (int64_t)ti * BM, n0 = (int64_t)tj * BN;
 
         // Staging: every thread moves 4 x 16-B chunks of A and of B per slab straight from global
@@ -131,8 +137,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
         // image of a slab is [128 rows][8 chunks] with NO padding (the DMA writes lane-linear);
         // bank conflicts are avoided by an XOR swizzle applied on the SOURCE side: position p of
         // row r holds global chunk p ^ (r & 7), and the fragment reads apply the same involution.
-        const T* __restrict__ Ab = A + m0 * lda;
-        const T* __restrict__ Bb = B + n0 * ldb;
+        const T* __restrict__ Ab = A + bi * qa.strideA + m0 * lda;
+        const T* __restrict__ Bb = B + bi * qa.strideB + n0 * ldb;
         const int mrem = (int)((M - m0 < BM ? M - m0 : BM) - 1);  // last valid local row
         const int nrem = (int)((N - n0 < BN ? N - n0 : BN) - 1);
         int oa[4], ob[4];
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
 #pragma unroll
                         for (int e = 0; e < VEC; ++e) cv[it][e] = T(0);
                     } else {
-                        cv[it] = *reinterpret_cast<const VT*>(C + grow * ldc + gcol);
+                        cv[it] = *reinterpret_cast<const VT*>(Ct + grow * ldc + gcol);
                     }
                 }
 #pragma unroll
@@ -291,11 +297,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
                     const VT v = *reinterpret_cast<const VT*>(stg + (it * RPI + rloc) * 64 + cloc);
                     if (grow < M) {
                         if (gcol + VEC <= N) {
-                            *reinterpret_cast<VT*>(C + grow * ldc + gcol) = (flags & GEMM_OVERWRITE) ? v : cv[it] - v;
+                            *reinterpret_cast<VT*>(Ct + grow * ldc + gcol) = (flags & GEMM_OVERWRITE) ? v : cv[it] - v;
                         } else {  // ragged right edge (only the P x P full_cov update gets here)
 #pragma unroll
                             for (int e = 0; e < VEC; ++e)
-                                if (gcol + e < N) C[grow * ldc + gcol + e] = (flags & GEMM_OVERWRITE) ? v[e] : C[grow * ldc + gcol + e] - v[e];
+                                if (gcol + e < N) Ct[grow * ldc + gcol + e] = (flags & GEMM_OVERWRITE) ? v[e] : Ct[grow * ldc + gcol + e] - v[e];
                         }
                     }
                 }
@@ -348,16 +354,21 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(T* out, int iters) {
 
 template <typename T, int V>
 static void launch_persistent(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M,
-                              int64_t N, int64_t K, TileShape shape, const int* info, int flags = 0) {
+                              int64_t N, int64_t K, TileShape shape, const int* info, int flags = 0, const GemmBatch* batch = nullptr) {
     shape.ntm = (int)((M + GEMM_BM - 1) / GEMM_BM);
     shape.ntn = (int)((N + GEMM_BN - 1) / GEMM_BN);
-    const int64_t ntiles = tile_count(shape);
+    const int64_t tiles_per = tile_count(shape);
+    const int64_t ntiles = tiles_per * (batch ? batch->count : 1);
     if (ntiles <= 0) return;
     const int slots = ctx->gemm_wgs_per_cu * ctx->num_cus - ctx->gemm_reserve;  // both multiples of 8
     // small launches: one workgroup per tile (rounded up to a multiple of 8 so XCD chunks stay contiguous)
     const int grid = (int)std::min<int64_t>(slots, (ntiles + 7) / 8 * 8);
     QueueArgs qa;
     qa.use_queue = ntiles > grid;
+    qa.tiles_per = tiles_per;
+    qa.strideA = batch ? batch->strideA : 0;
+    qa.strideB = batch ? batch->strideB : 0;
+    qa.strideC = batch ? batch->strideC : 0;
     for (int x = 0; x <= 8; ++x) qa.start[x] = ntiles * x / 8;
     for (int x = 0; x < 8; ++x) {
         qa.base[x] = ctx->queue_base[x];
@@ -384,16 +395,17 @@ static double shape_entries(int64_t M, int64_t N, const TileShape& s) {
 
 template <typename T>
 void launch_gemm_shape(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M,
-                       int64_t N, int64_t K, TileShape shape, const int* info, int flags) {
+                       int64_t N, int64_t K, TileShape shape, const int* info, int flags, const GemmBatch* batch) {
     if (M <= 0 || N <= 0 || K <= 0) return;
     // Two instantiations of the same code so that profilers separate them by name: <T, 0> is the Cholesky trailing
     // update (the roofline kernel of bench.py), <T, 64> every other product (panel / predict / gradient GEMMs).
     const bool trailing = shape.mode && !flags;
-    ProfScope ps(ctx, trailing ? GPMI_PROF_SYRK : GPMI_PROF_PANEL, 2.0 * shape_entries(M, N, shape) * (double)K);
+    ProfScope ps(ctx, trailing ? GPMI_PROF_SYRK : GPMI_PROF_PANEL,
+                 2.0 * shape_entries(M, N, shape) * (double)K * (batch ? batch->count : 1));
     if (trailing)
-        launch_persistent<T, 0>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags);
+        launch_persistent<T, 0>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags, batch);
     else
-        launch_persistent<T, 64>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags);
+        launch_persistent<T, 64>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags, batch);
 }
 
 template <typename T>
@@ -403,9 +415,9 @@ void launch_gemm_nt(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, c
 }
 
 template void launch_gemm_shape<double>(gpmi_ctx*, double*, int64_t, const double*, int64_t, const double*, int64_t, int64_t,
-                                        int64_t, int64_t, TileShape, const int*, int);
+                                        int64_t, int64_t, TileShape, const int*, int, const GemmBatch*);
 template void launch_gemm_shape<float>(gpmi_ctx*, float*, int64_t, const float*, int64_t, const float*, int64_t, int64_t,
-                                       int64_t, int64_t, TileShape, const int*, int);
+                                       int64_t, int64_t, TileShape, const int*, int, const GemmBatch*);
 template void launch_gemm_nt<double>(gpmi_ctx*, double*, int64_t, const double*, int64_t, const double*, int64_t,
                                      int64_t, int64_t, int64_t, int, const int*);
 template void launch_gemm_nt<float>(gpmi_ctx*, float*, int64_t, const float*, int64_t, const float*, int64_t, int64_t,

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void diag64_kernel(T* __restrict__ A, int64
 template <typename T>
 __global__ __launch_bounds__(256, 2) void rows64_kernel(T* __restrict__ Xp, int64_t ldx, int64_t M, int K1,
                                                      const T* __restrict__ Lp, int64_t ldl, const T* __restrict__ Linv,
-                                                     int64_t diag_rows, const int* __restrict__ info) {
+                                                     int64_t diag_rows, const int* __restrict__ info, int refine) {
     if (info && *info != 0) return;
     __builtin_amdgcn_s_setprio(3);  // see diag64_kernel
     using MF = Mfma<T>;
@@ -282,6 +282,63 @@ __global__ __launch_bounds__(256, 2) void rows64_kernel(T* __restrict__ Xp, int6
             mma16_nt<T>(acc[mi][ni], buf1 + (wm * 32 + mi * 16) * LD, LD, buf2 + (wn * 32 + ni * 16) * LD, LD, 64, lane);
         }
     __syncthreads();
+    if (refine) {
+        // One step of iterative refinement against the block itself:  X <- X + (T - X L_jj') Linv_j'.
+        // The product with the explicit inverse is only accurate to cond(L_jj) eps; for covariance blocks whose only
+        // regularisation is a 1e-10 nugget (FITC's Kuu, make_posdef!) that is as large as the nugget and the next
+        // pivot goes negative where LAPACK's substitution succeeds.  The refined solve has the substitution's accuracy.
+        Acc tacc[2][2], xacc[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                xacc[mi][ni] = acc[mi][ni];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wm * 32 + mi * 16 + MF::row_of(lane, r), col = wn * 32 + ni * 16 + MF::col_of(lane, r);
+                    tacc[mi][ni].v[r] = buf1[row * LD + col];  // T, in the accumulator layout
+                }
+            }
+        __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wm * 32 + mi * 16 + MF::row_of(lane, r), col = wn * 32 + ni * 16 + MF::col_of(lane, r);
+                    buf1[row * LD + col] = acc_get<T>(xacc[mi][ni], r);
+                }
+        for (int e = tid; e < 64 * 64; e += 256) buf2[(e >> 6) * LD + (e & 63)] = Lp[(int64_t)(e >> 6) * ldl + K1 + (e & 63)];
+        __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                acc_zero<T>(acc[mi][ni]);
+                mma16_nt<T>(acc[mi][ni], buf1 + (wm * 32 + mi * 16) * LD, LD, buf2 + (wn * 32 + ni * 16) * LD, LD, 64, lane);
+            }
+        __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wm * 32 + mi * 16 + MF::row_of(lane, r), col = wn * 32 + ni * 16 + MF::col_of(lane, r);
+                    buf1[row * LD + col] = tacc[mi][ni].v[r] - acc_get<T>(acc[mi][ni], r);  // residual
+                }
+        for (int e = tid; e < 64 * 64; e += 256) buf2[(e >> 6) * LD + (e & 63)] = Linv[e];
+        __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                acc[mi][ni] = xacc[mi][ni];
+                mma16_nt<T>(acc[mi][ni], buf1 + (wm * 32 + mi * 16) * LD, LD, buf2 + (wn * 32 + ni * 16) * LD, LD, 64, lane);
+            }
+        __syncthreads();
+    }
     const bool diag = row0 < diag_rows;  // workgroup-uniform
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -658,7 +715,7 @@ void launch_rows64(gpmi_ctx* ctx, T* Xp, int64_t ldx, int64_t M, int K1, const T
     if (M <= 0) return;
     ProfScope ps(ctx, GPMI_PROF_PANEL, 2.0 * (double)M * 64.0 * (double)(K1 + 64));
     hipLaunchKernelGGL(rows64_kernel<T>, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, ctx->stream, Xp, ldx, M, K1, Lp, ldl,
-                       linv, diag_rows, info);
+                       linv, diag_rows, info, ctx->refine_solves ? 1 : 0);
 }
 template <typename T>
 void launch_trsm_rows(gpmi_ctx* ctx, T* X, int64_t ldx, const T* L11, int64_t ldl, const T* invdiag, int64_t M,

@@ -5,12 +5,13 @@ hierarchy; all covariance / Cholesky / solve arithmetic runs in libgpmi.so (HIP,
 Importing this package never imports anything under oracle/ and there is no CPU fallback.
 """
 from ._lib import ArgumentError, Context, DeviceError, PosDefException, load  # noqa: F401
-from .gpe import (GP, GPE, HIPPDMat, get_params, optimize, predict_f, predict_y, set_params,  # noqa: F401
+from .gpe import (FITC, GP, GPE, HIPPDMat, get_params, optimize, predict_f, predict_y, set_params,  # noqa: F401
                   update_mll, update_target)
 from .kernels import (RQ, SE, Const, FixedKernel, Kernel, Masked, Mat12Ard, Mat12Iso, Mat32Ard,  # noqa: F401
                       Mat32Iso, Mat52Ard, Mat52Iso, Matern, Noise, ProdKernel, RQArd, RQIso, SEArd,
                       SEIso, SumKernel, fix, from_spec)
 from .means import Mean, MeanConst, MeanLin, MeanZero  # noqa: F401
+from .sparse import FullyIndepPDMat, FullyIndepStrat  # noqa: F401
 
 
 def cov(kernel, X1, X2=None, dtype="float64", ctx=None):

@@ -80,7 +80,10 @@ class HIPPDMat:
 
 
 class GPE:
-    def __init__(self, x, y, mean=None, kernel=None, logNoise=-2.0, dtype=np.float64, ctx=None):
+    def __init__(self, x, y, mean=None, kernel=None, logNoise=-2.0, covstrat=None, dtype=np.float64, ctx=None):
+        """GPE(x, y, mean, kernel, logNoise[, covstrat]) — GPE.jl:68-71.  covstrat None = the exact (dense) device path;
+        a FullyIndepStrat selects FITC (gpmi355x.sparse)."""
+        self.covstrat = covstrat
         if kernel is None or not isinstance(kernel, Kernel):
             raise _lib.ArgumentError("a Kernel is required")
         self.mean = mean if mean is not None else MeanZero()
@@ -106,12 +109,22 @@ class GPE:
         self.x = _lib.colmajor(x, _lib.np_dtype(self.bits))
         self.y = y
         self.dim, self.nobs = self.x.shape
-        self.cK = HIPPDMat(self.ctx, self.x, self.bits)  # alloc_cK (GP.jl:14-20)
+        if self.covstrat is None:
+            self.cK = HIPPDMat(self.ctx, self.x, self.bits)  # alloc_cK (GP.jl:14-20)
+        else:
+            from .sparse import FullyIndepPDMat, FullyIndepStrat
+            if not isinstance(self.covstrat, FullyIndepStrat):
+                raise _lib.ArgumentError("covstrat must be None (exact) or a FullyIndepStrat")
+            xu = _lib.colmajor(self.covstrat.inducing, _lib.np_dtype(self.bits))
+            self.cK = FullyIndepPDMat(self.ctx, self.x, xu, self.bits)  # alloc_cK, fully_indep…:118-132
         self.initialise_target()
         return self
 
     # -- update_mll! : GPE.jl:202-212 ------------------------------------------
     def update_mll(self, noise=True, domean=True, kern=True):
+        if self.covstrat is not None:
+            from .sparse import fitc_update_mll
+            return fitc_update_mll(self)
         dt = _lib.np_dtype(self.bits)
         mu = self.mean.mean(self.x)
         ymu = np.ascontiguousarray(self.y - mu, dtype=dt)
@@ -134,6 +147,8 @@ class GPE:
     def update_dmll(self, noise=True, domean=True, kern=True):
         """Gradient of the mll in the order [logNoise; mean…; kernel…] (the exposed parameters only).
         Kernel and noise parts come from the device (gpmi_grad); the mean part is dot(grad_mean, alpha)."""
+        if self.covstrat is not None:
+            raise _lib.ArgumentError("the device gradient covers the exact path only (FITC gradients: SURVEY 8f, not built)")
         if self.alpha is None:
             raise _lib.ArgumentError("update_dmll needs a fitted model (call update_mll first)")
         parts = []
@@ -185,6 +200,9 @@ class GPE:
             raise _lib.ArgumentError("Gaussian Process object and input observations do not have consistent dimensions")
         dt = _lib.np_dtype(self.bits)
         xp = _lib.colmajor(x, dt)
+        if self.covstrat is not None:
+            from .sparse import fitc_predict_f
+            return fitc_predict_f(self, xp, full_cov)
         P = xp.shape[1]
         mx = np.ascontiguousarray(self.mean.mean(xp), dtype=dt)
         mu = np.empty(P, dtype=dt)
@@ -240,6 +258,12 @@ class GPE:
 def GP(x, y, mean=None, kernel=None, logNoise=-2.0, **kw):
     """GP(x, y, mean, kernel, logNoise) — src/GPE.jl:119-120."""
     return GPE(x, y, mean, kernel, logNoise, **kw)
+
+
+def FITC(x, inducing, y, mean=None, kernel=None, logNoise=-2.0, **kw):
+    """FITC(x, inducing, y, mean, kernel, logNoise) — src/sparse/fully_indep_train_conditional.jl:333-336."""
+    from .sparse import FullyIndepStrat
+    return GPE(x, y, mean, kernel, logNoise, covstrat=FullyIndepStrat(inducing), **kw)
 
 
 # functional spellings of the reference's exported verbs

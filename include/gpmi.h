@@ -127,6 +127,29 @@ int gpmi_predict(gpmi_gp*, const gpmi_kernel*, int64_t p, const void* xpred, con
 int gpmi_grad(gpmi_gp*, const gpmi_kernel*, const double* log_noise, int64_t n_noise, double* dkern_out, int32_t n_kern,
               double* dnoise_out);
 
+/* ---- FITC sparse approximation (BASELINE.json configs[4]) ----------------------
+ * Replaces, for covstrat = FullyIndepStrat(inducing):
+ *   alloc_cK / update_cK!(::FullyIndepPDMat, ...)   src/sparse/fully_indep_train_conditional.jl:118-156
+ *   `\`, logdet of FullyIndepPDMat                   :38-41, :80            (inside update_mll!, src/GPE.jl:202-212)
+ *   get_alpha_u, predictMVN(::FullyIndepStrat)      :279-286, :321-329 (DTC: determ_train_conditional.jl:41-59,
+ *                                                   SoR: subsetofregressors.jl:303-321)
+ * x: n x d row-major (== Julia's d x n), xu: m x d row-major (== the d x m `inducing` matrix).  Both make_posdef!
+ * nuggets (1e-10 on Kuu and on SigmaQR) are applied as the reference does.  log_noise is a scalar (the reference's
+ * FITC takes logNoise::Real).  alpha_out (n) = cK \ (y - mu), mll_out as GPE.jl:210 with the determinant lemma.
+ * GPMI_ENOTPD when Kuu / SigmaQR fail to factor or a Lambda_i is not positive (info = pivot / 1-based index).
+ * Device memory: three n x m matrices (Kfu, its whitened image, Kuf) -- sized for 288 GB, not for a host. */
+typedef struct gpmi_fitc gpmi_fitc;
+int gpmi_fitc_create(gpmi_ctx*, int dtype, int d, int64_t n, const void* x, int64_t m, const void* xu, gpmi_fitc** out);
+void gpmi_fitc_destroy(gpmi_fitc*);
+int gpmi_fitc_fit(gpmi_fitc*, const gpmi_kernel*, double log_noise, const void* y_minus_mu, double* mll_out, void* alpha_out,
+                  int64_t* info_out);
+/* mu_out[p] = mean_pred[p] + Kxu alpha_u ; var_out: p variances clamped at 0 (GP.jl:75), or the p x p matrix
+ * Kxx - Qxx + Kxu SigmaQR^-1 Kux (col-major == row-major, symmetric) when full_cov != 0 */
+int gpmi_fitc_predict(gpmi_fitc*, const gpmi_kernel*, int64_t p, const void* xpred, const void* mean_pred, int full_cov,
+                      void* mu_out, void* var_out);
+/* alpha_u = SigmaQR \ (Kuf (Lambda \ (y - mu))), m elements (get_alpha_u) */
+int gpmi_fitc_alpha_u(gpmi_fitc*, void* out);
+
 /* ---- cov: replaces cov / cov! (src/kernels/kernels.jl:31-71) -------------
  * out is n1 x n2 col-major; x2 == NULL selects the symmetric X1 === X2 form. */
 int gpmi_cov(gpmi_ctx*, const gpmi_kernel*, int dtype, int d, int64_t n1, const void* x1,

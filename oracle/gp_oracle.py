@@ -484,3 +484,143 @@ def update_dmll(spec, x, y, log_noise, mspec=("zero",), fit=None):
     _, dKs = grad_cov(spec, x)
     dkern = np.array([0.5 * np.sum(W * dK) for dK in dKs])  # GPE.jl:219-241 (diag/2 + strict lower = half the full sum)
     return {"dmll": np.concatenate([[dnoise], dmean, dkern]), "dnoise": dnoise, "dmean": dmean, "dkern": dkern}
+
+
+# --------------------------------------------------------------------------
+# FITC: src/sparse/fully_indep_train_conditional.jl, with the pieces it inherits from
+# subsetofregressors.jl (alpha_u, predictMVN) and determ_train_conditional.jl (the DTC predictive covariance)
+# --------------------------------------------------------------------------
+def _chol_upper(m, nugget):
+    """make_posdef!(m, factors; nugget) (GP.jl:101-112): add the nugget to the diagonal, upper Cholesky."""
+    a = np.array(m, dtype=np.float64)
+    if nugget > 0:
+        a[np.diag_indices_from(a)] += nugget
+    try:
+        return a, sla.cholesky(a, lower=False)
+    except sla.LinAlgError as e:  # LAPACK info -> PosDefException
+        raise NotPosDef(str(e)) from e
+
+
+def fitc_update_cK(spec, x, xu, log_noise):
+    """update_cK!(::FullyIndepPDMat, …) — fully_indep_train_conditional.jl:134-156."""
+    x = np.asarray(x, dtype=np.float64)
+    xu = np.asarray(xu, dtype=np.float64)
+    Kuu, Uuu = _chol_upper(cov(spec, xu), 1e-10)                      # :139-141
+    Kuf = cov(spec, xu, x)                                            # :142
+    Kdiag = _kdiag(spec, x)                                           # :146
+    Luf = sla.solve_triangular(Uuu, Kuf, trans="T", lower=False)      # invquad(Kuu, Kuf[:, i]) = |Uuu^-T Kuf[:, i]|^2
+    Qdiag = np.sum(Luf * Luf, axis=0)                                 # :147
+    lam = math.exp(2.0 * float(log_noise)) + Kdiag - Qdiag            # :148
+    SQR = Kuf @ (Kuf / lam).T + Kuu                                   # :150
+    SQR = np.triu(SQR) + np.triu(SQR, 1).T                            # copytri!(…, 'U') :151
+    SQR, Usqr = _chol_upper(SQR, 1e-10)                               # :153
+    return {"Kuu": Kuu, "Uuu": Uuu, "Kuf": Kuf, "lam": lam, "SQR": SQR, "Usqr": Usqr}
+
+
+def fitc_solve(cK, b):
+    r"""`\`(a::FullyIndepPDMat, x) — fully_indep_train_conditional.jl:38-41."""
+    Lk = sla.solve_triangular(cK["Usqr"], cK["Kuf"], trans="T", lower=False)  # whiten(ΣQR, Kuf)
+    bl = (b.T / cK["lam"]).T
+    return ((b - Lk.T @ (Lk @ bl)).T / cK["lam"]).T
+
+
+def fitc_logdet(cK):
+    """logdet(::FullyIndepPDMat) — fully_indep_train_conditional.jl:80."""
+    ld = lambda U: 2.0 * float(np.sum(np.log(np.diag(U))))
+    return ld(cK["Usqr"]) - ld(cK["Uuu"]) + float(np.sum(np.log(cK["lam"])))
+
+
+def fitc_dense(cK):
+    """Base.Matrix(::FullyIndepPDMat) — fully_indep_train_conditional.jl:81-86 (what test_sparse.jl:117-132 compares with)."""
+    Lk = sla.solve_triangular(cK["Uuu"], cK["Kuf"], trans="T", lower=False)
+    return Lk.T @ Lk + np.diag(cK["lam"])
+
+
+def fitc_update_mll(spec, x, xu, y, log_noise, mspec=("zero",)):
+    """update_mll! (GPE.jl:202-212) on a FITC covariance.  Returns the cK pieces + alpha, alpha_u, mll, logdet."""
+    x = np.asarray(x, dtype=np.float64)
+    cK = fitc_update_cK(spec, x, xu, log_noise)
+    ym = np.asarray(y, dtype=np.float64) - mean(mspec, x)
+    alpha = fitc_solve(cK, ym)
+    logdet = fitc_logdet(cK)
+    mll = -(float(ym @ alpha) + logdet + LOG2PI * x.shape[1]) / 2.0
+    # get_alpha_u (fully_indep_train_conditional.jl:279-286): ΣQR \ (Kuf (Λ \ (y - m)))
+    alpha_u = sla.cho_solve((cK["Usqr"], False), cK["Kuf"] @ (ym / cK["lam"]))
+    out = dict(cK)
+    out.update({"alpha": alpha, "alpha_u": alpha_u, "mll": mll, "logdet": logdet})
+    return out
+
+
+def fitc_predict_full(spec, xu, fit, xpred, mspec=("zero",)):
+    """predictMVN(…, ::FullyIndepStrat, …) = the DTC formulas (fully_indep…:321-329 -> determ_train_conditional.jl:41-59
+    -> subsetofregressors.jl:303-321): mu = m(x*) + Kux' alpha_u ;  Sigma = Kxx - Qxx + Kxu ΣQR^-1 Kux."""
+    xpred = np.asarray(xpred, dtype=np.float64)
+    Kux = cov(spec, np.asarray(xu, dtype=np.float64), xpred)
+    mu = mean(mspec, xpred) + Kux.T @ fit["alpha_u"]
+    Lck = sla.solve_triangular(fit["Usqr"], Kux, trans="T", lower=False)
+    S_sor = Lck.T @ Lck
+    Lq = sla.solve_triangular(fit["Uuu"], Kux, trans="T", lower=False)
+    Qxx = Lq.T @ Lq                                                    # Xt_invA_X(Kuu, Kux)
+    S = cov(spec, xpred) - Qxx + S_sor
+    S = np.triu(S) + np.triu(S, 1).T
+    return mu, S
+
+
+def fitc_predict_f(spec, xu, fit, xpred, mspec=("zero",), full_cov=False):
+    """predict_f (GP.jl:64-79) on the FITC model: per point max(diag, 0) unless full_cov."""
+    mu, S = fitc_predict_full(spec, xu, fit, xpred, mspec)
+    if full_cov:
+        return mu, S
+    return mu, np.maximum(np.diag(S), 0.0)
+
+
+def _chol_lower_ld(A):
+    """Unblocked lower Cholesky in np.longdouble (80-bit on x86): the arithmetic-independent value of a factorisation."""
+    LD = np.longdouble
+    A = np.asarray(A, dtype=LD)
+    n = A.shape[0]
+    L = np.zeros_like(A)
+    for j in range(n):
+        d = A[j, j] - np.dot(L[j, :j], L[j, :j])
+        if not d > 0:
+            raise NotPosDef(f"pivot {j + 1}")
+        L[j, j] = np.sqrt(d)
+        if j + 1 < n:
+            L[j + 1:, j] = (A[j + 1:, j] - L[j + 1:, :j] @ L[j, :j]) / L[j, j]
+    return L
+
+
+def fitc_update_mll_extended(spec, x, xu, y, log_noise, mspec=("zero",)):
+    """The same statements as fitc_update_cK / fitc_update_mll (fully_indep_train_conditional.jl:134-156, :38-41, :80,
+    :279-286) evaluated in 80-bit arithmetic on the fp64 covariance entries.  ΣQR = Kuf Λ⁻¹ Kfu + Kuu has a condition number
+    of order n / (σ² · 1e-10): its small pivots — and with them logdet and alpha_u — are rounding noise in ANY fp64 Cholesky,
+    LAPACK's included, so for covariances that are numerically rank-deficient (smooth kernels, many inducing points) this is
+    the value a faithful implementation has to be compared with.  O(n m²) Python-level loops: small cases only."""
+    LD = np.longdouble
+    x = np.asarray(x, dtype=np.float64)
+    xu = np.asarray(xu, dtype=np.float64)
+    m = xu.shape[1]
+    Kuu = cov(spec, xu).astype(LD)
+    Kuu[np.diag_indices_from(Kuu)] += LD(1e-10)
+    Luu = _chol_lower_ld(Kuu)
+    Kuf = cov(spec, xu, x).astype(LD)
+    W = np.zeros_like(Kuf)
+    for i in range(m):
+        W[i] = (Kuf[i] - Luu[i, :i] @ W[:i]) / Luu[i, i]
+    lam = LD(math.exp(2.0 * float(log_noise))) + _kdiag(spec, x).astype(LD) - (W * W).sum(axis=0)
+    S = Kuf @ (Kuf / lam).T + Kuu
+    S[np.diag_indices_from(S)] += LD(1e-10)
+    LS = _chol_lower_ld(S)
+    r = (np.asarray(y, dtype=np.float64) - mean(mspec, x)).astype(LD)
+    t = Kuf @ (r / lam)
+    z = np.zeros(m, dtype=LD)
+    for i in range(m):
+        z[i] = (t[i] - LS[i, :i] @ z[:i]) / LS[i, i]
+    au = np.zeros(m, dtype=LD)
+    for i in range(m - 1, -1, -1):
+        au[i] = (z[i] - LS[i + 1:, i] @ au[i + 1:]) / LS[i, i]
+    alpha = (r - Kuf.T @ au) / lam
+    logdet = 2 * np.log(np.diag(LS)).sum() - 2 * np.log(np.diag(Luu)).sum() + np.log(lam).sum()
+    mll = -(r @ alpha + logdet + LD(LOG2PI) * x.shape[1]) / 2
+    return {"mll": float(mll), "alpha": alpha.astype(np.float64), "alpha_u": au.astype(np.float64),
+            "lam": lam.astype(np.float64), "logdet": float(logdet)}

@@ -1,0 +1,115 @@
+"""GPU parity of the FITC path (gpmi_fitc_*) against the CPU oracle's restatement of
+src/sparse/fully_indep_train_conditional.jl — SURVEY §8f rank 2.
+
+Which oracle: ΣQR = Kuf Λ⁻¹ Kfu + Kuu has a condition number ~ n / (σ² · 1e-10); for smooth kernels its small pivots are
+rounding noise in any fp64 Cholesky, so the fp64 (LAPACK) evaluation of the reference's statements is itself off by up to
+1.4e-4 relative in mll on the SE cases below (tools/fitc_probe.py).  mll / alpha / alpha_u are therefore
+checked against the SAME statements evaluated in 80-bit arithmetic (oracle.fitc_update_mll_extended), where the device path
+(which factors the well-conditioned whitened matrix B instead of ΣQR) agrees to ~1e-8; predictions are checked against the
+fp64 oracle at the north-star's rtol 1e-5."""
+import math
+
+import numpy as np
+import pytest
+
+import gpmi355x as g
+from oracle import gp_oracle as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(n, d, m, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(size=(d, n))
+    xu = rng.uniform(size=(d, m))
+    y = np.sin(3.0 * x.sum(axis=0)) + 0.1 * rng.standard_normal(n)
+    xs = rng.uniform(size=(d, 37))
+    return x, xu, y, xs
+
+
+CASES = [
+    ("se_ard_d2", ("se_ard", [math.log(0.3), math.log(0.45)], 0.1), 1500, 2, 100),
+    ("se_iso_d1", ("se_iso", math.log(0.2), 0.0), 1000, 1, 12),          # test_sparse.jl's shape: n = 1000, 12 inducing
+    ("mat52+rq_d3", ("sum", ("mat52_iso", math.log(0.6), 0.1), ("rq_iso", 0.0, -0.5, 0.3)), 2100, 3, 300),
+    ("prod_masked_d3", ("prod", ("masked", ("se_iso", math.log(0.5), 0.0), [0, 1]), ("mat32_iso", math.log(0.9), 0.2)), 900, 3, 65),
+]
+
+
+@pytest.mark.parametrize("name,spec,n,d,m", CASES, ids=[c[0] for c in CASES])
+def test_fitc_fit_and_predict_match_the_oracle(name, spec, n, d, m):
+    x, xu, y, xs = _case(n, d, m, 31)
+    ln = math.log(0.2)
+    ref = G.fitc_update_mll(spec, x, xu, y, ln, ("const", 0.25))
+    ext = G.fitc_update_mll_extended(spec, x, xu, y, ln, ("const", 0.25))
+    gp = g.FITC(x, xu, y, g.MeanConst(0.25), g.from_spec(spec), ln)
+    assert abs(gp.mll - ext["mll"]) <= 1e-6 * abs(ext["mll"])
+    assert abs(gp.mll - ref["mll"]) <= 1e-3 * abs(ref["mll"])           # the fp64 statement of the same thing
+    np.testing.assert_allclose(gp.alpha, ext["alpha"], rtol=0, atol=1e-6 * np.abs(ext["alpha"]).max())
+    au = gp.cK.alpha_u()
+    np.testing.assert_allclose(au, ext["alpha_u"], rtol=0, atol=1e-3 * np.abs(ext["alpha_u"]).max())
+    mu_r, S_r = G.fitc_predict_f(spec, xu, ref, xs, ("const", 0.25), full_cov=True)
+    mu, var = gp.predict_f(xs)
+    np.testing.assert_allclose(mu, mu_r, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(var, np.maximum(np.diag(S_r), 0.0), rtol=1e-5, atol=1e-7)
+    mu2, S = gp.predict_f(xs, full_cov=True)
+    np.testing.assert_allclose(mu2, mu_r, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(S, S_r, rtol=1e-5, atol=1e-7)
+    muy, vy = gp.predict_y(xs)
+    np.testing.assert_allclose(vy, var + math.exp(2 * ln), rtol=1e-12)
+
+
+def test_fitc_parameter_updates_and_refit():
+    """set_params! -> update_mll! on the same device handle (the optimiser's loop), test_sparse.jl:122-127."""
+    spec = ("se_ard", [math.log(0.3), math.log(0.45)], 0.1)
+    x, xu, y, xs = _case(1200, 2, 70, 33)
+    gp = g.FITC(x, xu, y, g.MeanZero(), g.from_spec(spec), -1.0)
+    first = gp.mll
+    p = gp.get_params()
+    q = [v + 0.1 for v in p]
+    gp.set_params(q)
+    gp.update_mll()
+    spec2 = ("se_ard", [q[1], q[2]], q[3])
+    ref = G.fitc_update_mll_extended(spec2, x, xu, y, q[0])
+    assert abs(gp.mll - ref["mll"]) <= 1e-6 * abs(ref["mll"])
+    gp.set_params(p)
+    gp.update_mll()
+    assert gp.mll == first  # deterministic: same inputs, same bits
+
+
+def test_fitc_inducing_at_the_data_reproduces_the_exact_gp():
+    spec = ("mat32_iso", math.log(0.5), 0.0)
+    x, _, y, xs = _case(640, 2, 5, 35)
+    sp = g.FITC(x, x, y, g.MeanZero(), g.from_spec(spec), math.log(0.3))
+    ex = g.GP(x, y, g.MeanZero(), g.from_spec(spec), math.log(0.3))
+    assert abs(sp.mll - ex.mll) < 1e-5 * abs(ex.mll)  # they differ by the two 1e-10 nuggets (5.5e-4 here, oracle alike)
+    assert abs(sp.mll - G.fitc_update_mll(spec, x, x, y, math.log(0.3))["mll"]) < 1e-7 * abs(ex.mll)
+    m1, v1 = sp.predict_f(xs)
+    m2, v2 = ex.predict_f(xs)
+    np.testing.assert_allclose(m1, m2, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(v1, v2, rtol=1e-4, atol=1e-6)
+
+
+def test_fitc_fp32():
+    # a rough kernel and few inducing points: the 1e-10 nugget is below fp32's epsilon, so Kuu has to be
+    # positive definite in fp32 on its own (the reference has no fp32 path at all)
+    spec = ("mat12_iso", math.log(0.4), 0.0)
+    x, xu, y, xs = _case(2000, 2, 20, 37)
+    ref = G.fitc_update_mll(spec, x, xu, y, math.log(0.3))
+    gp = g.FITC(x, xu, y, g.MeanZero(), g.from_spec(spec), math.log(0.3), dtype=np.float32)
+    assert abs(gp.mll - ref["mll"]) <= 1e-2 * abs(ref["mll"])
+    mu_r, v_r = G.fitc_predict_f(spec, xu, ref, xs)
+    mu, var = gp.predict_f(xs)
+    np.testing.assert_allclose(mu, mu_r, rtol=1e-2, atol=1e-2)
+    np.testing.assert_allclose(var, v_r, rtol=1e-2, atol=1e-2)
+
+
+def test_fitc_error_contract():
+    x, xu, y, xs = _case(300, 2, 10, 39)
+    k = g.SEArd([0.0, 0.0], 0.0)
+    with pytest.raises(g.ArgumentError):
+        g.FITC(x, xu[:1], y, g.MeanZero(), k, -1.0)          # inducing points of the wrong dimension
+    gp = g.FITC(x, xu, y, g.MeanZero(), k, -1.0)
+    with pytest.raises(g.ArgumentError):
+        gp.predict_f(xs[:1])
+    with pytest.raises(g.ArgumentError):
+        gp.update_dmll()

@@ -9,6 +9,7 @@ import math
 
 import numpy as np
 import pytest
+import scipy.linalg as sla
 
 from oracle import c_oracle
 from oracle import gp_oracle as G
@@ -245,3 +246,72 @@ def test_oracle_gradient_vs_finite_differences(spec):
         up = G.update_mll(_perturb(spec, p, h), x, y, ln, ("const", 0.2))["mll"]
         dn = G.update_mll(_perturb(spec, p, -h), x, y, ln, ("const", 0.2))["mll"]
         assert g["dkern"][p] == pytest.approx((up - dn) / (2 * h), rel=2e-5, abs=2e-6), f"param {p}"
+
+
+# --------------------------------------------------------------------------------------------
+# FITC oracle: the relational checks test/test_sparse.jl makes on a sparse PDMat
+# --------------------------------------------------------------------------------------------
+def _fitc_case(n=300, d=2, m=25, seed=5):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(size=(d, n))
+    xu = rng.uniform(size=(d, m))
+    y = np.sin(4.0 * x.sum(axis=0)) + 0.1 * rng.standard_normal(n)
+    return x, xu, y
+
+
+@pytest.mark.parametrize("spec", [("se_iso", math.log(0.3), 0.2), ("se_ard", [math.log(0.3), math.log(0.5)], 0.0),
+                                  ("sum", ("mat52_iso", math.log(0.4), 0.1), ("rq_iso", 0.0, -0.5, 0.3))],
+                         ids=["se_iso", "se_ard", "mat52+rq"])
+def test_fitc_pdmat_semantics_match_the_dense_matrix(spec):
+    """test_sparse.jl:117-132: logdet / `\\` of the sparse PDMat against Matrix(cK)."""
+    x, xu, y = _fitc_case()
+    f = G.fitc_update_mll(spec, x, xu, y, math.log(0.2), ("const", 0.3))
+    S = G.fitc_dense(f)
+    c = sla.cho_factor(S, lower=False)
+    ym = y - 0.3
+    # (the reference's two 1e-10 nuggets sit inside f but not in Matrix(cK): agreement to ~1e-5 of the scale, as
+    #  test_sparse.jl's own atol 1e-3 allows for)
+    ref_alpha = sla.cho_solve(c, ym)
+    np.testing.assert_allclose(f["alpha"], ref_alpha, rtol=1e-4, atol=1e-5 * np.abs(ref_alpha).max())
+    logdet = 2.0 * np.sum(np.log(np.diag(c[0])))
+    assert abs(f["logdet"] - logdet) < 1e-5 * max(1.0, abs(logdet))
+    mll = -(ym @ sla.cho_solve(c, ym) + logdet + x.shape[1] * math.log(2 * math.pi)) / 2
+    assert abs(f["mll"] - mll) < 1e-5 * max(1.0, abs(mll))
+    # Λ is what makes diag(Σ) exact: diag(Kfu Kuu^-1 Kuf + Λ) = k(x, x) + σ²
+    np.testing.assert_allclose(np.diag(S), G._kdiag(spec, x) + math.exp(2 * math.log(0.2)), rtol=1e-9)
+
+
+def test_fitc_predictions_match_the_dense_conditional():
+    """test_sparse.jl:38-111: μ = Qxf (Qff + Λ)^-1 (y - m) + m(x*),  Σ = Kxx - Qxf (Qff + Λ)^-1 Qfx."""
+    spec = ("se_ard", [math.log(0.3), math.log(0.4)], 0.1)
+    x, xu, y = _fitc_case(n=400, m=30, seed=7)
+    f = G.fitc_update_mll(spec, x, xu, y, math.log(0.15))
+    xs = np.random.default_rng(8).uniform(size=(2, 9))
+    mu, S = G.fitc_predict_f(spec, xu, f, xs, full_cov=True)
+    _, v = G.fitc_predict_f(spec, xu, f, xs)
+    Kux = G.cov(spec, xu, xs)
+    Qxf = Kux.T @ sla.cho_solve((f["Uuu"], False), f["Kuf"])
+    c = sla.cho_factor(G.fitc_dense(f))
+    np.testing.assert_allclose(mu, Qxf @ sla.cho_solve(c, y), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(S, G.cov(spec, xs) - Qxf @ sla.cho_solve(c, Qxf.T), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(v, np.maximum(np.diag(S), 0.0), rtol=0, atol=0)
+
+
+def test_fitc_with_inducing_points_at_the_data_is_the_exact_gp():
+    """m = n, inducing = x: Qff = Kff, Λ = σ² I, so FITC reproduces the exact mll (up to the two 1e-10 nuggets)."""
+    spec = ("mat32_iso", math.log(0.5), 0.0)
+    x, _, y = _fitc_case(n=120, m=5, seed=9)
+    f = G.fitc_update_mll(spec, x, x, y, math.log(0.3))
+    e = G.update_mll(spec, x, y, math.log(0.3))
+    assert abs(f["mll"] - e["mll"]) < 1e-6 * abs(e["mll"])
+    np.testing.assert_allclose(f["alpha"], e["alpha"], rtol=1e-5, atol=1e-6)
+
+
+def test_fitc_extended_precision_oracle_agrees_with_fp64_when_well_conditioned():
+    spec = ("mat32_iso", math.log(0.4), 0.1)
+    x, xu, y = _fitc_case(n=250, m=15, seed=11)
+    a = G.fitc_update_mll(spec, x, xu, y, math.log(0.2), ("const", 0.1))
+    b = G.fitc_update_mll_extended(spec, x, xu, y, math.log(0.2), ("const", 0.1))
+    assert abs(a["mll"] - b["mll"]) < 1e-9 * abs(b["mll"])
+    np.testing.assert_allclose(a["alpha"], b["alpha"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(a["alpha_u"], b["alpha_u"], rtol=1e-6, atol=1e-9)
