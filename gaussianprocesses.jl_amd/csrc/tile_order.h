@@ -56,6 +56,15 @@ GPMI_HD int64_t strip_count(int st, const TileShape& s) {
     return c;
 }
 
+// mode 1: number of tiles in tile-rows < r  (row i keeps min(i + g0 + 1, ntn) tiles)
+GPMI_HD int64_t lower_tiles_before_row(int r, const TileShape& s) {
+    const int64_t off = s.g0;
+    int64_t rt = (int64_t)s.ntn - off - 1;  // first row that already holds all ntn columns
+    if (rt < 0) rt = 0;
+    if (rt > r) rt = r;
+    return rt * (rt + 1) / 2 + off * rt + ((int64_t)r - rt) * s.ntn;
+}
+
 GPMI_HD int64_t tile_count(const TileShape& s) {
     int64_t c = 0;
     const int ns = (s.ntm + TILE_GROUP - 1) / TILE_GROUP;
@@ -65,11 +74,33 @@ GPMI_HD int64_t tile_count(const TileShape& s) {
 
 // t in [0, tile_count) -> (ti, tj)
 GPMI_HD void tile_decode(int64_t t, const TileShape& s, int* ti, int* tj) {
+    if (s.mode == 0) {  // every full strip holds TILE_GROUP * ntn tiles: no scan (a 1e6-row product has ~1000 strips)
+        const int64_t per = (int64_t)TILE_GROUP * s.ntn;
+        const int st0 = (int)(t / per);
+        t -= (int64_t)st0 * per;
+        const int r00 = st0 * TILE_GROUP;
+        const int h0 = (s.ntm - r00 < TILE_GROUP) ? (s.ntm - r00) : TILE_GROUP;
+        *tj = (int)(t / h0);
+        *ti = r00 + (int)(t % h0);
+        return;
+    }
     int st = 0;
-    for (;; ++st) {
-        const int64_t c = strip_count(st, s);
-        if (t < c) break;
-        t -= c;
+    if (s.mode == 1) {  // closed-form prefix count + bisection over the strips (782 tile rows at N = 100 000)
+        const int ns = (s.ntm + TILE_GROUP - 1) / TILE_GROUP;
+        int lo = 0, hi = ns - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (lower_tiles_before_row(mid * TILE_GROUP, s) <= t) lo = mid;
+            else hi = mid - 1;
+        }
+        st = lo;
+        t -= lower_tiles_before_row(st * TILE_GROUP, s);
+    } else {
+        for (;; ++st) {
+            const int64_t c = strip_count(st, s);
+            if (t < c) break;
+            t -= c;
+        }
     }
     const int r0 = st * TILE_GROUP;
     const int h = (s.ntm - r0 < TILE_GROUP) ? (s.ntm - r0) : TILE_GROUP;

@@ -31,7 +31,8 @@ for n, m in sizes:
         Kuu = np.asarray(g.cov(gp.kernel, xu)) + 1e-10 * np.eye(m)
         c = sla.cho_factor(Kuu)
         W = sla.solve_triangular(c[0], Kuf, trans="T", lower=False)
-        lam = math.exp(2 * gp.logNoise) + 1.0 - (W * W).sum(axis=0)
+        kdiag = math.exp(2.0 * gp.kernel.get_params()[-1])   # SEArd: sigma_f^2
+        lam = math.exp(2 * gp.logNoise) + kdiag - (W * W).sum(axis=0)
         a = np.asarray(gp.alpha, dtype=np.float64)
         res = W.T @ (W @ a) + lam * a - y
         print(f"   Woodbury residual |Sigma alpha - r|_inf / |r|_inf = {np.abs(res).max() / np.abs(y).max():.2e}", flush=True)
