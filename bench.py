@@ -154,6 +154,8 @@ def _main_json(args, world, elapsed, gp, n, d, p, fl_syrk, ms_syrk, n_syrk, ms_c
             "panel_potf2_trsm_update": ms_pan / args.steps,
             "alpha_solve_mll": ms_sol / args.steps,
             "predict": ms_pre / args.steps,
+            "note": "per-class sums of HIP-event intervals; the panel chain runs on a side stream UNDER the trailing update "
+                    "(look-ahead), so the classes overlap and do not add up to ms_per_step",
         },
         "first_fit_incl_upload_s": t_build,
     }

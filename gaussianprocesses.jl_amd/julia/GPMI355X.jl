@@ -15,7 +15,7 @@ using GaussianProcesses
 using GaussianProcesses: GPE, GPBase, Kernel, Mean, KernelData, EmptyData, CovarianceStrategy,
     SEIso, SEArd, Mat12Iso, Mat12Ard, Mat32Iso, Mat32Ard, Mat52Iso, Mat52Ard, RQIso, RQArd,
     Noise, Const, SumKernel, ProdKernel, Masked, FixedKernel, get_value, log2π
-import GaussianProcesses: alloc_cK, update_cK!, update_mll!, update_dmll!, grad_stack, num_params, predictMVN, predict_f, mat, cholfactors, wrap_cK
+import GaussianProcesses: alloc_cK, update_cK!, update_mll!, update_dmll!, grad_stack, num_params, get_alpha_u, predictMVN, predict_f, mat, cholfactors, wrap_cK
 using PDMats
 import PDMats: dim, whiten!, whiten, unwhiten!
 using LinearAlgebra
@@ -217,5 +217,70 @@ predictMVN(xpred::AbstractMatrix, xtrain::AbstractMatrix, ytrain::AbstractVector
 # convenience constructor, as SoR(...)/FITC(...) are (src/sparse/subsetofregressors.jl:324-327)
 GP_hip(x::AbstractMatrix, y::AbstractVector, m::Mean, k::Kernel, logNoise=-2.0) = GPE(x, y, m, k, logNoise, HIPCovariance())
 
-export HIPCovariance, HIPPDMat, GP_hip
+# ---- FITC (src/sparse/fully_indep_train_conditional.jl) on the device ------------------------------------
+# HIPFITC plays FullyIndepStrat's role (:111-113); HIPFITCPDMat the FullyIndepPDMat's (:8-19): the n x m matrices,
+# Lambda and both factors stay in HBM (gpmi_fitc_*), only alpha / mll / predictions cross the bus.
+struct HIPFITC{M<:AbstractMatrix} <: GaussianProcesses.SparseStrategy
+    inducing::M
+end
+mutable struct HIPFITCPDMat <: GaussianProcesses.SparsePDMat{Float64}
+    handle::Ptr{Cvoid}   # gpmi_fitc*
+    n::Int
+    inducing::Matrix{Float64}
+    xref::Any
+    function HIPFITCPDMat(n, inducing)
+        a = new(C_NULL, n, Matrix{Float64}(inducing), nothing)
+        finalizer(a) do a
+            a.handle == C_NULL || ccall((:gpmi_fitc_destroy, libgpmi), Cvoid, (Ptr{Cvoid},), a.handle)
+        end
+    end
+end
+alloc_cK(s::HIPFITC, nobs) = HIPFITCPDMat(nobs, s.inducing)             # replaces fully_indep…:118-132
+GaussianProcesses.KernelData(k::Kernel, X1::AbstractMatrix, X2::AbstractMatrix, ::HIPFITC) = EmptyData()
+Base.size(a::HIPFITCPDMat) = (a.n, a.n); Base.size(a::HIPFITCPDMat, i::Int) = a.n; dim(a::HIPFITCPDMat) = a.n
+function ensure_handle!(a::HIPFITCPDMat, x::Matrix{Float64})
+    if a.handle == C_NULL || a.xref !== x
+        a.handle == C_NULL || ccall((:gpmi_fitc_destroy, libgpmi), Cvoid, (Ptr{Cvoid},), a.handle)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        rc = ccall((:gpmi_fitc_create, libgpmi), Cint,
+                   (Ptr{Cvoid}, Cint, Cint, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Ptr{Cvoid}}),
+                   context(), 64, size(x, 1), size(x, 2), x, size(a.inducing, 2), a.inducing, h)
+        check(context(), rc); a.handle = h[]; a.xref = x; a.n = size(x, 2)
+    end
+    a
+end
+# update_mll! (src/GPE.jl:202-212) over update_cK!(::FullyIndepPDMat) (:134-156), its `\` (:38-41) and logdet (:80)
+function update_mll!(gp::GPE{X,Y,M,K,<:HIPFITC}; noise::Bool=true, domean::Bool=true, kern::Bool=true) where {X,Y,M,K}
+    ensure_handle!(gp.cK, gp.x)
+    ymμ = Vector{Float64}(gp.y - mean(gp.mean, gp.x))
+    length(gp.alpha) == gp.nobs || (gp.alpha = Vector{Float64}(undef, gp.nobs))
+    mll = Ref{Float64}(NaN); info = Ref{Int64}(0)
+    rc = withkernel(descriptor(gp.kernel)) do ck
+        ccall((:gpmi_fitc_fit, libgpmi), Cint,
+              (Ptr{Cvoid}, Ref{CKernel}, Float64, Ptr{Float64}, Ref{Float64}, Ptr{Float64}, Ref{Int64}),
+              gp.cK.handle, ck, Float64(get_value(gp.logNoise)), ymμ, mll, gp.alpha, info)
+    end
+    check(context(), rc, info[]); gp.mll = mll[]; gp
+end
+# predictMVN(::FullyIndepStrat) (:321-329 -> determ_train_conditional.jl:41-59 -> subsetofregressors.jl:303-321)
+function predict_f(gp::GPE{X,Y,M,K,<:HIPFITC}, x::AbstractMatrix; full_cov::Bool=false) where {X,Y,M,K}
+    size(x, 1) == gp.dim || throw(ArgumentError("Gaussian Process object and input observations do not have consistent dimensions"))
+    xp = Matrix{Float64}(x); P = size(xp, 2)
+    mx = Vector{Float64}(mean(gp.mean, xp)); μ = Vector{Float64}(undef, P)
+    Σ = full_cov ? Matrix{Float64}(undef, P, P) : Vector{Float64}(undef, P)
+    rc = withkernel(descriptor(gp.kernel)) do ck
+        ccall((:gpmi_fitc_predict, libgpmi), Cint,
+              (Ptr{Cvoid}, Ref{CKernel}, Int64, Ptr{Float64}, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Float64}),
+              gp.cK.handle, ck, P, xp, mx, full_cov ? 1 : 0, μ, Σ)
+    end
+    check(context(), rc); μ, Σ
+end
+function get_alpha_u(a::HIPFITCPDMat, args...)                           # fully_indep…:279-286
+    au = Vector{Float64}(undef, size(a.inducing, 2))
+    check(context(), ccall((:gpmi_fitc_alpha_u, libgpmi), Cint, (Ptr{Cvoid}, Ptr{Float64}), a.handle, au)); au
+end
+FITC_hip(x::AbstractMatrix, inducing::AbstractMatrix, y::AbstractVector, m::Mean, k::Kernel, logNoise::Real) =
+    GPE(x, y, m, k, logNoise, HIPFITC(inducing))                        # as FITC(...) :333-336
+
+export HIPCovariance, HIPPDMat, GP_hip, HIPFITC, HIPFITCPDMat, FITC_hip
 end # module
