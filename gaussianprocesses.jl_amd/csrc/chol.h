@@ -112,14 +112,14 @@ inline void whiten_rows(gpmi_ctx* c, const T* A, int64_t ld, const T* linv, int6
 // one NB-wide panel: per 64 columns diag64 (factor + invert the diagonal block) and rows64 over every row below
 // (left-looking update inside the panel + TRSM as a product with the inverse + diagonal-block updates)
 template <typename T>
+inline void factor_panel_diag(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, int64_t k0, int64_t nbk, int* d_info);
+template <typename T>
+inline void factor_panel_below(gpmi_ctx* c, T* A, int64_t ld, const T* linv, int64_t k0, int64_t nbk, int64_t Mtot,
+                               const int* d_info);
+template <typename T>
 inline void factor_panel(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, int64_t k0, int64_t nbk, int64_t Mtot, int* d_info) {
-    const int64_t kend = k0 + nbk;
-    for (int64_t j0 = k0; j0 < kend; j0 += IB) {
-        T* linv_j = linv + (j0 / IB) * IB * IB;
-        launch_diag64<T>(c, A + j0 * ld + j0, ld, linv_j, invdiag + j0, d_info, j0);
-        const int64_t r0 = j0 + IB;
-        launch_rows64<T>(c, A + r0 * ld + k0, ld, Mtot - r0, (int)(j0 - k0), A + j0 * ld + k0, ld, linv_j, kend - r0, d_info);
-    }
+    factor_panel_diag<T>(c, A, ld, linv, invdiag, k0, nbk, d_info);
+    factor_panel_below<T>(c, A, ld, linv, k0, nbk, Mtot, d_info);
 }
 // the same panel in two parts: the serial chain on the nbk x nbk diagonal block (one to three workgroups per launch) ...
 template <typename T>
@@ -138,6 +138,14 @@ template <typename T>
 inline void factor_panel_below(gpmi_ctx* c, T* A, int64_t ld, const T* linv, int64_t k0, int64_t nbk, int64_t Mtot,
                                const int* d_info) {
     const int64_t kend = k0 + nbk;
+    // one fused launch when every workgroup gets a CU to itself (rows256 keeps 64 x 256 of X in registers: one workgroup
+    // per CU; with more row blocks than CUs it would run in two rounds and lose to the four rows64 launches);
+    // the refinement step lives in rows64 only
+    if (!c->refine_solves && (Mtot - kend + IB - 1) / IB <= c->num_cus) {
+        launch_rows256<T>(c, A + kend * ld + k0, ld, Mtot - kend, (int)(nbk / IB), A + k0 * ld + k0, ld, linv + (k0 / IB) * IB * IB,
+                          d_info);
+        return;
+    }
     for (int64_t j0 = k0; j0 < kend; j0 += IB)
         launch_rows64<T>(c, A + kend * ld + k0, ld, Mtot - kend, (int)(j0 - k0), A + j0 * ld + k0, ld,
                          linv + (j0 / IB) * IB * IB, 0, d_info);

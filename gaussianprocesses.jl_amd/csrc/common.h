@@ -195,6 +195,12 @@ template <typename T>
 void launch_rows64(gpmi_ctx* ctx, T* Xp, int64_t ldx, int64_t M, int K1, const T* Lp, int64_t ldl, const T* linv,
                    int64_t diag_rows, const int* info);
 
+// The whole panel step (nsub <= 4 column blocks of 64) for rows BELOW the panel's diagonal block, one launch:
+//   Xp: the rows at the panel's first column; Lp: the panel's diagonal block (ldl); linv: its nsub stored 64 x 64 inverses
+template <typename T>
+void launch_rows256(gpmi_ctx* ctx, T* Xp, int64_t ldx, int64_t M, int nsub, const T* Lp, int64_t ldl, const T* linv,
+                    const int* info);
+
 // X[M x 64] <- X * L11^-T  (row-wise forward substitution against the 64 x 64 lower L11)
 template <typename T>
 void launch_trsm_rows(gpmi_ctx* ctx, T* X, int64_t ldx, const T* L11, int64_t ldl, const T* invdiag, int64_t M,
