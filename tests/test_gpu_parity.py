@@ -385,3 +385,33 @@ def test_optimize_with_device_gradient_matches_reference_contract():
     after = gp.get_params()
     assert after[1] == before[1]  # the mean parameter was not optimised
     assert res.nfev < 40           # a gradient-based run, not a finite-difference one
+
+
+# --------------------------------------------------------------------------------------------
+# look-ahead Cholesky / whitening: sizes on both sides of its thresholds, and a pivot that
+# fails on the side stream while a trailing update is in flight
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,p", [(1100, 64), (4700, 300), (6100, 1500)])
+def test_lookahead_transitions_vs_oracle(n, p):
+    x, y, xs = G.synthetic_inputs(n, 4, p=p)
+    spec = ("sum", ("se_ard", [math.log(0.4), math.log(0.5), math.log(0.6), math.log(0.7)], 0.0), ("mat32_iso", math.log(0.8), -0.5))
+    gp, ref = _fit_both(spec, x, y, math.log(0.15))
+    assert gp.mll == pytest.approx(ref["mll"], rel=1e-9)
+    _close(gp.alpha, ref["alpha"], 1e-6, 1e-8 * np.abs(ref["alpha"]).max(), "alpha")
+    mu, s2 = gp.predict_f(xs)
+    mu_o, s2_o = G.predict_f(spec, x, ref, xs)
+    _close(mu, mu_o, 1e-6, 1e-8, "mu")
+    _close(s2, s2_o, 1e-5, 1e-9, "sigma2")
+
+
+def test_not_posdef_during_lookahead():
+    """The failing pivot (1301) belongs to a diagonal block that is factored on the side stream under a trailing update."""
+    n = 6200
+    x = np.arange(n, dtype=np.float64)[None, :]
+    x[0, 1300] = x[0, 40]
+    y = np.random.default_rng(1).standard_normal(n)
+    with pytest.raises(g.PosDefException) as ei:
+        g.GP(x, y, g.MeanZero(), g.SEIso(-3.0, 0.0), -400.0)
+    assert ei.value.info == 1301
+    gp = g.GP(x, y, g.MeanZero(), g.SEIso(-3.0, 0.0), -1.0)  # the context is still usable afterwards
+    assert np.isfinite(gp.mll)
