@@ -315,6 +315,27 @@ static int grad_t(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, do
     return GPMI_OK;
 }
 
+// diag((K + noise)^-1) = squared row norms of L^-T (whitened identity): what predict_LOO needs (crossvalidation.jl:8-13)
+template <typename T>
+static int inv_diag_t(gpmi_gp* gp, void* out) {
+    gpmi_ctx* c = gp->ctx;
+    const int64_t n = gp->n, npad = gp->npad, ld = gp->ld;
+    la_reset(c);
+    const size_t bytes = (size_t)(npad * ld) * sizeof(T);
+    if (!gp->g1) GPMI_HIP(c, hipMalloc(&gp->g1, bytes));
+    if (!gp->g2) GPMI_HIP(c, hipMalloc(&gp->g2, bytes));
+    T* G1 = (T*)gp->g1;
+    T* G2 = (T*)gp->g2;
+    launch_set_identity<T>(c, G2, ld, npad);
+    whiten_rows_inv<T>(c, (const T*)gp->A, ld, (const T*)gp->linv256, npad, G2, ld, G1, ld, [](int64_t kend) { return kend; });
+    // row i of G1 is written from the first column of its own NB-block on (zero left of that in exact arithmetic)
+    launch_row_sumsq<T>(c, G1, ld, n, npad, NB, G2);  // G2 is free again: result vector
+    GPMI_HIP(c, hipMemcpyAsync(out, G2, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    GPMI_HIP(c, hipStreamSynchronize(c->stream));
+    GPMI_HIP(c, hipGetLastError());
+    return GPMI_OK;
+}
+
 int grow(gpmi_ctx* c, void** p, int64_t* cap, int64_t need_bytes) {
     if (*cap >= need_bytes) return GPMI_OK;
     if (*p) hipFree(*p);
@@ -657,6 +678,14 @@ int gpmi_whiten(gpmi_gp* gp, int64_t nrhs, void* b) {
     if (nrhs <= 0 || !b) return GPMI_EARG;
     GPMI_HIP(gp->ctx, hipSetDevice(gp->ctx->device));
     return gp->dtype == 64 ? solve_t<double>(gp, nrhs, b, false) : solve_t<float>(gp, nrhs, b, false);
+}
+
+int gpmi_inv_diag(gpmi_gp* gp, void* out) {
+    if (!gp || !out) return GPMI_EARG;
+    int rc = need_fit(gp, "gpmi_inv_diag");
+    if (rc != GPMI_OK) return rc;
+    hipSetDevice(gp->ctx->device);
+    return gp->dtype == 64 ? gpmi::inv_diag_t<double>(gp, out) : gpmi::inv_diag_t<float>(gp, out);
 }
 
 int gpmi_logdet(gpmi_gp* gp, double* out) {

@@ -228,6 +228,10 @@ void launch_row_gemv(gpmi_ctx* ctx, const T* R, int64_t ldr, int64_t P, int64_t 
 template <typename T>
 void launch_row_var(gpmi_ctx* ctx, const T* R, int64_t ldr, int64_t P, int64_t n, double kdiag, T* var);
 
+// out[p] = sum_{j >= (p / blk) * blk} R[p][j]^2   (blk = 0: whole row)
+template <typename T>
+void launch_row_sumsq(gpmi_ctx* ctx, const T* R, int64_t ldr, int64_t P, int64_t n, int64_t blk, T* out);
+
 template <typename T>
 void launch_logdiag(gpmi_ctx* ctx, const T* A, int64_t ld, int64_t nrows, int64_t col_off, double* out);
 

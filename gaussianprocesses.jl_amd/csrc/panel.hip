@@ -811,6 +811,28 @@ __global__ __launch_bounds__(256) void row_var_kernel(const T* __restrict__ R, i
     }
 }
 
+// out[p] = sum_{j >= j0(p)} R[p][j]^2,  j0(p) = (p / blk) * blk for blk > 0 (rows of a block upper-triangular matrix whose
+// entries left of the row's own block were never written), 0 otherwise
+template <typename T>
+__global__ __launch_bounds__(256) void row_sumsq_kernel(const T* __restrict__ R, int64_t ldr, int64_t n, int64_t blk,
+                                                        T* __restrict__ out) {
+    __shared__ double sh[256];
+    const T* row = R + (int64_t)blockIdx.x * ldr;
+    double s = 0.0;
+    const int64_t j0 = blk > 0 ? ((int64_t)blockIdx.x / blk) * blk : 0;
+    for (int64_t j = j0 + threadIdx.x; j < n; j += 256) {
+        const double v = (double)row[j];
+        s += v * v;
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = (T)sh[0];
+}
+
 }  // namespace
 
 template <typename T>
@@ -874,6 +896,12 @@ void launch_row_var(gpmi_ctx* ctx, const T* R, int64_t ldr, int64_t P, int64_t n
 }
 
 template <typename T>
+void launch_row_sumsq(gpmi_ctx* ctx, const T* R, int64_t ldr, int64_t P, int64_t n, int64_t blk, T* out) {
+    if (P <= 0) return;
+    hipLaunchKernelGGL(row_sumsq_kernel<T>, dim3((unsigned)P), dim3(256), 0, ctx->stream, R, ldr, n, blk, out);
+}
+
+template <typename T>
 void launch_logdiag(gpmi_ctx* ctx, const T* A, int64_t ld, int64_t nrows, int64_t col_off, double* out) {
     hipLaunchKernelGGL(logdiag_kernel<T>, dim3(1), dim3(1024), 0, ctx->stream, A, ld, nrows, col_off, out);
 }
@@ -890,6 +918,7 @@ void launch_logdiag(gpmi_ctx* ctx, const T* A, int64_t ld, int64_t nrows, int64_
     template void launch_finalize<T>(gpmi_ctx*, const T*, int64_t, int64_t, const T*, const T*, double*);         \
     template void launch_row_gemv<T>(gpmi_ctx*, const T*, int64_t, int64_t, int64_t, const T*, const T*, T*);     \
     template void launch_row_var<T>(gpmi_ctx*, const T*, int64_t, int64_t, int64_t, double, T*);                  \
+    template void launch_row_sumsq<T>(gpmi_ctx*, const T*, int64_t, int64_t, int64_t, int64_t, T*);               \
     template void launch_logdiag<T>(gpmi_ctx*, const T*, int64_t, int64_t, int64_t, double*);
 INST(double)
 INST(float)

@@ -72,6 +72,12 @@ class HIPPDMat:
         self.ctx.check(_lib.load().gpmi_logdet(self.h, C.byref(out)))
         return out.value
 
+    def inv_diag(self):
+        """diag(inv(cK)) — the only part of `inv(Σ)` predict_LOO uses (crossvalidation.jl:8-13)."""
+        out = np.empty(self.n, dtype=_lib.np_dtype(self.bits))
+        self.ctx.check(_lib.load().gpmi_inv_diag(self.h, out.ctypes.data))
+        return out
+
     def cholfactors(self):
         """Upper factor U (n × n), as Cholesky(factors, 'U', 0) holds it (GPE.jl:60)."""
         U = np.empty((self.n, self.n), dtype=_lib.np_dtype(self.bits), order="F")
@@ -214,6 +220,33 @@ class GPE:
         self.ctx.check(rc)
         return mu, var
 
+    # -- leave-one-out : src/crossvalidation.jl:8-13, 31-37, 50-58 ---------------------
+    def predict_LOO(self):
+        """(μᵢ, σᵢ²) of yᵢ given y₋ᵢ for every observation: σᵢ² = 1 / (Σ⁻¹)ᵢᵢ, μᵢ = yᵢ − αᵢ σᵢ²."""
+        if self.covstrat is not None:
+            raise _lib.ArgumentError("predict_LOO covers the exact path only")
+        s2 = 1.0 / np.asarray(self.cK.inv_diag(), dtype=np.float64)
+        return self.y - np.asarray(self.alpha, dtype=np.float64) * s2, s2
+
+    def logp_LOO(self):
+        mu, s2 = self.predict_LOO()
+        return float(np.sum(-0.5 * np.log(2.0 * np.pi * s2) - 0.5 * (self.y - mu) ** 2 / s2))
+
+    # -- rand(gp, x, n) : src/GP.jl:120-146 (posterior branch) ------------------------
+    def rand(self, x, n=1, nugget=1e-10, rng=None):
+        """Posterior draws at the columns of x: μ + unwhiten(Σ + nugget·I, randn) with (μ, Σ) = predict_f(full_cov=true).
+        The P × P factorisation is host work, like the reference's."""
+        rng = rng if rng is not None else np.random.default_rng()
+        mu, S = self.predict_f(x, full_cov=True)
+        S = np.array(S, dtype=np.float64)
+        S[np.diag_indices_from(S)] += nugget
+        try:
+            L = np.linalg.cholesky(S)
+        except np.linalg.LinAlgError as e:
+            raise _lib.PosDefException(-1) from e
+        out = np.asarray(mu, dtype=np.float64)[:, None] + L @ rng.standard_normal((S.shape[0], n))
+        return out
+
     def noise_variance(self):  # GPE.jl:269-271
         return np.exp(2.0 * np.asarray(self.logNoise))
 
@@ -264,6 +297,14 @@ def FITC(x, inducing, y, mean=None, kernel=None, logNoise=-2.0, **kw):
     """FITC(x, inducing, y, mean, kernel, logNoise) — src/sparse/fully_indep_train_conditional.jl:333-336."""
     from .sparse import FullyIndepStrat
     return GPE(x, y, mean, kernel, logNoise, covstrat=FullyIndepStrat(inducing), **kw)
+
+
+def predict_LOO(gp):
+    return gp.predict_LOO()
+
+
+def logp_LOO(gp):
+    return gp.logp_LOO()
 
 
 # functional spellings of the reference's exported verbs

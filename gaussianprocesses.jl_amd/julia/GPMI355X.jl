@@ -193,6 +193,13 @@ function cholfactors(a::HIPPDMat)                                       # src/GP
     U = Matrix{Float64}(undef, a.n, a.n)
     check(context(), ccall((:gpmi_factor_to_host, libgpmi), Cint, (Ptr{Cvoid}, Ptr{Float64}), a.handle, U)); U
 end
+# predict_LOO(Σ, alpha, y) (src/crossvalidation.jl:8-13) needs only diag(inv(Σ)): n^3/3 on the device instead of inv(Σ)
+function GaussianProcesses.predict_LOO(a::HIPPDMat, alpha::AbstractVector{<:Real}, y::AbstractVector{<:Real})
+    d = Vector{Float64}(undef, a.n)
+    check(context(), ccall((:gpmi_inv_diag, libgpmi), Cint, (Ptr{Cvoid}, Ptr{Float64}), a.handle, d))
+    σi2 = 1 ./ d
+    return -alpha .* σi2 .+ y, σi2
+end
 Base.Matrix(a::HIPPDMat) = (U = UpperTriangular(cholfactors(a)); Matrix(U' * U))
 mat(a::HIPPDMat) = Matrix(a)                                            # K is regenerated on demand, never resident
 

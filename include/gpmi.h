@@ -160,6 +160,9 @@ int gpmi_cov(gpmi_ctx*, const gpmi_kernel*, int dtype, int d, int64_t n1, const 
  * b_inout is n x nrhs col-major, overwritten with the result.               */
 int gpmi_solve(gpmi_gp*, int64_t nrhs, void* b_inout);  /* (K + noise)^-1 b     */
 int gpmi_whiten(gpmi_gp*, int64_t nrhs, void* b_inout); /* L^-1 b,  L = U'      */
+/* out[i] = ((K + noise)^-1)_ii, n elements: what predict_LOO needs — inv(Σ) / diag in src/crossvalidation.jl:8-13
+ * (SURVEY 8f rank 4).  n^3/3 flops on the device instead of the reference's dense inverse. */
+int gpmi_inv_diag(gpmi_gp*, void* out);
 int gpmi_logdet(gpmi_gp*, double* out);                 /* 2 sum log U_ii       */
 /* U_out: n x n col-major with the upper factor in its upper triangle and zeros
  * below (== Cholesky(factors,'U',0), src/GPE.jl:60).                        */

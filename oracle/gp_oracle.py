@@ -624,3 +624,11 @@ def fitc_update_mll_extended(spec, x, xu, y, log_noise, mspec=("zero",)):
     mll = -(r @ alpha + logdet + LD(LOG2PI) * x.shape[1]) / 2
     return {"mll": float(mll), "alpha": alpha.astype(np.float64), "alpha_u": au.astype(np.float64),
             "lam": lam.astype(np.float64), "logdet": float(logdet)}
+
+
+def predict_loo(fit, y):
+    """predict_LOO(Σ, alpha, y) — src/crossvalidation.jl:8-13: σᵢ² = 1 / (Σ⁻¹)ᵢᵢ, μᵢ = yᵢ − αᵢ σᵢ²."""
+    U = fit["U"]
+    invS = sla.cho_solve((U, False), np.eye(U.shape[0]))
+    s2 = 1.0 / np.diag(invS)
+    return np.asarray(y, dtype=np.float64) - fit["alpha"] * s2, s2

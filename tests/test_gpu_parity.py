@@ -415,3 +415,30 @@ def test_not_posdef_during_lookahead():
     assert ei.value.info == 1301
     gp = g.GP(x, y, g.MeanZero(), g.SEIso(-3.0, 0.0), -1.0)  # the context is still usable afterwards
     assert np.isfinite(gp.mll)
+
+
+# --------------------------------------------------------------------------------------------
+# predict_LOO / logp_LOO (src/crossvalidation.jl) and rand (src/GP.jl:120-146)
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [150, 700, 1500])
+def test_predict_loo_matches_the_oracle(n):
+    x, y, _ = G.synthetic_inputs(n, 3, p=4)
+    spec = ("sum", ("se_ard", [math.log(0.4), math.log(0.5), math.log(0.6)], 0.0), ("mat32_iso", math.log(0.8), -0.5))
+    gp, ref = _fit_both(spec, x, y, math.log(0.15))
+    mu, s2 = gp.predict_LOO()
+    mu_o, s2_o = G.predict_loo(ref, y)
+    _close(s2, s2_o, 1e-7, 1e-12, "loo variance")
+    _close(mu, mu_o, 1e-7, 1e-9, "loo mean")
+    ref_lp = float(np.sum(-0.5 * np.log(2 * np.pi * s2_o) - 0.5 * (y - mu_o) ** 2 / s2_o))
+    assert gp.logp_LOO() == pytest.approx(ref_lp, rel=1e-8)
+
+
+def test_rand_draws_have_the_predictive_moments():
+    """test/gp.jl:62-64 draws samples; here their first two moments are checked against predict_f(full_cov=true)."""
+    x, y, xs = G.synthetic_inputs(300, 2, p=6)
+    gp = g.GP(x, y, g.MeanZero(), g.SEArd([math.log(0.4), math.log(0.5)], 0.0), math.log(0.2))
+    mu, S = gp.predict_f(xs, full_cov=True)
+    draws = gp.rand(xs, n=40000, rng=np.random.default_rng(3))
+    assert draws.shape == (6, 40000)
+    np.testing.assert_allclose(draws.mean(axis=1), mu, atol=4 * np.sqrt(np.diag(S).max() / 40000) + 1e-3)
+    np.testing.assert_allclose(np.cov(draws), S, atol=0.03 * np.abs(S).max() + 1e-4)

@@ -315,3 +315,20 @@ def test_fitc_extended_precision_oracle_agrees_with_fp64_when_well_conditioned()
     assert abs(a["mll"] - b["mll"]) < 1e-9 * abs(b["mll"])
     np.testing.assert_allclose(a["alpha"], b["alpha"], rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(a["alpha_u"], b["alpha_u"], rtol=1e-6, atol=1e-9)
+
+
+def test_predict_loo_is_refitting_without_the_point():
+    """test_crossvalidation.jl:22-37: the analytic LOO equals predict_y of the model fitted on the other points."""
+    rng = np.random.default_rng(13)
+    n = 40
+    x = rng.uniform(size=(2, n))
+    y = np.sin(3 * x.sum(axis=0)) + 0.1 * rng.standard_normal(n)
+    spec = ("mat52_iso", math.log(0.5), 0.0)
+    ln = math.log(0.2)
+    fit = G.update_mll(spec, x, y, ln)
+    mu, s2 = G.predict_loo(fit, y)
+    for i in (0, 7, 39):
+        keep = np.arange(n) != i
+        f_i = G.update_mll(spec, x[:, keep], y[keep], ln)
+        m_i, v_i = G.predict_y(spec, x[:, keep], f_i, x[:, i:i + 1], ln)
+        assert abs(mu[i] - m_i[0]) < 1e-8 and abs(s2[i] - v_i[0]) < 1e-8
