@@ -10,7 +10,8 @@ perturbed every step so nothing can be cached.  Workload at N=1: BASELINE.json c
 N > 1 (one process per GPU, torchrun): by default every rank runs its own fit (the metric's unit is a fit, the
 units are independent: weak scaling, no data-path collective) and, as an extra "sharded_leg", ONE fit of the same
 size is also run row-block sharded over all GPUs with the RCCL panel all-gather (gpmi355x.dist); `--mode sharded`
-makes that the measured workload instead (strong scaling).
+makes that the measured workload instead (strong scaling).  The extra leg runs AFTER the JSON line has been printed and
+reports on stderr / gpurun_out/sharded_leg_<N>.json.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     — the dominant kernel (Cholesky trailing update, MFMA-bound): algorithmic flops per
@@ -253,19 +254,33 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, d, p, ll, min(args.cpu_sample_n, n))
 
-    # Extra leg (N > 1, replicas mode): the SAME workload as ONE fit row-block sharded over all GPUs, so that the
-    # RCCL panel all-gather path is exercised and timed on real multi-GPU hardware.  It is reported inside the one
-    # JSON line as "sharded_leg"; a failure or a hang there must never cost the main measurement, hence the watchdog.
+    # The ONE JSON line of the contract goes out first: nothing after this point can cost the measurement.
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+    # Extra leg (N > 1, replicas mode): the SAME workload as ONE fit row-block sharded over all GPUs, so that the RCCL
+    # panel all-gather path is exercised and timed on real multi-GPU hardware (this build's containers have one GPU: the
+    # path is covered by gloo / virtual-rank tests only).  Reported on stderr and in gpurun_out/sharded_leg_<N>.json,
+    # never on stdout; a hang is cut by the watchdog.
     if world > 1 and not sharded and not args.no_sharded_leg:
         import threading
 
         done = threading.Event()
 
+        def report(leg):
+            if rank == 0:
+                sys.stderr.write("[sharded_leg] " + json.dumps(leg) + "\n")
+                sys.stderr.flush()
+                try:
+                    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                    with open(os.path.join(ROOT, "gpurun_out", f"sharded_leg_{world}.json"), "w") as fh:
+                        json.dump(leg, fh)
+                except OSError:
+                    pass
+
         def watchdog():
             if not done.wait(240.0):
-                if rank == 0:
-                    out["sharded_leg"] = {"error": "no result within 240 s (watchdog)"}
-                    print(json.dumps(out), flush=True)
+                report({"error": "no result within 240 s (watchdog)"})
                 os._exit(0)
 
         threading.Thread(target=watchdog, daemon=True).start()
@@ -288,17 +303,17 @@ def main():
         except Exception as e:  # noqa: BLE001
             leg = {"error": repr(e)[:300]}
         done.set()
-        if rank == 0:
-            out["sharded_leg"] = leg
+        report(leg)
 
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if dist is not None:
         try:
             dist.barrier()
             dist.destroy_process_group()
         except Exception:  # noqa: BLE001
             pass
+    if world > 1:
+        sys.stdout.flush()
+        os._exit(0)  # skip interpreter teardown of RCCL / HIP objects in multi-process runs
 
 
 if __name__ == "__main__":
