@@ -40,25 +40,37 @@ LOG2PI = math.log(2.0 * math.pi)
 # communicators
 # ------------------------------------------------------------------------------------------------
 class TorchDistComm:
-    """torch.distributed process group (nccl == RCCL on ROCm; gloo for the CPU tests)."""
+    """torch.distributed process group (nccl == RCCL on ROCm; gloo for the CPU tests).
 
-    def __init__(self, group=None):
+    `force` (or GPMI_DIST_FORCE=1) issues the collectives even in a group of one: that is how the RCCL calls themselves —
+    tensor placement, dtypes, contiguity — are exercised on the single-GPU test box (tests/test_gpu_dist.py)."""
+
+    def __init__(self, group=None, force=None):
+        import os
+
+        import torch
         import torch.distributed as dist
 
         self.dist = dist
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self.force = bool(int(os.environ.get("GPMI_DIST_FORCE", "0"))) if force is None else bool(force)
+        # scalars are reduced on the device the backend moves data on
+        self._dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+    def _active(self):
+        return self.world > 1 or self.force
 
     def broadcast(self, t, src):
-        if self.world > 1:
+        if self._active():
             self.dist.broadcast(t, src=src, group=self.group)
 
     def all_gather_rows(self, send, rows_per_rank):
         """send: (rows_per_rank[rank] × w) contiguous.  Returns one (rows × w) tensor per rank."""
         import torch
 
-        if self.world == 1:
+        if not self._active():
             return [send]
         mx = max(rows_per_rank)
         w = send.shape[1]
@@ -71,14 +83,12 @@ class TorchDistComm:
     def all_reduce(self, value, op="sum"):
         import torch
 
-        if self.world == 1:
+        if not self._active():
             return value
         t = torch.tensor([float(value)], dtype=torch.float64, device=self._dev)
         rop = {"sum": self.dist.ReduceOp.SUM, "max": self.dist.ReduceOp.MAX, "min": self.dist.ReduceOp.MIN}[op]
         self.dist.all_reduce(t, op=rop, group=self.group)
         return float(t.item())
-
-    _dev = "cpu"
 
 
 class SingleComm:

@@ -96,3 +96,40 @@ def test_virtual_ranks_not_posdef():
         t.join()
     assert not errs, errs
     assert infos == [301, 301]
+
+
+def test_rccl_collectives_in_a_group_of_one():
+    """The RCCL calls themselves (broadcast / all_gather_into_tensor / all_reduce on the library's device buffers) with the
+    nccl backend in a single-rank group, collectives forced: everything about the real multi-GPU transport that one GPU can
+    exercise.  Runs in a subprocess (its own process group)."""
+    import os
+    import subprocess
+    import sys
+
+    code = r"""
+import math, os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, os.path.join(os.getcwd(), "gaussianprocesses.jl_amd")); sys.path.insert(0, os.getcwd())
+import gpmi355x as g
+from gpmi355x import dist as gd
+from oracle import gp_oracle as G
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29611")
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+rng = np.random.default_rng(3)
+n = 1300
+x = rng.uniform(size=(4, n)); y = np.sin(3 * x.sum(axis=0)) + 0.1 * rng.standard_normal(n); xs = rng.uniform(size=(4, 33))
+spec = ("sum", ("se_ard", [-0.5, -0.3, -0.6, -0.2], 0.2), ("mat52_iso", -0.4, -0.5))
+gp = gd.ShardedGPE(x, y, g.MeanZero(), g.from_spec(spec), math.log(0.1), comm=gd.TorchDistComm(force=True))
+ref = G.update_mll(spec, x, y, math.log(0.1))
+assert abs(gp.mll - ref["mll"]) <= 1e-10 * abs(ref["mll"]), (gp.mll, ref["mll"])
+mu, s2 = gp.predict_f(xs)
+mu_o, s2_o = G.predict_f(spec, x, ref, xs)
+np.testing.assert_allclose(mu, mu_o, rtol=1e-7, atol=1e-9); np.testing.assert_allclose(s2, s2_o, rtol=1e-6, atol=1e-10)
+print("rccl-one-rank ok", gp.mll)
+dist.destroy_process_group()
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "rccl-one-rank ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
