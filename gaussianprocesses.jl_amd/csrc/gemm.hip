@@ -108,22 +108,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
 
     // VARIANT & 128 (tools only): wave 0 accumulates wall-clock ticks (100 MHz) per phase into queue[64 + 4 * blockIdx ...]
     long long tk_pro = 0, tk_loop = 0, tk_epi = 0, tk_n = 0, tk0 = 0, tk1 = 0, tk2 = 0;
-    bool first = true;
+    // static first tile, then one queue pull per processed tile.  The pull for the NEXT tile is issued right after the K
+    // loop, so its round trip to the L2 atomic unit (~2 us) runs under the epilogue instead of in front of the prologue.
+    int64_t t = cbeg + li;
+    __syncthreads();
     for (;;) {
         if constexpr (VARIANT & 128) tk0 = wall_clock64();
-        int64_t t;
-        if (first) {  // static first round
-            first = false;
-            t = cbeg + li;
-            __syncthreads();  // (the epilogue buffers of the previous tile do not exist yet; keeps the loop uniform)
-        } else {
-            if (!qa.use_queue) break;
-            if (tid == 0) s_tile = (long long)(atomicAdd(queue + 8 * xcd, 1ull) - qa.base[xcd]) + cbeg + nloc;
-            __syncthreads();  // also: every wave has left the epilogue's LDS buffers
-            const long long tl = s_tile;
-            __syncthreads();
-            t = __builtin_amdgcn_readfirstlane((int)tl);  // scalar: the decode runs on the SALU
-        }
         if (t >= cend) break;
         if constexpr (VARIANT & 128) tk_n += 1;
         int ti, tj;
@@ -244,6 +234,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
             tk2 = wall_clock64();
             tk_loop += tk2 - tk1;
         }
+        unsigned long long pulled = 0;
+        if (qa.use_queue && tid == 0) pulled = atomicAdd(queue + 8 * xcd, 1ull);
         // ---- epilogue: C -= acc --------------------------------------------------------------
         if constexpr (VARIANT & 2) {
             T sacc = T(0);
@@ -254,13 +246,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
 #pragma unroll
                     for (int r = 0; r < 4; ++r) sacc += acc_get<T>(acc[mi][ni], r);
             if (sacc == T(-1.2345e300)) C[0] = sacc;
-            continue;
         }
         // The accumulators leave in the MFMA lane layout (32-byte row fragments).  They are bounced
         // through a wave-private LDS buffer, 32 rows x 64 columns at a time, and re-read row-major,
         // so that C is read-modified-written with 16 bytes per lane and whole 128-byte lines per row
         // (the fragment-shaped RMW cost 19 % of the kernel: it re-fetched every line four times).
-        {
+        if constexpr (!(VARIANT & 2)) {
             constexpr int VEC = 16 / sizeof(T);  // elements per 16-byte access
             constexpr int LPR = 64 / VEC;        // lanes per 64-column row
             constexpr int RPI = 64 / LPR;        // rows per wave instruction
@@ -268,6 +259,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
             using VT = T __attribute__((ext_vector_type(VEC)));
             T* stg = smem + wv * (32 * 64);
             const int rloc = lane / LPR, cloc = (lane % LPR) * VEC;
+            // (issuing the second pass's C loads together with the first pass's was tried: the 64 extra registers spill)
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
@@ -307,6 +299,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
                 }
             }
         }
+        if (!qa.use_queue) {
+            if constexpr (VARIANT & 128) tk_epi += wall_clock64() - tk2;
+            break;
+        }
+        if (tid == 0) s_tile = (long long)(pulled - qa.base[xcd]) + cbeg + nloc;
+        __syncthreads();  // publishes the next tile; also: every wave has left the epilogue's LDS buffers
+        t = __builtin_amdgcn_readfirstlane((int)s_tile);  // scalar: the decode runs on the SALU
+        // (the next write of s_tile is a whole K loop of barriers away: no second barrier needed)
         if constexpr (VARIANT & 128) {
             const long long tk3 = wall_clock64();
             tk_epi += tk3 - tk2;
