@@ -506,6 +506,7 @@ int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
     }
     if (const char* e = getenv("GPMI_REFINE")) c->refine_default = atoi(e) != 0;
     c->refine_solves = c->refine_default;
+    if (const char* e = getenv("GPMI_GEMM_NI")) c->gemm_ni = atoi(e) == 2 ? 2 : atoi(e) == 4 ? 4 : 0;
     if (const char* e = getenv("GPMI_GEMM_WGS")) c->gemm_wgs_per_cu = atoi(e) == 1 ? 1 : 2;
     if (getenv("GPMI_DEBUG")) fprintf(stderr, "[gpmi] device %d: %d CUs, look-ahead slots %d\n", dev, c->num_cus, c->lookahead_slots);
     *out = c;

@@ -78,6 +78,8 @@ struct gpmi_ctx {
     bool refine_default = false;         // GPMI_REFINE=1: refine everywhere (bring-up / accuracy studies)
     bool refine_solves = false;          // rows64: one refinement step on every product with a stored inverse
                                          // (set for factorisations regularised only by a nugget; panel.hip)
+    int gemm_ni = 0;                     // 0: per launch (gemm.hip); 4: always 128 x 128 tiles, 2 workgroups per CU;
+                                         // 2: always 128 x 64 tiles, 3 per CU (GPMI_GEMM_NI)
     int gemm_wgs_per_cu = 2;             // tools: GPMI_GEMM_WGS=1 runs one workgroup per CU
     int num_cus = 256;                   // CUs the persistent GEMM sizes its grid for on the CURRENT stream
     // look-ahead Cholesky (api.hip: cholesky_lower): the next panel's serial chain runs on side_stream under the

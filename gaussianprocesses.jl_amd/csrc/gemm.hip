@@ -62,8 +62,8 @@ struct QueueArgs {
     int64_t strideA, strideB, strideC;
 };
 
-template <typename T, int VARIANT>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int64_t ldc, const T* __restrict__ A,
+template <typename T, int VARIANT, int NI>
+__global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __restrict__ C, int64_t ldc, const T* __restrict__ A,
                                                          int64_t lda, const T* __restrict__ B, int64_t ldb, int64_t M,
                                                          int64_t N, int64_t K, TileShape shape,
                                                          unsigned long long* __restrict__ queue, QueueArgs qa,
@@ -73,14 +73,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
     using Acc = typename MF::Acc;
     constexpr int E = MF::E;
     constexpr int BK = MF::BK;
-    constexpr int BM = GEMM_BM, BN = GEMM_BN;
+    // NI = 16-column blocks per wave: 4 -> 128 x 128 tiles, two workgroups per CU; 2 -> 128 x 64 tiles (64 x 32 per wave,
+    // half the accumulators, 48 KiB of LDS), THREE workgroups per CU
+    constexpr int BM = GEMM_BM, BN = 32 * NI, WN = 16 * NI;  // WN = columns per wave
 
     // one 64 KiB LDS array: [A buf0 | A buf1 | B buf0 | B buf1] during the K loop, then four
     // wave-private 16 KiB transposition buffers for the epilogue
-    __shared__ __attribute__((aligned(16))) T smem[4 * BM * BK];
+    __shared__ __attribute__((aligned(16))) T smem[2 * (BM + BN) * BK];
     __shared__ long long s_tile;
     T* const As0 = smem;
     T* const Bs0 = smem + 2 * BM * BK;
+    static_assert(2 * (BM + BN) * BK >= 4 * 32 * WN, "epilogue staging does not fit");
 
     const int tid = threadIdx.x;
     const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;  // li-th workgroup of its XCD
@@ -131,15 +134,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
         const T* __restrict__ Bb = B + bi * qa.strideB + n0 * ldb;
         const int mrem = (int)((M - m0 < BM ? M - m0 : BM) - 1);  // last valid local row
         const int nrem = (int)((N - n0 < BN ? N - n0 : BN) - 1);
-        int oa[4], ob[4];
+        int oa[4], ob[NI];  // B slab: BN rows x 8 chunks = 256 threads x NI
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = tid + 256 * i;
             const int row = c >> 3, kc = (c & 7) ^ (row & 7);
             const int ra = row < mrem ? row : mrem;  // rows past M / N re-read the last valid row; never stored
-            const int rb = row < nrem ? row : nrem;
             oa[i] = (int)(ra * lda) + kc * E;
-            ob[i] = (int)(rb * ldb) + kc * E;
+            if (i < NI) {
+                const int rb = row < nrem ? row : nrem;
+                ob[i] = (int)(rb * ldb) + kc * E;
+            }
         }
         auto stage = [&](int buf, int ko) {
 #pragma unroll
@@ -147,17 +152,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ab + oa[i] + ko),
                                                  (__attribute__((address_space(3))) void*)(As0 + buf * BM * BK + (wvu * 64 + 256 * i) * E),
                                                  16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bb + ob[i] + ko),
-                                                 (__attribute__((address_space(3))) void*)(Bs0 + buf * BN * BK + (wvu * 64 + 256 * i) * E),
-                                                 16, 0, 0);
+                if (i < NI)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bb + ob[i] + ko),
+                                                     (__attribute__((address_space(3))) void*)(Bs0 + buf * BN * BK + (wvu * 64 + 256 * i) * E),
+                                                     16, 0, 0);
             }
         };
 
-        Acc acc[4][4];
+        Acc acc[4][NI];
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[mi][ni].v[r] = T(0);
 
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
             // into the MFMA stream (the natural order) every slab waited for the NEXT slab's DMA before computing —
             // no load/compute overlap inside a workgroup (lone-workgroup K loop 2.9 us per slab against 2.08 us of
             // MFMA).  In this order the only wait is the one the end-of-slab barrier needs anyway.
-            Vec af[2][4], bf[2][4];
+            Vec af[2][4], bf[2][NI];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 if constexpr (VARIANT & 16) {
@@ -188,24 +194,28 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
 #pragma unroll
                         for (int e = 0; e < E; ++e) {
                             af[h][q][e] = T(1) + T(lane) * T(1e-3);
-                            bf[h][q][e] = T(0.5) + T(q) * T(1e-3);
+                            if (q < NI) bf[h][q][e] = T(0.5) + T(q) * T(1e-3);
                         }
-                        asm volatile("" : "+v"(af[h][q]), "+v"(bf[h][q]));
+                        asm volatile("" : "+v"(af[h][q]));
+                        if (q < NI) asm volatile("" : "+v"(bf[h][q]));
                     }
                 } else {
                     const T* as = As0 + cur * BM * BK + (wm * 64 + r16) * BK + fo[h];
-                    const T* bs = Bs0 + cur * BN * BK + (wn * 64 + r16) * BK + fo[h];
+                    const T* bs = Bs0 + cur * BN * BK + (wn * WN + r16) * BK + fo[h];
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi) af[h][mi] = *reinterpret_cast<const Vec*>(as + mi * 16 * BK);
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) bf[h][ni] = *reinterpret_cast<const Vec*>(bs + ni * 16 * BK);
+                    for (int ni = 0; ni < NI; ++ni) bf[h][ni] = *reinterpret_cast<const Vec*>(bs + ni * 16 * BK);
                 }
             }
             if constexpr (!(VARIANT & 16)) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(af[h][q]), "+v"(bf[h][q]));  // reads stay above the DMA
+                    for (int q = 0; q < 4; ++q) {  // reads stay above the DMA
+                        asm volatile("" : "+v"(af[h][q]));
+                        if (q < NI) asm volatile("" : "+v"(bf[h][q]));
+                    }
             }
             if (kt + 1 < nk && !(VARIANT & 4)) stage(cur ^ 1, (kt + 1) * BK);
             __builtin_amdgcn_sched_barrier(0);
@@ -214,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) {
+                    for (int ni = 0; ni < NI; ++ni) {
                         T br[4];
                         if constexpr (VARIANT & 8) {
                             br[0] = br[1] = br[2] = br[3] = bf[h][ni][e];
@@ -242,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
+                for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) sacc += acc_get<T>(acc[mi][ni], r);
             if (sacc == T(-1.2345e300)) C[0] = sacc;
@@ -253,11 +263,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
         // (the fragment-shaped RMW cost 19 % of the kernel: it re-fetched every line four times).
         if constexpr (!(VARIANT & 2)) {
             constexpr int VEC = 16 / sizeof(T);  // elements per 16-byte access
-            constexpr int LPR = 64 / VEC;        // lanes per 64-column row
+            constexpr int LPR = WN / VEC;        // lanes per WN-column row
             constexpr int RPI = 64 / LPR;        // rows per wave instruction
             constexpr int NIT = 32 / RPI;
             using VT = T __attribute__((ext_vector_type(VEC)));
-            T* stg = smem + wv * (32 * 64);
+            T* stg = smem + wv * (32 * WN);
             const int rloc = lane / LPR, cloc = (lane % LPR) * VEC;
             // (issuing the second pass's C loads together with the first pass's was tried: the 64 extra registers spill)
 #pragma unroll
@@ -265,13 +275,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni)
+                    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            stg[(mi * 16 + MF::row_of(lane, r)) * 64 + ni * 16 + MF::col_of(lane, r)] =
+                            stg[(mi * 16 + MF::row_of(lane, r)) * WN + ni * 16 + MF::col_of(lane, r)] =
                                 acc_get<T>(acc[2 * hh + mi][ni], r);
                 const int64_t grow0 = m0 + wm * 64 + hh * 32 + rloc;
-                const int64_t gcol = n0 + wn * 64 + cloc;
+                const int64_t gcol = n0 + wn * WN + cloc;
                 VT cv[NIT];
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
@@ -286,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int6
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     const int64_t grow = grow0 + it * RPI;
-                    const VT v = *reinterpret_cast<const VT*>(stg + (it * RPI + rloc) * 64 + cloc);
+                    const VT v = *reinterpret_cast<const VT*>(stg + (it * RPI + rloc) * WN + cloc);
                     if (grow < M) {
                         if (gcol + VEC <= N) {
                             *reinterpret_cast<VT*>(Ct + grow * ldc + gcol) = (flags & GEMM_OVERWRITE) ? v : cv[it] - v;
@@ -352,15 +362,18 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(T* out, int iters) {
 
 }  // namespace
 
-template <typename T, int V>
-static void launch_persistent(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M,
-                              int64_t N, int64_t K, TileShape shape, const int* info, int flags = 0, const GemmBatch* batch = nullptr) {
+template <typename T, int V, int NI>
+static void launch_persistent_ni(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M,
+                                 int64_t N, int64_t K, TileShape shape, const int* info, int flags, const GemmBatch* batch) {
+    constexpr int BN = 32 * NI;
     shape.ntm = (int)((M + GEMM_BM - 1) / GEMM_BM);
-    shape.ntn = (int)((N + GEMM_BN - 1) / GEMM_BN);
+    shape.ntn = (int)((N + BN - 1) / BN);
+    if (NI == 2 && shape.mode == 1) shape.mode = 3;  // the same lower region in 128 x 64 tiles
     const int64_t tiles_per = tile_count(shape);
     const int64_t ntiles = tiles_per * (batch ? batch->count : 1);
     if (ntiles <= 0) return;
-    const int slots = ctx->gemm_wgs_per_cu * ctx->num_cus - ctx->gemm_reserve;  // both multiples of 8
+    const int per_cu = NI == 2 ? (ctx->gemm_wgs_per_cu == 1 ? 1 : 3) : ctx->gemm_wgs_per_cu;
+    const int slots = per_cu * ctx->num_cus - ctx->gemm_reserve;  // both multiples of 8
     // small launches: one workgroup per tile (rounded up to a multiple of 8 so XCD chunks stay contiguous)
     const int grid = (int)std::min<int64_t>(slots, (ntiles + 7) / 8 * 8);
     QueueArgs qa;
@@ -376,14 +389,38 @@ static void launch_persistent(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int6
         // the chunk is smaller than the XCD's workgroup count): the word advances by `chunk` either way
         if (qa.use_queue) ctx->queue_base[x] += (unsigned long long)(qa.start[x + 1] - qa.start[x]);
     }
-    hipLaunchKernelGGL((gemm_nt_kernel<T, V>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, C, ldc, A, lda, B, ldb, M, N,
+    hipLaunchKernelGGL((gemm_nt_kernel<T, V, NI>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, C, ldc, A, lda, B, ldb, M, N,
                        K, shape, ctx->d_queue, qa, info, flags);
+}
+template <typename T, int V>
+static void launch_persistent(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M,
+                              int64_t N, int64_t K, TileShape shape, const int* info, int flags = 0, const GemmBatch* batch = nullptr) {
+    // 128 x 64 tiles with three workgroups per CU for launches that do not fill the chip for long: measured at K = 256
+    // (tools/gemm_phases.py) 16 tiles 49 -> 28 us, 310 tiles 92 -> 70 us, 780 lower tiles 34.5 -> 42 TFLOP/s, and no
+    // difference once there are thousands of tiles.  The look-ahead main launches (gemm_reserve > 0) stay at 128 x 128:
+    // their reserved slots must leave whole half-CUs free for the 256-register chain kernels.  The staircase order of
+    // the sharded path exists for 128 x 128 only.
+    bool narrow = false;
+    if (shape.mode != 2 && ctx->gemm_ni != 4) {
+        if (ctx->gemm_ni == 2) {
+            narrow = true;  // forced (GPMI_GEMM_NI=2)
+        } else if (ctx->gemm_reserve == 0) {
+            TileShape t4 = shape;
+            t4.ntm = (int)((M + GEMM_BM - 1) / GEMM_BM);
+            t4.ntn = (int)((N + GEMM_BN - 1) / GEMM_BN);
+            narrow = tile_count(t4) * (batch ? batch->count : 1) < 2048;
+        }
+    }
+    if (narrow)
+        launch_persistent_ni<T, V, 2>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags, batch);
+    else
+        launch_persistent_ni<T, V, 4>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags, batch);
 }
 
 static double shape_entries(int64_t M, int64_t N, const TileShape& s) {
     if (s.mode == 0) return (double)M * (double)N;
-    if (s.mode == 1) {  // row i keeps columns j <= i + 128 * g0
-        const double off = (double)s.g0 * GEMM_BN;
+    if (s.mode == 1 || s.mode == 3) {  // row i keeps columns j <= i + 128 * g0
+        const double off = (double)s.g0 * GEMM_BM;
         const double tri_rows = std::max(0.0, std::min((double)M, (double)N - off));  // rows still under the diagonal
         return tri_rows * (off + 0.5 * (tri_rows + 1.0)) + ((double)M - tri_rows) * (double)N;
     }

@@ -10,6 +10,7 @@
 //     mode 2 (staircase)   cmax = 2*(g0 + (ti>>1)*G) + (ti&1) for ti < nstair, ntn - 1 beyond
 //                          (row-block-cyclic shard: local 256-row block i is global block g0 + i*G;
 //                           two 128-row tiles per block; rows past the staircase are carried rows)
+//     mode 3 (lower, half-width column tiles: 128 x 64 output tiles)   cmax = 2*(ti + g0) + 1
 // Order: strips of GROUP tile-rows.  Modes 0/1: column-major inside a strip, so GROUP consecutive
 // tiles share one B panel and the strip's GROUP A panels stay hot.  Mode 2: row-major inside a strip.
 #pragma once
@@ -39,6 +40,21 @@ GPMI_HD int stair_cmax(const TileShape& s, int ti) {
     return c;
 }
 
+// modes 1 / 3: number of tiles in tile-rows < r  (row i keeps min(i + g0 + 1, ntn), resp. min(2 (i + g0) + 2, ntn) tiles)
+GPMI_HD int64_t lower_tiles_before_row(int r, const TileShape& s) {
+    const int64_t off = s.g0;
+    if (s.mode == 3) {
+        int64_t rt = (int64_t)s.ntn / 2 - off;  // rows below rt are not capped by ntn
+        if (rt < 0) rt = 0;
+        if (rt > r) rt = r;
+        return rt * rt + (2 * off + 1) * rt + ((int64_t)r - rt) * s.ntn;
+    }
+    int64_t rt = (int64_t)s.ntn - off - 1;  // first row that already holds all ntn columns
+    if (rt < 0) rt = 0;
+    if (rt > r) rt = r;
+    return rt * (rt + 1) / 2 + off * rt + ((int64_t)r - rt) * s.ntn;
+}
+
 GPMI_HD int64_t strip_count(int st, const TileShape& s) {
     const int r0 = st * TILE_GROUP;
     const int h = (s.ntm - r0 < TILE_GROUP) ? (s.ntm - r0) : TILE_GROUP;
@@ -49,20 +65,12 @@ GPMI_HD int64_t strip_count(int st, const TileShape& s) {
         return c;
     }
     const int off = s.g0;
+    if (s.mode == 3) return lower_tiles_before_row(r0 + h, s) - lower_tiles_before_row(r0, s);
     const int nfull = (r0 + off + 1 < s.ntn) ? (r0 + off + 1) : s.ntn;
     int64_t c = (int64_t)h * nfull;
     const int jmax = (r0 + h - 1 + off < s.ntn - 1) ? (r0 + h - 1 + off) : (s.ntn - 1);
     for (int tj = nfull; tj <= jmax; ++tj) c += r0 + h - (tj - off);
     return c;
-}
-
-// mode 1: number of tiles in tile-rows < r  (row i keeps min(i + g0 + 1, ntn) tiles)
-GPMI_HD int64_t lower_tiles_before_row(int r, const TileShape& s) {
-    const int64_t off = s.g0;
-    int64_t rt = (int64_t)s.ntn - off - 1;  // first row that already holds all ntn columns
-    if (rt < 0) rt = 0;
-    if (rt > r) rt = r;
-    return rt * (rt + 1) / 2 + off * rt + ((int64_t)r - rt) * s.ntn;
 }
 
 GPMI_HD int64_t tile_count(const TileShape& s) {
@@ -85,7 +93,7 @@ GPMI_HD void tile_decode(int64_t t, const TileShape& s, int* ti, int* tj) {
         return;
     }
     int st = 0;
-    if (s.mode == 1) {  // closed-form prefix count + bisection over the strips (782 tile rows at N = 100 000)
+    if (s.mode == 1 || s.mode == 3) {  // closed-form prefix count + bisection over the strips (782 tile rows at N = 100 000)
         const int ns = (s.ntm + TILE_GROUP - 1) / TILE_GROUP;
         int lo = 0, hi = ns - 1;
         while (lo < hi) {
@@ -121,6 +129,26 @@ GPMI_HD void tile_decode(int64_t t, const TileShape& s, int* ti, int* tj) {
         }
     }
     const int off = s.g0;
+    if (s.mode == 3) {  // columns kept by every row of the strip first (column-major), then the staircase columns
+        const int full0 = 2 * (r0 + off) + 2;
+        const int nf = full0 < s.ntn ? full0 : s.ntn;
+        if (t < (int64_t)h * nf) {
+            *tj = (int)(t / h);
+            *ti = r0 + (int)(t % h);
+            return;
+        }
+        int q = (int)(t - (int64_t)h * nf);
+        for (int c = nf;; ++c) {
+            const int first = c / 2 - off;  // first row that keeps column c
+            const int n = r0 + h - first;
+            if (q < n) {
+                *tj = c;
+                *ti = first + q;
+                return;
+            }
+            q -= n;
+        }
+    }
     const int nfull = (r0 + off + 1 < s.ntn) ? (r0 + off + 1) : s.ntn;
     if (t < (int64_t)h * nfull) {
         *tj = (int)(t / h);

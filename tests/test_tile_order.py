@@ -18,6 +18,7 @@ static int check(const TileShape& s) {
         for (int j = 0; j < s.ntn; ++j) {
             bool ok = true;
             if (s.mode == 1) ok = j <= i + s.g0;
+            if (s.mode == 3) ok = j <= 2 * (i + s.g0) + 1;
             if (s.mode == 2 && i < s.nstair) ok = j <= 2 * (s.g0 + (i >> 1) * s.G) + (i & 1);
             if (ok) want.insert({i, j});
         }
@@ -35,6 +36,10 @@ int main() {
     for (int off = 1; off <= 3; ++off)
         for (int ntm = 1; ntm <= 30; ++ntm)
             for (int ntn = 1; ntn <= ntm + off; ++ntn) { ++cases; bad += check(TileShape{ntm, ntn, 1, off, 1, 0}); }
+    // lower mode with half-width column tiles (128 x 64 output tiles), with and without the row offset
+    for (int off = 0; off <= 2; ++off)
+        for (int ntm = 1; ntm <= 30; ++ntm)
+            for (int ntn = 1; ntn <= 2 * (ntm + off); ++ntn) { ++cases; bad += check(TileShape{ntm, ntn, 3, off, 1, 0}); }
     // staircase (row-block-cyclic shards): G ranks, first owned block g0, carried rows past the staircase
     for (int G = 1; G <= 4; ++G)
         for (int g0 = 0; g0 < G + 2; ++g0)
