@@ -76,7 +76,7 @@ inline void whiten_rows_inv(gpmi_ctx* c, const T* A, int64_t ld, const T* linv25
         const int64_t Mr1 = rows_upto(k2);  // rows the next block's solve covers (>= Mr)
         // worth it while the rest of the update outlasts the solve it hides (~60 us at 45 TFLOP/s), and only when the
         // next solve needs no rows the update does not already carry
-        const bool ahead = la && k2 < npad && Mr1 == Mr && (double)Mr * (double)(npad - k2) > 5.3e6;
+        const bool ahead = la && k2 < npad && Mr1 == Mr && (double)Mr * (double)(npad - k2) > c->whiten_lookahead_min;
         if (!ahead) {
             launch_gemm_nt<T>(c, R + k1, ldr, V + k0, ldv, A + k1 * ld + k0, ld, Mr, npad - k1, nbk, 0, nullptr);
             continue;

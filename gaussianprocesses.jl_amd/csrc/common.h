@@ -86,6 +86,7 @@ struct gpmi_ctx {
     // trailing update, which leaves lookahead_slots workgroup slots free (gemm_reserve is set around that launch)
     hipStream_t side_stream = nullptr;
     int lookahead_slots = 0;
+    double whiten_lookahead_min = 5.3e6;     // rows x remaining columns below which the whitening runs serially
     int64_t lookahead_min_trailing = 4608;  // trailing size below which the serial order is faster (update < chain)
     int gemm_reserve = 0;
     std::vector<hipEvent_t> la_events;
@@ -202,11 +203,6 @@ void launch_rows64(gpmi_ctx* ctx, T* Xp, int64_t ldx, int64_t M, int K1, const T
 template <typename T>
 void launch_rows256(gpmi_ctx* ctx, T* Xp, int64_t ldx, int64_t M, int nsub, const T* Lp, int64_t ldl, const T* linv,
                     const int* info);
-
-// X[M x 64] <- X * L11^-T  (row-wise forward substitution against the 64 x 64 lower L11)
-template <typename T>
-void launch_trsm_rows(gpmi_ctx* ctx, T* X, int64_t ldx, const T* L11, int64_t ldl, const T* invdiag, int64_t M,
-                      const int* info);
 
 // One step of the backward solve  L' alpha = z  for the 64-block starting at j0:
 //   alpha[j0..j0+64) = Linv_b' z[j0..)  (linv = stored inverse of the diagonal block);  z[0..j0) -= L[j0..j0+64, 0..j0)' alpha_b

@@ -1,10 +1,13 @@
 // panel.hip — the latency-bound pieces around the MFMA update:
-//   potf2      64 x 64 diagonal-block Cholesky, LDS/register resident, ONE wavefront
+//   diag64     64 x 64 diagonal-block Cholesky + explicit inverse, ONE wavefront
 //              (the POTF2 of the blocked dpotrf behind make_posdef!, src/GP.jl:110)
-//   trsm_rows  X <- X * L11^-T, one row per lane (panel solve; also whiten!, src/GP.jl:27)
-//   bsolve     backward substitution L' alpha = z  (second half of cK \ y, src/GPE.jl:208)
+//   rows64     one 64-column panel step for the rows below: left-looking update, TRSM as a product with the stored inverse
+//              (+ optional refinement step), diagonal-block updates (panel solve; also whiten!, src/GP.jl:27)
+//   rows256    the whole 256-column panel step for rows below the diagonal block, in one launch
+//   linv256    explicit inverses of the 256 x 256 diagonal blocks; bsolve256 / bsolve_step: backward substitution
+//              L' alpha = z  (second half of cK \ y, src/GPE.jl:208)
 //   finalize   logdet (PDMats: 2 sum log U_ii) + y'alpha + mll (src/GPE.jl:210)
-//   row_gemv / row_var   predictive mean / variance reductions (src/GP.jl:26,75)
+//   row_gemv / row_var / row_sumsq   predictive mean / variance reductions (src/GP.jl:26,75), diag(K^-1)
 #include "common.h"
 #include "mfma.h"
 
@@ -27,7 +30,7 @@ __device__ __forceinline__ float tsqrt<float>(float x) { return sqrtf(x); }
 //   column j is scaled in place (dpotf2 does the same dscal by the reciprocal);
 //   every other lane's l_cj is fetched with v_readlane into SGPRs and applied as
 //   a_ic -= l_ij * l_cj (c > j) — no LDS round trip, no barrier, one SGPR operand per v_fma_f64.
-// The reciprocals 1 / L_jj are kept in `invdiag` for the solves that follow (trsm_rows, bsolve).
+// The reciprocals 1 / L_jj are kept in `invdiag`.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ T rsqrt_seed(T x);
@@ -480,51 +483,6 @@ __global__ __launch_bounds__(256, 1) void rows256_kernel(T* __restrict__ Xp, int
 }
 
 // ---------------------------------------------------------------------------------------------
-// trsm_rows: X <- X * L11^-T, 64 rows per workgroup (one wavefront), lane r owns row r in registers.
-//   x_k = b_k / L_kk ;  b_j -= x_k * L_jk  (j > k)      — right-looking, full ILP over j.
-// L11 is read from LDS as wave-uniform broadcasts; 1 / L_kk comes from `invdiag` (written by potf2).
-// Measured alternatives that were SLOWER on MI355X (profiles/r01_notes): L through the scalar cache
-// (s_load_dwordx16 + SGPR operands: 55 us — 313 waves x 232 dependent loads of the same 16 KiB) and
-// a transposed LDS image shared by two waves (39 us: the transposing store is a 64-way bank conflict).
-// ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(64) void trsm_rows_kernel(T* __restrict__ X, int64_t ldx, const T* __restrict__ L11,
-                                                       int64_t ldl, const T* __restrict__ invd_g, int64_t M,
-                                                       const int* __restrict__ info) {
-    if (info && *info != 0) return;
-    __shared__ T SL[64 * 64];   // L11, row-major, read uniformly
-    __shared__ T SX[64 * 65];   // X tile (transposition buffer)
-    __shared__ T invd[64];
-    const int t = threadIdx.x;
-    const int64_t row0 = (int64_t)blockIdx.x * 64;
-    for (int r = 0; r < 64; ++r) SL[r * 64 + t] = L11[(int64_t)r * ldl + t];
-    for (int r = 0; r < 64; ++r) {
-        int64_t gr = row0 + r;
-        gr = gr < M ? gr : M - 1;
-        SX[r * 65 + t] = X[gr * ldx + t];
-    }
-    invd[t] = invd_g[t];
-    __syncthreads();
-    T b[64];
-#pragma unroll
-    for (int c = 0; c < 64; ++c) b[c] = SX[t * 65 + c];
-#pragma unroll
-    for (int k = 0; k < 64; ++k) {
-        const T xk = b[k] * invd[k];
-        b[k] = xk;
-#pragma unroll
-        for (int j = k + 1; j < 64; ++j) b[j] -= xk * SL[j * 64 + k];
-    }
-#pragma unroll
-    for (int c = 0; c < 64; ++c) SX[t * 65 + c] = b[c];
-    __syncthreads();
-    for (int r = 0; r < 64; ++r) {
-        const int64_t gr = row0 + r;
-        if (gr < M) X[gr * ldx + t] = SX[r * 65 + t];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // bsolve_step: one 64-block of the backward solve  L' alpha = z.  With the stored inverse of the diagonal block
 // the block solve is a 64 x 64 mat-vec  alpha_b = Linv_b' z_b  (every workgroup recomputes it — cheaper than an
 // extra launch on the critical path), workgroup 0 publishes alpha_b, then all workgroups apply
@@ -857,14 +815,6 @@ void launch_rows256(gpmi_ctx* ctx, T* Xp, int64_t ldx, int64_t M, int nsub, cons
                        linv, info);
 }
 template <typename T>
-void launch_trsm_rows(gpmi_ctx* ctx, T* X, int64_t ldx, const T* L11, int64_t ldl, const T* invdiag, int64_t M,
-                      const int* info) {
-    if (M <= 0) return;
-    ProfScope ps(ctx, GPMI_PROF_PANEL, (double)M * 64.0 * 64.0);
-    hipLaunchKernelGGL(trsm_rows_kernel<T>, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, ctx->stream, X, ldx, L11, ldl,
-                       invdiag, M, info);
-}
-template <typename T>
 void launch_bsolve_step(gpmi_ctx* ctx, const T* Arow, int64_t ld, int64_t j0, const T* linv, T* z, T* alpha) {
     const unsigned blocks = (unsigned)(j0 > 0 ? (j0 + 255) / 256 : 1);
     hipLaunchKernelGGL(bsolve_step_kernel<T>, dim3(blocks), dim3(256), 0, ctx->stream, Arow, ld, j0, linv, z, alpha);
@@ -911,7 +861,6 @@ void launch_logdiag(gpmi_ctx* ctx, const T* A, int64_t ld, int64_t nrows, int64_
     template void launch_rows64<T>(gpmi_ctx*, T*, int64_t, int64_t, int, const T*, int64_t, const T*, int64_t,    \
                                    const int*);                                                                   \
     template void launch_rows256<T>(gpmi_ctx*, T*, int64_t, int64_t, int, const T*, int64_t, const T*, const int*); \
-    template void launch_trsm_rows<T>(gpmi_ctx*, T*, int64_t, const T*, int64_t, const T*, int64_t, const int*);  \
     template void launch_bsolve_step<T>(gpmi_ctx*, const T*, int64_t, int64_t, const T*, T*, T*);                 \
     template void launch_linv256<T>(gpmi_ctx*, const T*, int64_t, const T*, T*, int64_t, const int*);             \
     template void launch_bsolve256<T>(gpmi_ctx*, const T*, int64_t, int64_t, int, const T*, T*, T*);              \
