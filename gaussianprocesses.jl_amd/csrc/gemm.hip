@@ -392,25 +392,22 @@ static void launch_persistent_ni(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, i
     hipLaunchKernelGGL((gemm_nt_kernel<T, V, NI>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, C, ldc, A, lda, B, ldb, M, N,
                        K, shape, ctx->d_queue, qa, info, flags);
 }
+// 128 x 64 tiles with three workgroups per CU for launches that do not fill the chip for long: measured at K = 256
+// (tools/gemm_phases.py) 16 tiles 49 -> 28 us, 310 tiles 92 -> 70 us, 780 lower tiles 34.5 -> 42 TFLOP/s, and no
+// difference once there are thousands of tiles.  The look-ahead main launches (gemm_reserve > 0) stay at 128 x 128:
+// their reserved slots must leave whole half-CUs free for the 256-register chain kernels.  The staircase order of
+// the sharded path exists for 128 x 128 only.
+static bool use_narrow_tiles(const gpmi_ctx* ctx, int64_t M, int64_t N, TileShape shape, const GemmBatch* batch) {
+    if (shape.mode == 2 || ctx->gemm_ni == 4) return false;
+    if (ctx->gemm_ni == 2) return true;  // forced (GPMI_GEMM_NI=2)
+    if (ctx->gemm_reserve != 0) return false;
+    shape.ntm = (int)((M + GEMM_BM - 1) / GEMM_BM);
+    shape.ntn = (int)((N + GEMM_BN - 1) / GEMM_BN);
+    return tile_count(shape) * (batch ? batch->count : 1) < 2048;
+}
 template <typename T, int V>
 static void launch_persistent(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M,
-                              int64_t N, int64_t K, TileShape shape, const int* info, int flags = 0, const GemmBatch* batch = nullptr) {
-    // 128 x 64 tiles with three workgroups per CU for launches that do not fill the chip for long: measured at K = 256
-    // (tools/gemm_phases.py) 16 tiles 49 -> 28 us, 310 tiles 92 -> 70 us, 780 lower tiles 34.5 -> 42 TFLOP/s, and no
-    // difference once there are thousands of tiles.  The look-ahead main launches (gemm_reserve > 0) stay at 128 x 128:
-    // their reserved slots must leave whole half-CUs free for the 256-register chain kernels.  The staircase order of
-    // the sharded path exists for 128 x 128 only.
-    bool narrow = false;
-    if (shape.mode != 2 && ctx->gemm_ni != 4) {
-        if (ctx->gemm_ni == 2) {
-            narrow = true;  // forced (GPMI_GEMM_NI=2)
-        } else if (ctx->gemm_reserve == 0) {
-            TileShape t4 = shape;
-            t4.ntm = (int)((M + GEMM_BM - 1) / GEMM_BM);
-            t4.ntn = (int)((N + GEMM_BN - 1) / GEMM_BN);
-            narrow = tile_count(t4) * (batch ? batch->count : 1) < 2048;
-        }
-    }
+                              int64_t N, int64_t K, TileShape shape, const int* info, int flags, const GemmBatch* batch, bool narrow) {
     if (narrow)
         launch_persistent_ni<T, V, 2>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags, batch);
     else
@@ -434,15 +431,17 @@ template <typename T>
 void launch_gemm_shape(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M,
                        int64_t N, int64_t K, TileShape shape, const int* info, int flags, const GemmBatch* batch) {
     if (M <= 0 || N <= 0 || K <= 0) return;
-    // Two instantiations of the same code so that profilers separate them by name: <T, 0> is the Cholesky trailing
-    // update (the roofline kernel of bench.py), <T, 64> every other product (panel / predict / gradient GEMMs).
-    const bool trailing = shape.mode && !flags;
+    // The same code under different template tags so that profilers separate the launches by name:
+    // <T, 0, 4> is the Cholesky trailing update in 128 x 128 tiles (the roofline kernel of bench.py; its short tail
+    // launches run as narrow tiles and are accounted with the panel), <T, 64, *> every other product.
+    const bool narrow = use_narrow_tiles(ctx, M, N, shape, batch);
+    const bool trailing = shape.mode && !flags && !narrow;
     ProfScope ps(ctx, trailing ? GPMI_PROF_SYRK : GPMI_PROF_PANEL,
                  2.0 * shape_entries(M, N, shape) * (double)K * (batch ? batch->count : 1));
     if (trailing)
-        launch_persistent<T, 0>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags, batch);
+        launch_persistent<T, 0>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags, batch, false);
     else
-        launch_persistent<T, 64>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags, batch);
+        launch_persistent<T, 64>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags, batch, narrow);
 }
 
 template <typename T>
@@ -464,7 +463,8 @@ template void launch_gemm_nt<float>(gpmi_ctx*, float*, int64_t, const float*, in
 // ---- isolated timing of the update kernel (tools / bench only) ------------------------------
 template <typename T, int V>
 static void launch_variant(gpmi_ctx* ctx, T* C, int64_t ld, const T* A, int64_t M, int64_t N, int64_t K, int lower) {
-    launch_persistent<T, V>(ctx, C, ld, A, ld, A, ld, M, N, K, TileShape{0, 0, lower ? 1 : 0, 0, 1, 0}, nullptr);
+    const TileShape shape{0, 0, lower ? 1 : 0, 0, 1, 0};
+    launch_persistent<T, V>(ctx, C, ld, A, ld, A, ld, M, N, K, shape, nullptr, 0, nullptr, use_narrow_tiles(ctx, M, N, shape, nullptr));
 }
 
 template <typename T>
