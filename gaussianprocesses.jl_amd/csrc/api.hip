@@ -503,7 +503,6 @@ int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
         c->lookahead_slots = 8;
         if (const char* e = getenv("GPMI_LOOKAHEAD")) c->lookahead_slots = atoi(e) / 8 * 8;
         if (const char* e = getenv("GPMI_LOOKAHEAD_MIN")) c->lookahead_min_trailing = atoll(e);
-        if (const char* e = getenv("GPMI_WHITEN_LOOKAHEAD_MIN")) c->whiten_lookahead_min = atof(e);
     }
     if (const char* e = getenv("GPMI_REFINE")) c->refine_default = atoi(e) != 0;
     c->refine_solves = c->refine_default;

@@ -53,50 +53,18 @@ inline hipEvent_t la_event(gpmi_ctx* c) {
 //   V[:, k0:kend] = R[:, k0:kend] * Linv_k' ;  R[:, kend:npad] -= V[:, k0:kend] * A[kend:npad, k0:kend]'
 // (R is consumed).  Out of place because the two 128-column tiles of a block read each other's input columns.
 // rows_upto(kend) gives the number of leading rows that can be non-zero up to column kend (identity right-hand sides).
-//
-// Look-ahead, as in cholesky_lower: the product against the inverse is a one-round launch (<= 16 tiles, ~55 us) on the
-// critical path of every block.  While the update by block k is long enough, the NEXT block's columns are updated and
-// solved on the side stream (two small high-priority launches) under the rest of the update.
+// (A look-ahead of the next block's solve on the side stream, as in cholesky_lower, bought 1.6 ms per predict while the
+//  solve was a 49 us launch of 128 x 128 tiles; with 128 x 64 tiles it is 28 us and the look-ahead measured neutral: removed.)
 template <typename T, typename F>
 inline void whiten_rows_inv(gpmi_ctx* c, const T* A, int64_t ld, const T* linv256, int64_t npad, T* R, int64_t ldr, T* V,
                             int64_t ldv, F rows_upto) {
     const TileShape rect{0, 0, 0, 0, 1, 0};
-    const bool la = c->lookahead_slots > 0 && c->side_stream;
-    hipStream_t main_s = c->stream, side = c->side_stream;
-    bool solved = false;  // is V[:, k0:kend] already there (done by the look-ahead of the previous block)?
     for (int64_t k0 = 0; k0 < npad; k0 += NB) {
         const int64_t nbk = std::min<int64_t>(NB, npad - k0), k1 = k0 + nbk;
         const int64_t Mr = rows_upto(k1);
-        if (!solved)
-            launch_gemm_shape<T>(c, V + k0, ldv, R + k0, ldr, linv256 + (k0 / NB) * NB * NB, NB, Mr, nbk, nbk, rect, nullptr,
-                                 GEMM_OVERWRITE);
-        solved = false;
-        if (k1 >= npad) break;
-        const int64_t nb1 = std::min<int64_t>(NB, npad - k1), k2 = k1 + nb1;
-        const int64_t Mr1 = rows_upto(k2);  // rows the next block's solve covers (>= Mr)
-        // worth it while the rest of the update outlasts the solve it hides (~60 us at 45 TFLOP/s), and only when the
-        // next solve needs no rows the update does not already carry
-        const bool ahead = la && k2 < npad && Mr1 == Mr && (double)Mr * (double)(npad - k2) > c->whiten_lookahead_min;
-        if (!ahead) {
-            launch_gemm_nt<T>(c, R + k1, ldr, V + k0, ldv, A + k1 * ld + k0, ld, Mr, npad - k1, nbk, 0, nullptr);
-            continue;
-        }
-        hipEvent_t ev = la_event(c);  // V_k complete, R current up to block k - 1
-        (void)hipEventRecord(ev, main_s);
-        (void)hipStreamWaitEvent(side, ev, 0);
-        {
-            StreamScope sc(c, side, c->num_cus);
-            launch_gemm_shape<T>(c, R + k1, ldr, V + k0, ldv, A + k1 * ld + k0, ld, Mr, nb1, nbk, rect, nullptr, GEMM_AUX);
-            launch_gemm_shape<T>(c, V + k1, ldv, R + k1, ldr, linv256 + (k1 / NB) * NB * NB, NB, Mr, nb1, nb1, rect, nullptr,
-                                 GEMM_OVERWRITE | GEMM_AUX);
-        }
-        hipEvent_t es = la_event(c);
-        (void)hipEventRecord(es, side);
-        c->gemm_reserve = 4 * c->lookahead_slots;
-        launch_gemm_nt<T>(c, R + k2, ldr, V + k0, ldv, A + k2 * ld + k0, ld, Mr, npad - k2, nbk, 0, nullptr);
-        c->gemm_reserve = 0;
-        (void)hipStreamWaitEvent(main_s, es, 0);
-        solved = true;
+        launch_gemm_shape<T>(c, V + k0, ldv, R + k0, ldr, linv256 + (k0 / NB) * NB * NB, NB, Mr, nbk, nbk, rect, nullptr,
+                             GEMM_OVERWRITE);
+        if (k1 < npad) launch_gemm_nt<T>(c, R + k1, ldr, V + k0, ldv, A + k1 * ld + k0, ld, Mr, npad - k1, nbk, 0, nullptr);
     }
 }
 

@@ -86,7 +86,6 @@ struct gpmi_ctx {
     // trailing update, which leaves lookahead_slots workgroup slots free (gemm_reserve is set around that launch)
     hipStream_t side_stream = nullptr;
     int lookahead_slots = 0;
-    double whiten_lookahead_min = 5.3e6;     // rows x remaining columns below which the whitening runs serially
     int64_t lookahead_min_trailing = 4608;  // trailing size below which the serial order is faster (update < chain)
     int gemm_reserve = 0;
     std::vector<hipEvent_t> la_events;
