@@ -442,3 +442,15 @@ def test_rand_draws_have_the_predictive_moments():
     assert draws.shape == (6, 40000)
     np.testing.assert_allclose(draws.mean(axis=1), mu, atol=4 * np.sqrt(np.diag(S).max() / 40000) + 1e-3)
     np.testing.assert_allclose(np.cov(draws), S, atol=0.03 * np.abs(S).max() + 1e-4)
+
+
+def test_tiny_noise_keeps_lapack_accuracy():
+    """logNoise = -8 on a smooth kernel: the factorisation switches to refined block solves and the mll
+    agrees with LAPACK's to well inside the 1e-5 parity bound (both are ~1e-9 relative from the 80-bit value)."""
+    rng = np.random.default_rng(5)
+    n = 1500
+    x = rng.uniform(size=(2, n))
+    y = np.sin(4 * x.sum(axis=0)) + 0.05 * rng.standard_normal(n)
+    spec = ("se_ard", [math.log(0.3), math.log(0.4)], 0.0)
+    gp, ref = _fit_both(spec, x, y, -8.0)
+    assert abs(gp.mll - ref["mll"]) <= 2e-8 * abs(ref["mll"])
