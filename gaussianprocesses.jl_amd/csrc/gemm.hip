@@ -63,7 +63,7 @@ struct QueueArgs {
 };
 
 template <typename T, int VARIANT, int NI>
-__global__ __launch_bounds__(256, (VARIANT & 256) ? 1 : NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __restrict__ C, int64_t ldc, const T* __restrict__ A,
+__global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __restrict__ C, int64_t ldc, const T* __restrict__ A,
                                                          int64_t lda, const T* __restrict__ B, int64_t ldb, int64_t M,
                                                          int64_t N, int64_t K, TileShape shape,
                                                          unsigned long long* __restrict__ queue, QueueArgs qa,
@@ -186,9 +186,6 @@ __global__ __launch_bounds__(256, (VARIANT & 256) ? 1 : NI == 4 ? 2 : 3) void ge
             // no load/compute overlap inside a workgroup (lone-workgroup K loop 2.9 us per slab against 2.08 us of
             // MFMA).  In this order the only wait is the one the end-of-slab barrier needs anyway.
             Vec af[2][4], bf[2][NI];
-            // VARIANT & 256 (tools only, fp64): the three rotated copies of every B fragment come from LDS (three more
-            // ds_read_b128 of the rows (r16 + 4 r) & 15) instead of from v_mov_b32_dpp — does the MFMA issue rate rise?
-            Vec bfr[2][NI][3];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 if constexpr (VARIANT & 16) {
@@ -209,15 +206,6 @@ __global__ __launch_bounds__(256, (VARIANT & 256) ? 1 : NI == 4 ? 2 : 3) void ge
                     for (int mi = 0; mi < 4; ++mi) af[h][mi] = *reinterpret_cast<const Vec*>(as + mi * 16 * BK);
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) bf[h][ni] = *reinterpret_cast<const Vec*>(bs + ni * 16 * BK);
-                    if constexpr ((VARIANT & 256) != 0) {
-#pragma unroll
-                        for (int rot = 1; rot < 4; ++rot) {
-                            const int rr = (r16 + 4 * rot) & 15;
-                            const T* bsr = Bs0 + cur * BN * BK + (wn * WN + rr) * BK + (((4 * h + g) ^ (rr & 7)) * E);
-#pragma unroll
-                            for (int ni = 0; ni < NI; ++ni) bfr[h][ni][rot - 1] = *reinterpret_cast<const Vec*>(bsr + ni * 16 * BK);
-                        }
-                    }
                 }
             }
             if constexpr (!(VARIANT & 16)) {
@@ -227,9 +215,6 @@ __global__ __launch_bounds__(256, (VARIANT & 256) ? 1 : NI == 4 ? 2 : 3) void ge
                     for (int q = 0; q < 4; ++q) {  // reads stay above the DMA
                         asm volatile("" : "+v"(af[h][q]));
                         if (q < NI) asm volatile("" : "+v"(bf[h][q]));
-                        if constexpr ((VARIANT & 256) != 0) {
-                            if (q < NI) asm volatile("" : "+v"(bfr[h][q][0]), "+v"(bfr[h][q][1]), "+v"(bfr[h][q][2]));
-                        }
                     }
             }
             if (kt + 1 < nk && !(VARIANT & 4)) stage(cur ^ 1, (kt + 1) * BK);
@@ -243,11 +228,6 @@ __global__ __launch_bounds__(256, (VARIANT & 256) ? 1 : NI == 4 ? 2 : 3) void ge
                         T br[4];
                         if constexpr (VARIANT & 8) {
                             br[0] = br[1] = br[2] = br[3] = bf[h][ni][e];
-                        } else if constexpr ((VARIANT & 256) != 0) {
-                            br[0] = bf[h][ni][e];
-                            br[1] = bfr[h][ni][0][e];
-                            br[2] = bfr[h][ni][1][e];
-                            br[3] = bfr[h][ni][2][e];
                         } else {
                             MF::rotations(bf[h][ni][e], br);
                         }
@@ -517,8 +497,6 @@ int gemm_bench(gpmi_ctx* ctx, int64_t M, int64_t N, int64_t K, int lower, int va
             case 22: launch_variant<T, 22>(ctx, C, ld, A, M, N, K, lower); break;
             case 30: launch_variant<T, 30>(ctx, C, ld, A, M, N, K, lower); break;
             case 128: launch_variant<T, 128>(ctx, C, ld, A, M, N, K, lower); break;
-            case 256: launch_variant<T, 256>(ctx, C, ld, A, M, N, K, lower); break;
-            case 384: launch_variant<T, 384>(ctx, C, ld, A, M, N, K, lower); break;
 
             default: break;
         }
