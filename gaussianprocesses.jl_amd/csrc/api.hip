@@ -203,6 +203,10 @@ static void potrf_block(gpmi_ctx* c, T* A, int64_t ld, int64_t nb, T* linv, T* i
 template <typename T>
 static void rows_solve_block(gpmi_ctx* c, T* X, int64_t ldx, int64_t M, const T* L, int64_t ldl, const T* linv, int64_t nb,
                              const int* d_info) {
+    if (!c->refine_solves && (M + IB - 1) / IB <= c->num_cus && nb <= NB) {  // one fused launch (see factor_panel_below)
+        launch_rows256<T>(c, X, ldx, M, (int)(nb / IB), L, ldl, linv, d_info);
+        return;
+    }
     for (int64_t j0 = 0; j0 < nb; j0 += IB)
         launch_rows64<T>(c, X, ldx, M, (int)j0, L + j0 * ldl, ldl, linv + (j0 / IB) * IB * IB, 0, d_info);
 }
