@@ -3,6 +3,9 @@
  * This is the drop-in boundary for ONE hot path of STOR-i/GaussianProcesses.jl:
  *   GPE.update_mll!  (cov! -> nugget -> Cholesky -> alpha -> logdet -> mll)
  *   predict_f        (cross-cov -> whiten -> mean / variance)
+ * and, as the "next" rows of SURVEY.md 8(f) built on the same kernels:
+ *   update_dmll!     (gpmi_grad), FITC update_mll! / predict_f (gpmi_fitc_*),
+ *   predict_LOO      (gpmi_inv_diag).
  * The reference has no FFI; its seam is Julia dispatch on CovarianceStrategy /
  * AbstractPDMat (src/GP.jl:10-20).  Each entry point below names the reference
  * code it replaces (paths relative to the reference repository root); the
