@@ -65,6 +65,87 @@ __device__ __forceinline__ T leaf_value(int op, T r, T s2, T p0inv, T p1) {
     }
 }
 
+// Is this tile one the fast kernel takes?  One stationary leaf (the bench's SEArd; any single SE / Matern / RQ kernel) and a
+// tile that needs neither padding nor the diagonal (nugget).  Both kernels evaluate it, so every tile has exactly one owner.
+__device__ __forceinline__ bool fast_tile(const DevProgram* __restrict__ prog, int nops, int flags, int64_t row0, int64_t col0,
+                                          int TR, int TC, int64_t na, int64_t nb, int64_t nrows, int64_t ncols, int64_t row_off) {
+    if (nops != 1) return false;
+    const int op0 = prog->leaf[0].op;
+    if (op0 == GPMI_K_NOISE || op0 == GPMI_K_CONST) return false;
+    const bool interior = row0 + TR <= na && row0 + TR <= nrows && col0 + TC <= nb && col0 + TC <= ncols;
+    const bool on_diag = (flags & COV_NUGGET) && col0 <= row_off + row0 + TR - 1 && row_off + row0 <= col0 + TC - 1;
+    return interior && !on_diag;
+}
+
+// cov_fast_kernel: the same tiling as cov_kernel for the tiles fast_tile() selects.  Weights and leaf constants are read
+// once, there is no evaluation stack and no per-entry edge logic: about half the VALU instructions per entry of the
+// interpreter, and few enough registers for 6+ waves per SIMD (the interpreter needs 177 VGPRs: 2 waves).
+template <typename T, int DMAX>
+__global__ __launch_bounds__(256) void cov_fast_kernel(const T* __restrict__ xa, int64_t na, const T* __restrict__ xb,
+                                                       int64_t nb, int d, T* __restrict__ C, int64_t ldc, int64_t nrows,
+                                                       int64_t ncols, const DevProgram* __restrict__ prog, int flags,
+                                                       int64_t row_off) {
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int TC = 64 * VEC;
+    constexpr int TR = 64;
+    using VT = T __attribute__((ext_vector_type(VEC)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* sa = reinterpret_cast<T*>(smem);  // [TR][d]
+    T* sbT = sa + TR * d;                // [d][TC]
+    const int64_t row0 = (int64_t)blockIdx.y * TR;
+    const int64_t col0 = (int64_t)blockIdx.x * TC;
+    if ((flags & COV_LOWER) && col0 > row_off + row0 + TR - 1) return;  // tile strictly above the diagonal
+    if (!fast_tile(prog, prog->n_ops, flags, row0, col0, TR, TC, na, nb, nrows, ncols, row_off)) return;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < TR * d; e += 256) sa[e] = xa[(row0 + e / d) * d + (e % d)];
+    for (int e = tid; e < TC * d; e += 256) {
+        const int c = e / d, k = e - c * d;
+        sbT[k * TC + c] = xb[(col0 + c) * d + k];
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    T xbr[DMAX][VEC];
+#pragma unroll
+    for (int k = 0; k < DMAX; ++k) {
+        if (k < d) {
+            const VT v = *reinterpret_cast<const VT*>(&sbT[k * TC + lane * VEC]);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) xbr[k][q] = v[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) xbr[k][q] = T(0);
+        }
+    }
+    const int op0 = prog->leaf[0].op;
+    const double* w = prog->w + prog->leaf[0].woff;
+    T wk[DMAX];
+#pragma unroll
+    for (int k = 0; k < DMAX; ++k) wk[k] = k < d ? (T)w[k] : T(0);
+    const T s2 = (T)prog->leaf[0].s2, p0inv = (T)prog->leaf[0].p0, p1 = (T)prog->leaf[0].p1;
+    for (int rr = 0; rr < TR / 4; ++rr) {
+        const int row = wave * (TR / 4) + rr;
+        const T* sar = sa + row * d;
+        T r[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) r[q] = T(0);
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) {
+            if (k < d) {
+                const T a = sar[k];
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) {
+                    const T df = a - xbr[k][q];
+                    r[q] = Tr<T>::fma_(df * df, wk[k], r[q]);  // same operation order as the interpreter
+                }
+            }
+        }
+        VT out;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) out[q] = leaf_value<T>(op0, r[q], s2, p0inv, p1);
+        *reinterpret_cast<VT*>(&C[(row0 + row) * ldc + col0 + (int64_t)lane * VEC]) = out;
+    }
+}
+
 template <typename T, int DMAX>
 __global__ __launch_bounds__(256) void cov_kernel(const T* __restrict__ xa, int64_t na, const T* __restrict__ xb,
                                                   int64_t nb, int d, T* __restrict__ C, int64_t ldc, int64_t nrows,
@@ -118,6 +199,11 @@ __global__ __launch_bounds__(256) void cov_kernel(const T* __restrict__ xa, int6
                 for (int q = 0; q < VEC; ++q) xbr[k][q] = T(0);
             }
         }
+    }
+
+    // interior, off-diagonal tiles of a single stationary leaf belong to cov_fast_kernel (launched alongside)
+    if constexpr (DMAX > 0) {
+        if (fast_tile(prog, nops, flags, row0, col0, TR, TC, na, nb, nrows, ncols, row_off)) return;
     }
 
     for (int rr = 0; rr < TR / 4; ++rr) {
@@ -258,6 +344,14 @@ void launch_cov_t(gpmi_ctx* ctx, const T* xa, int64_t na, const T* xb, int64_t n
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, xa, na, xb, nb, d, C, ldc, nrows_total, ncols_total,
                        ctx->d_prog, flags, nugget, nugget_vec, row_off);
+    if constexpr (DMAX > 0) {
+        const DevProgram* hp = ctx->h_prog;
+        if (hp->n_ops == 1 && hp->leaf[0].op != GPMI_K_NOISE && hp->leaf[0].op != GPMI_K_CONST) {
+            auto fk = cov_fast_kernel<T, DMAX>;
+            hipLaunchKernelGGL(fk, grid, dim3(256), lds, ctx->stream, xa, na, xb, nb, d, C, ldc, nrows_total, ncols_total,
+                               ctx->d_prog, flags, row_off);
+        }
+    }
 }
 
 }  // namespace
