@@ -28,6 +28,7 @@
 // Tile order is XCD-aware: block b runs on XCD b % 8, so each XCD gets a contiguous run of
 // 8 x 8 super-tiles (64 concurrent tiles share 16 operand panels in that XCD's 4 MiB L2).
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -68,7 +69,8 @@ __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __rest
                                                          int64_t N, int64_t K, TileShape shape,
                                                          unsigned long long* __restrict__ queue, QueueArgs qa,
                                                          const int* __restrict__ info, int flags) {
-    using MF = Mfma<T>;
+    // (VARIANT & 512, fp64, tools only: the four-instruction 4x4x4 + DPP form of the product, for the ablation)
+    using MF = std::conditional_t<(VARIANT & 512) != 0 && std::is_same<T, double>::value, Mfma4x4d, Mfma<T>>;
     using Vec = typename MF::Vec;
     using Acc = typename MF::Acc;
     constexpr int E = MF::E;
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __rest
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sacc += acc_get<T>(acc[mi][ni], r);
+                    for (int r = 0; r < 4; ++r) sacc += acc[mi][ni].v[r];
             if (sacc == T(-1.2345e300)) C[0] = sacc;
         }
         // The accumulators leave in the MFMA lane layout (32-byte row fragments).  They are bounced
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __rest
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             stg[(mi * 16 + MF::row_of(lane, r)) * WN + ni * 16 + MF::col_of(lane, r)] =
-                                acc_get<T>(acc[2 * hh + mi][ni], r);
+                                acc[2 * hh + mi][ni].v[r];
                 const int64_t grow0 = m0 + wm * 64 + hh * 32 + rloc;
                 const int64_t gcol = n0 + wn * WN + cloc;
                 VT cv[NIT];
@@ -497,6 +499,10 @@ int gemm_bench(gpmi_ctx* ctx, int64_t M, int64_t N, int64_t K, int lower, int va
             case 22: launch_variant<T, 22>(ctx, C, ld, A, M, N, K, lower); break;
             case 30: launch_variant<T, 30>(ctx, C, ld, A, M, N, K, lower); break;
             case 128: launch_variant<T, 128>(ctx, C, ld, A, M, N, K, lower); break;
+            case 512: launch_variant<T, 512>(ctx, C, ld, A, M, N, K, lower); break;
+            case 640: launch_variant<T, 640>(ctx, C, ld, A, M, N, K, lower); break;
+            case 514: launch_variant<T, 514>(ctx, C, ld, A, M, N, K, lower); break;
+            case 542: launch_variant<T, 542>(ctx, C, ld, A, M, N, K, lower); break;
 
             default: break;
         }

@@ -1,7 +1,6 @@
 // mfma.h — per-precision matrix-core traits shared by the trailing-update kernel (gemm.hip) and the
-// panel kernels (panel.hip).  See the header comment of gemm.hip for the instruction choice:
-// fp64 uses FOUR v_mfma_f64_4x4x4_4b_f64 per 16 x 16 x 4 product (B rotated by 0/4/8/12 lanes with
-// v_mov_b32_dpp row_ror), fp32 uses one v_mfma_f32_16x16x4_f32.
+// panel kernels (panel.hip).  One 16 x 16 x 4 product per instruction in both precisions:
+// v_mfma_f64_16x16x4_f64 and v_mfma_f32_16x16x4_f32 (the accumulator layouts differ, see row_of).
 //   operand layout (both):  lane l supplies A[row = l & 15][k = l >> 4],  B[col = l & 15][k = l >> 4]
 //   result layout:          element r of lane l is C[row_of(l, r)][col_of(l, r)]
 #pragma once
@@ -20,8 +19,11 @@ __device__ __forceinline__ double dpp_rot(double x) {
     return __hiloint2double(hi, lo);
 }
 
-template <>
-struct Mfma<double> {
+// The four-instruction form (kept for the ablation, VARIANT & 512 of the update kernel): it was the first choice because a
+// bare-loop micro-benchmark put v_mfma_f64_16x16x4 at 48 TFLOP/s against 69 for v_mfma_f64_4x4x4_4b; inside the real
+// kernel the one-instruction form is 5 % (two workgroups per CU) to 11 % (one) FASTER — no B rotations, a quarter of the
+// MFMA issue slots — and it is what rocBLAS's MT128x128x16_MI16x16x4 kernel uses.
+struct Mfma4x4d {
     using Vec = double __attribute__((ext_vector_type(2)));
     static constexpr int E = 2;
     static constexpr int BK = 16;
@@ -44,6 +46,27 @@ struct Mfma<double> {
     static __device__ __forceinline__ int row_of(int lane, int) { return ((lane >> 2) & 3) * 4 + (lane >> 4); }
     static __device__ __forceinline__ int col_of(int lane, int r) { return ((((lane >> 2) & 3) + r) & 3) * 4 + (lane & 3); }
 };
+// fp64: one v_mfma_f64_16x16x4_f64 per 16 x 16 x 4 product.
+template <>
+struct Mfma<double> {
+    using Vec = double __attribute__((ext_vector_type(2)));
+    static constexpr int E = 2;
+    static constexpr int BK = 16;
+    static constexpr int NR = 4;
+    using V4 = double __attribute__((ext_vector_type(4)));
+    struct Acc {
+        V4 v;
+    };
+    static __device__ __forceinline__ void rotations(double b, double (&br)[4]) { br[0] = b; }
+    static __device__ __forceinline__ void mma(double a, const double (&br)[4], Acc& c) {
+        c.v = __builtin_amdgcn_mfma_f64_16x16x4f64(a, br[0], c.v, 0, 0, 0);
+    }
+    // probed on hardware (tools/mfma16_probe.hip): register r of lane l holds D[row 4 r + (l >> 4)][col l & 15]
+    // (NOT the fp32 instruction's 4 (l >> 4) + r)
+    static __device__ __forceinline__ int row_of(int lane, int reg) { return 4 * reg + (lane >> 4); }
+    static __device__ __forceinline__ int col_of(int lane, int) { return lane & 15; }
+};
+
 template <>
 struct Mfma<float> {
     using Vec = float __attribute__((ext_vector_type(4)));
