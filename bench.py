@@ -135,7 +135,7 @@ def _main_json(args, world, elapsed, gp, n, d, p, fl_syrk, ms_syrk, n_syrk, ms_c
             "mll": gp.mll,
         },
         "roofline": {
-            "kernel": "gemm_nt_kernel<T, 0, 4> (Cholesky trailing update, 128x128 tiles, K=256, v_mfma_f64_4x4x4)",
+            "kernel": "gemm_nt_kernel<T, 0, 4> (Cholesky trailing update, 128x128 tiles, K=256, v_mfma_f64_16x16x4)",
             "bound": "mfma",
             "achieved": achieved,
             "peak": peak,

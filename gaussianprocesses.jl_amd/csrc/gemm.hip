@@ -5,16 +5,13 @@
 // lower factor both operands have K contiguous ("NT" form), which is exactly the MFMA
 // operand layout: lane l supplies A[row = l & 15][k = l >> 4].
 //
-// FP64 instruction choice (measured on this MI355X, tools/mfma_bench.hip, profiles/r01_mfma_*):
-//   v_mfma_f64_16x16x4_f64      tops out at 48 TFLOP/s chip-wide (~105 cycles / instruction / SIMD);
-//   v_mfma_f64_4x4x4_4b_f64     sustains 75-76 TFLOP/s (97 % of the 78.6 TF FP64-matrix spec).
-// The 4x4x4 form multiplies four independent 4x4 blocks: block b of A (rows 4b..4b+3 of the
-// 16-row fragment) meets block b of B.  Its cbsz/abid broadcast controls are ignored for f64
-// (probed: tools/mfma_probe.hip), so a full 16 x 16 x 4 product is built from FOUR of them with
-// the B fragment rotated by 0/4/8/12 lanes inside each 16-lane row (v_mov_b32_dpp row_ror — VALU
-// work that issues in the shadow of the MFMAs):
-//   acc[r][lane = j + 4b + 16i]  =  C[row 4b + i][col 4((b + r) & 3) + j],   r = 0..3.
-// FP32 uses v_mfma_f32_16x16x4_f32 directly (149.5 TF measured, 95 % of peak).
+// FP64 instruction: v_mfma_f64_16x16x4_f64, one per 16 x 16 x 4 product (accumulator register r of lane l holds
+// D[row 4 r + (l >> 4)][col l & 15], probed: tools/mfma16_probe.hip).  History worth keeping: a bare-loop micro-benchmark
+// (tools/mfma_bench.hip, profiles/r01_mfma_*) put this instruction at 48 TFLOP/s against 69-76 for v_mfma_f64_4x4x4_4b_f64,
+// so the kernel was first built on FOUR 4x4x4 MFMAs per product with the B fragment rotated by v_mov_b32_dpp row_ror
+// (Mfma4x4d in mfma.h, still selectable with VARIANT & 512).  Inside the real kernel the one-instruction form is 5 % (two
+// workgroups per CU) to 11 % (one) faster, and it is what rocBLAS's MT128x128x16_MI16x16x4 kernel for this shape uses.
+// FP32 uses v_mfma_f32_16x16x4_f32 (149.5 TF measured, 95 % of peak).
 //
 // Structure per 256-thread workgroup (4 wavefronts, 2 x 2):
 //   128 x 128 output tile, each wavefront a 64 x 64 sub-tile = 4 x 4 MFMA tiles whose
