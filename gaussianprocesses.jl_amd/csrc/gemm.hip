@@ -76,13 +76,11 @@ __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __rest
     // half the accumulators, 48 KiB of LDS), THREE workgroups per CU
     constexpr int BM = GEMM_BM, BN = 32 * NI, WN = 16 * NI;  // WN = columns per wave
 
-    // one 64 KiB LDS array: [A buf0 | A buf1 | B buf0 | B buf1] during the K loop, then four
-    // wave-private 16 KiB transposition buffers for the epilogue
+    // one 64 KiB LDS array: [A buf0 | A buf1 | B buf0 | B buf1]
     __shared__ __attribute__((aligned(16))) T smem[2 * (BM + BN) * BK];
     __shared__ long long s_tile;
     T* const As0 = smem;
     T* const Bs0 = smem + 2 * BM * BK;
-    static_assert(2 * (BM + BN) * BK >= 4 * 32 * WN, "epilogue staging does not fit");
 
     const int tid = threadIdx.x;
     const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;  // li-th workgroup of its XCD
@@ -97,6 +95,14 @@ __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __rest
     // one in wave slot 0 wins the MFMA arbitration (oldest first) and runs its tiles at lone-workgroup speed (68 us at
     // K = 256), the slot-1 workgroup fills the gaps (135 us per tile).  Anti-phasing the pair with a start delay and
     // alternating s_setprio per slab were both measured neutral (43.5 TFLOP/s either way), so neither is done.
+    if constexpr (VARIANT & 32) {  // experiment: spread the CUs' tile phases over one tile period (C traffic bursts)
+        const unsigned half = gridDim.x >> 1;
+        const unsigned c = blockIdx.x % half;  // CU pair index
+        const unsigned phi = (c * 2654435769u) >> 19;  // 13 bits, golden-ratio hash
+        const long long wait = ((long long)phi * (long long)(flags >> 16)) >> 13;  // flags>>16 = period in 10 ns ticks
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
     if (flags & GEMM_AUX) __builtin_amdgcn_s_setprio(2);  // critical-path side launch next to the persistent update
 
     const int lane = tid & 63;
@@ -158,27 +164,66 @@ __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __rest
             }
         };
 
-        Acc acc[4][NI];
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[mi][ni].v[r] = T(0);
+        // The accumulators START as the C tile (fragment-shaped loads: in fp64 one wave instruction covers four whole
+        // 128-byte row segments) and the MFMAs subtract into them (neg:[1,0,0] on the fp64 instruction; fp32 has no such
+        // modifier and keeps -C instead).  The tile then leaves with plain stores: no read-modify-write pass, no LDS
+        // transposition, no load latency at the end of a tile — the C loads fly together with the first slab's DMA.
+        //   NEG:  acc = C - A B'               (OVERWRITE: acc = -A B', stored negated)
+        //   !NEG: acc = -C + A B', stored negated   (OVERWRITE: acc = A B')
+        const bool overwrite = (flags & GEMM_OVERWRITE) != 0;
+        const bool interior = mrem == BM - 1 && nrem == BN - 1;
+        const int lrow = wm * 64, lcol = wn * WN;  // this wave's corner inside the tile
+        T* __restrict__ const Cw = Ct + (m0 + lrow) * ldc + n0 + lcol;
+        auto c_index = [&](int64_t ld, int ln, int mi, int ni, int r) -> int64_t {
+            return (int64_t)(mi * 16 + MF::row_of(ln, r)) * ld + ni * 16 + MF::col_of(ln, r);
+        };
+        auto c_valid = [&](int mi, int ni, int r) -> bool {
+            return lrow + mi * 16 + MF::row_of(lane, r) <= mrem && lcol + ni * 16 + MF::col_of(lane, r) <= nrem;
+        };
 
         // GEMM_KSTART_ROW: A is upper-triangular-by-rows (A[i][k] = 0 for k < i), so the products below the
         // tile's first row vanish — start the K loop there (this is what makes K^-1 = L^-T L^-1 cost N^3/3)
         const int kbeg = (flags & GEMM_KSTART_ROW) ? (int)(m0 / BK) : 0;
         stage(kbeg & 1, kbeg * BK);
+        Acc acc[4][NI];
+        if ((VARIANT & 1) || overwrite) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[mi][ni].v[r] = T(0);
+        } else if (interior) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const T c = Cw[c_index(ldc, lane, mi, ni, r)];
+                        acc[mi][ni].v[r] = MF::NEG ? c : -c;
+                    }
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const T c = c_valid(mi, ni, r) ? Cw[c_index(ldc, lane, mi, ni, r)] : T(0);
+                        acc[mi][ni].v[r] = MF::NEG ? c : -c;
+                    }
+        }
         __syncthreads();  // drains the DMA (vmcnt) and publishes the slab
         if constexpr (VARIANT & 128) {
             tk1 = wall_clock64();
             tk_pro += tk1 - tk0;
         }
 
+        unsigned long long pulled = 0;
         for (int kt = kbeg; kt < nk; ++kt) {
             const int cur = kt & 1;
-            // All fragments of the slab go to registers FIRST, then the DMA of the next slab is issued, then the 256
+            // All fragments of the slab go to registers FIRST, then the DMA of the next slab is issued, then the
             // MFMAs run.  The compiler cannot tell the DMA's LDS writes (other buffer) from LDS reads and puts
             // s_waitcnt vmcnt(0) in front of the first LDS read after a global_load_lds: with the reads interleaved
             // into the MFMA stream (the natural order) every slab waited for the NEXT slab's DMA before computing —
@@ -216,7 +261,13 @@ __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __rest
                         if (q < NI) asm volatile("" : "+v"(bf[h][q]));
                     }
             }
-            if (kt + 1 < nk && !(VARIANT & 4)) stage(cur ^ 1, (kt + 1) * BK);
+            const bool last = kt + 1 == nk;
+            if (!last) {
+                if (!(VARIANT & 4)) stage(cur ^ 1, (kt + 1) * BK);
+            } else if (qa.use_queue && tid == 0) {
+                // the pull for the NEXT tile rides under the last slab's MFMAs (round trip to the L2 atomic unit ~2 us)
+                pulled = atomicAdd(queue + 8 * xcd, 1ull);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -231,21 +282,26 @@ __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __rest
                             MF::rotations(bf[h][ni][e], br);
                         }
 #pragma unroll
-                        for (int mi = 0; mi < 4; ++mi) MF::mma(af[h][mi][e], br, acc[mi][ni]);
+                        for (int mi = 0; mi < 4; ++mi) MF::mma_sub(af[h][mi][e], br, acc[mi][ni]);
                     }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs above the barrier (they are what hides the DMA)
-            __syncthreads();  // (a) next slab has landed for everyone  (b) everyone is done reading `cur`
+            if (last && tid == 0) s_tile = (long long)(pulled - qa.base[xcd]) + cbeg + nloc;
+            __syncthreads();  // (a) next slab has landed for everyone  (b) everyone is done reading `cur`  (c) s_tile
         }
+        if (kbeg >= nk && qa.use_queue) {  // (no slab at all: cannot happen for the shapes launched, kept for safety)
+            if (tid == 0) s_tile = (long long)(atomicAdd(queue + 8 * xcd, 1ull) - qa.base[xcd]) + cbeg + nloc;
+            __syncthreads();
+        }
+        // the next write of s_tile is behind the next tile's prologue barrier, which no wave passes before this read
+        const long long t_next = qa.use_queue ? (long long)__builtin_amdgcn_readfirstlane((int)s_tile) : (long long)cend;
 
         if constexpr (VARIANT & 128) {
             tk2 = wall_clock64();
             tk_loop += tk2 - tk1;
         }
-        unsigned long long pulled = 0;
-        if (qa.use_queue && tid == 0) pulled = atomicAdd(queue + 8 * xcd, 1ull);
-        // ---- epilogue: C -= acc --------------------------------------------------------------
+        // ---- epilogue: the tile leaves straight from the accumulators -------------------------
         if constexpr (VARIANT & 2) {
             T sacc = T(0);
 #pragma unroll
@@ -255,72 +311,42 @@ __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __rest
 #pragma unroll
                     for (int r = 0; r < 4; ++r) sacc += acc[mi][ni].v[r];
             if (sacc == T(-1.2345e300)) C[0] = sacc;
-        }
-        // The accumulators leave in the MFMA lane layout (32-byte row fragments).  They are bounced
-        // through a wave-private LDS buffer, 32 rows x 64 columns at a time, and re-read row-major,
-        // so that C is read-modified-written with 16 bytes per lane and whole 128-byte lines per row
-        // (the fragment-shaped RMW cost 19 % of the kernel: it re-fetched every line four times).
-        if constexpr (!(VARIANT & 2)) {
-            constexpr int VEC = 16 / sizeof(T);  // elements per 16-byte access
-            constexpr int LPR = WN / VEC;        // lanes per WN-column row
-            constexpr int RPI = 64 / LPR;        // rows per wave instruction
-            constexpr int NIT = 32 / RPI;
-            using VT = T __attribute__((ext_vector_type(VEC)));
-            T* stg = smem + wv * (32 * WN);
-            const int rloc = lane / LPR, cloc = (lane % LPR) * VEC;
-            // (issuing the second pass's C loads together with the first pass's was tried: the 64 extra registers spill)
+        } else {
+            const bool negate = overwrite ? MF::NEG : !MF::NEG;
+            // the addresses are recomputed from opaque copies: kept alive across the K loop they cost 32 VGPRs (spills)
+            int64_t ld2 = ldc;
+            int ln2 = lane;
+            asm volatile("" : "+s"(ld2), "+v"(ln2));
+            if (interior) {
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            stg[(mi * 16 + MF::row_of(lane, r)) * WN + ni * 16 + MF::col_of(lane, r)] =
-                                acc[2 * hh + mi][ni].v[r];
-                const int64_t grow0 = m0 + wm * 64 + hh * 32 + rloc;
-                const int64_t gcol = n0 + wn * WN + cloc;
-                VT cv[NIT];
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const int64_t grow = grow0 + it * RPI;
-                    if ((VARIANT & 1) || (flags & GEMM_OVERWRITE) || grow >= M || gcol + VEC > N) {
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) cv[it][e] = T(0);
-                    } else {
-                        cv[it] = *reinterpret_cast<const VT*>(Ct + grow * ldc + gcol);
-                    }
-                }
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const int64_t grow = grow0 + it * RPI;
-                    const VT v = *reinterpret_cast<const VT*>(stg + (it * RPI + rloc) * WN + cloc);
-                    if (grow < M) {
-                        if (gcol + VEC <= N) {
-                            *reinterpret_cast<VT*>(Ct + grow * ldc + gcol) = (flags & GEMM_OVERWRITE) ? v : cv[it] - v;
-                        } else {  // ragged right edge (only the P x P full_cov update gets here)
-#pragma unroll
-                            for (int e = 0; e < VEC; ++e)
-                                if (gcol + e < N) Ct[grow * ldc + gcol + e] = (flags & GEMM_OVERWRITE) ? v[e] : Ct[grow * ldc + gcol + e] - v[e];
+                        for (int r = 0; r < 4; ++r) {
+                            const T v = acc[mi][ni].v[r];
+                            Cw[c_index(ld2, ln2, mi, ni, r)] = negate ? -v : v;
                         }
-                    }
-                }
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const T v = acc[mi][ni].v[r];
+                            if (c_valid(mi, ni, r)) Cw[c_index(ld2, ln2, mi, ni, r)] = negate ? -v : v;
+                        }
             }
         }
-        if (!qa.use_queue) {
-            if constexpr (VARIANT & 128) tk_epi += wall_clock64() - tk2;
-            break;
-        }
-        if (tid == 0) s_tile = (long long)(pulled - qa.base[xcd]) + cbeg + nloc;
-        __syncthreads();  // publishes the next tile; also: every wave has left the epilogue's LDS buffers
-        t = __builtin_amdgcn_readfirstlane((int)s_tile);  // scalar: the decode runs on the SALU
-        // (the next write of s_tile is a whole K loop of barriers away: no second barrier needed)
+        // No barrier here: the epilogue touches no LDS, and the next tile's first DMA may overwrite the slab buffers
+        // because every wave left its last fragment read before the K loop's final barrier.
+        t = t_next;
         if constexpr (VARIANT & 128) {
             const long long tk3 = wall_clock64();
             tk_epi += tk3 - tk2;
             const int half = (int)(gridDim.x >> 1);
-            if (tid == 0 && tk_n <= 24 && (blockIdx.x == 40 || blockIdx.x == 40 + half)) {
+            if (qa.use_queue && tid == 0 && tk_n <= 24 && (blockIdx.x == 40 || blockIdx.x == 40 + half)) {
                 unsigned long long* st = queue + 64 + 2048 + (blockIdx.x == 40 ? 0 : 96) + 4 * (tk_n - 1);
                 st[0] = (unsigned long long)tk0;
                 st[1] = (unsigned long long)tk1;
@@ -463,7 +489,12 @@ template void launch_gemm_nt<float>(gpmi_ctx*, float*, int64_t, const float*, in
 template <typename T, int V>
 static void launch_variant(gpmi_ctx* ctx, T* C, int64_t ld, const T* A, int64_t M, int64_t N, int64_t K, int lower) {
     const TileShape shape{0, 0, lower ? 1 : 0, 0, 1, 0};
-    launch_persistent<T, V>(ctx, C, ld, A, ld, A, ld, M, N, K, shape, nullptr, 0, nullptr, use_narrow_tiles(ctx, M, N, shape, nullptr));
+    int flags = 0;
+    if (V & 32) {
+        const char* e = getenv("GPMI_STAGGER_US");
+        flags = (int)((e ? atof(e) : 80.0) * 100.0) << 16;
+    }
+    launch_persistent<T, V>(ctx, C, ld, A, ld, A, ld, M, N, K, shape, nullptr, flags, nullptr, use_narrow_tiles(ctx, M, N, shape, nullptr));
 }
 
 template <typename T>
@@ -495,6 +526,8 @@ int gemm_bench(gpmi_ctx* ctx, int64_t M, int64_t N, int64_t K, int lower, int va
             case 14: launch_variant<T, 14>(ctx, C, ld, A, M, N, K, lower); break;
             case 22: launch_variant<T, 22>(ctx, C, ld, A, M, N, K, lower); break;
             case 30: launch_variant<T, 30>(ctx, C, ld, A, M, N, K, lower); break;
+            case 32: launch_variant<T, 32>(ctx, C, ld, A, M, N, K, lower); break;
+            case 160: launch_variant<T, 160>(ctx, C, ld, A, M, N, K, lower); break;
             case 128: launch_variant<T, 128>(ctx, C, ld, A, M, N, K, lower); break;
             case 512: launch_variant<T, 512>(ctx, C, ld, A, M, N, K, lower); break;
             case 640: launch_variant<T, 640>(ctx, C, ld, A, M, N, K, lower); break;

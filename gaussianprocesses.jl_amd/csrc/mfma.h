@@ -28,6 +28,7 @@ struct Mfma4x4d {
     static constexpr int E = 2;
     static constexpr int BK = 16;
     static constexpr int NR = 4;  // accumulator registers per 16 x 16 tile
+    static constexpr bool NEG = false;
     struct Acc {
         double v[4];
     };
@@ -42,6 +43,7 @@ struct Mfma4x4d {
 #pragma unroll
         for (int r = 0; r < 4; ++r) c.v[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, br[r], c.v[r], 0, 0, 0);
     }
+    static __device__ __forceinline__ void mma_sub(double a, const double (&br)[4], Acc& c) { mma(a, br, c); }
     // acc register r of lane (j + 4b + 16i) holds C[row 4b + i][col 4((b + r) & 3) + j]
     static __device__ __forceinline__ int row_of(int lane, int) { return ((lane >> 2) & 3) * 4 + (lane >> 4); }
     static __device__ __forceinline__ int col_of(int lane, int r) { return ((((lane >> 2) & 3) + r) & 3) * 4 + (lane & 3); }
@@ -61,8 +63,14 @@ struct Mfma<double> {
     static __device__ __forceinline__ void mma(double a, const double (&br)[4], Acc& c) {
         c.v = __builtin_amdgcn_mfma_f64_16x16x4f64(a, br[0], c.v, 0, 0, 0);
     }
+    // c -= a b': the fp64 MFMAs reuse the BLGP field as neg:[a, b, c] modifiers, so the subtraction is free
+    static constexpr bool NEG = true;
+    static __device__ __forceinline__ void mma_sub(double a, const double (&br)[4], Acc& c) {
+        c.v = __builtin_amdgcn_mfma_f64_16x16x4f64(a, br[0], c.v, 0, 0, 1);
+    }
     // probed on hardware (tools/mfma16_probe.hip): register r of lane l holds D[row 4 r + (l >> 4)][col l & 15]
     // (NOT the fp32 instruction's 4 (l >> 4) + r)
+    static constexpr int RSTEP = 4;  // rows between consecutive accumulator registers
     static __device__ __forceinline__ int row_of(int lane, int reg) { return 4 * reg + (lane >> 4); }
     static __device__ __forceinline__ int col_of(int lane, int) { return lane & 15; }
 };
@@ -81,7 +89,11 @@ struct Mfma<float> {
     static __device__ __forceinline__ void mma(float a, const float (&br)[4], Acc& c) {
         c.v = __builtin_amdgcn_mfma_f32_16x16x4f32(a, br[0], c.v, 0, 0, 0);
     }
+    // (no neg modifiers on the fp32 MFMAs: callers that want c - a b' keep -c in the accumulator, see gemm.hip)
+    static constexpr bool NEG = false;
+    static __device__ __forceinline__ void mma_sub(float a, const float (&br)[4], Acc& c) { mma(a, br, c); }
     // v_mfma_f32_16x16x4_f32 C/D map: col = lane & 15, row = 4 * (lane >> 4) + reg
+    static constexpr int RSTEP = 1;
     static __device__ __forceinline__ int row_of(int lane, int reg) { return 4 * (lane >> 4) + reg; }
     static __device__ __forceinline__ int col_of(int lane, int) { return lane & 15; }
 };
