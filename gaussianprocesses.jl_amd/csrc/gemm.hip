@@ -20,8 +20,8 @@
 //   16-byte-padded LDS image filled with coalesced 16-B loads (one cache line per row);
 //   fragments are read with ds_read_b128 (E consecutive k per lane — the k permutation is
 //   identical for A and B, so the dot products are unchanged);
-//   2 workgroups per CU (launch_bounds(256, 2)): one group's epilogue / global loads hide
-//   under the other's MFMA stream, which is the only busy pipe.
+//   2 workgroups per CU (launch_bounds(256, 2)): one group's LDS reads and barrier gaps hide under the other's
+//   MFMA stream (their C loads do not: co-resident groups phase-lock, see below).
 // Tile order is XCD-aware: block b runs on XCD b % 8, so each XCD gets a contiguous run of
 // 8 x 8 super-tiles (64 concurrent tiles share 16 operand panels in that XCD's 4 MiB L2).
 #include <algorithm>
@@ -37,9 +37,10 @@ namespace gpmi {
 namespace {
 
 // VARIANT bits are ablation switches used only by gpmi_bench_gemm (0 = the product kernel):
-//   1 no C read in the epilogue   2 no epilogue at all   4 no global loads inside the K loop
-//   8 no DPP rotations            16 no LDS fragment reads inside the K loop
-//   32 s_setprio(1) around the MFMA cluster (experiment)
+//   1 no C read (accumulators start at zero)   2 no stores (no epilogue at all)   4 no global loads inside the K loop
+//   8 no DPP rotations (4x4x4 form only)       16 no LDS fragment reads inside the K loop
+//   32 start of each CU pair delayed by a hash of its index (GPMI_STAGGER_US; measured neutral)
+//   128 phase timers + timelines (tools/gemm_phases.py)   512 the four-instruction 4x4x4 + DPP form of the fp64 product
 //
 // PERSISTENT kernel: the grid is at most 2 workgroups per CU.  Tiles are numbered in the order of
 // tile_order.h and split into 8 contiguous chunks, one per XCD (workgroup b runs on XCD b % 8 — an
@@ -91,10 +92,11 @@ __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __rest
         return;
     }
 
-    // Co-residency (tools/slot_probe.hip, tools/gemm_phases.py): the two workgroups of a CU are (b, b + gridDim/2); the
-    // one in wave slot 0 wins the MFMA arbitration (oldest first) and runs its tiles at lone-workgroup speed (68 us at
-    // K = 256), the slot-1 workgroup fills the gaps (135 us per tile).  Anti-phasing the pair with a start delay and
-    // alternating s_setprio per slab were both measured neutral (43.5 TFLOP/s either way), so neither is done.
+    // Co-residency (tools/slot_probe.hip, tools/gemm_phases.py): the two workgroups of a CU are (b, b + gridDim/2).  With
+    // the 16x16x4 instruction they advance at the same rate and PHASE-LOCK (both load C, then both compute: the one that
+    // is behind has the MFMA pipe to itself while the leader loads, and catches up).  Start delays, s_setprio for one of
+    // the pair, C fetched inside the K loop and a per-CU load token were all measured neutral
+    // (profiles/r01_gemm_c_traffic_experiments.log), so none of them is done.
     if constexpr (VARIANT & 32) {  // experiment: spread the CUs' tile phases over one tile period (C traffic bursts)
         const unsigned half = gridDim.x >> 1;
         const unsigned c = blockIdx.x % half;  // CU pair index
