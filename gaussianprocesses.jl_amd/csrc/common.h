@@ -182,7 +182,8 @@ template <typename T>
 void launch_gemm_shape(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M,
                        int64_t N, int64_t K, TileShape shape, const int* info, int flags = 0, const GemmBatch* batch = nullptr);
 enum GemmFlags { GEMM_OVERWRITE = 1 /* C = A B' instead of C -= A B' */, GEMM_KSTART_ROW = 2 /* A[i][k] = 0 for k < i: start K at the tile's first row */,
-                 GEMM_AUX = 4 /* no effect on the kernel: account the launch to the panel class, not to the trailing update */ };
+                 GEMM_AUX = 4 /* no effect on the kernel: account the launch to the panel class, not to the trailing update */,
+                 GEMM_NO_PAIR16 = 32 /* tools: 8-byte instead of 16-byte C accesses in fp64 (A/B of the access width) */ };
 
 // in-place Cholesky of the 64 x 64 block at A (row-major, ld): lower factor, upper part zeroed; linv (64 x 64,
 // row-major, ld 64) receives L^-1 and invdiag[0..64) 1 / L_jj.  On a non-positive pivot j (0-based) writes

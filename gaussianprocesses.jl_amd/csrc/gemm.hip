@@ -174,6 +174,10 @@ __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __rest
         //   !NEG: acc = -C + A B', stored negated   (OVERWRITE: acc = A B')
         const bool overwrite = (flags & GEMM_OVERWRITE) != 0;
         const bool interior = mrem == BM - 1 && nrem == BN - 1;
+        // 16-byte C accesses (fp64, 16x16x4 accumulator layout only) need even leading dimension and 16-byte aligned rows
+        constexpr bool PAIR16 = std::is_same<T, double>::value && std::is_same<MF, Mfma<double>>::value;
+        using V2 = double __attribute__((ext_vector_type(2)));
+        const bool pair16 = PAIR16 && !(ldc & 1) && !(reinterpret_cast<uintptr_t>(Ct + n0) & 15) && !(flags & GEMM_NO_PAIR16);
         const int lrow = wm * 64, lcol = wn * WN;  // this wave's corner inside the tile
         T* __restrict__ const Cw = Ct + (m0 + lrow) * ldc + n0 + lcol;
         auto c_index = [&](int64_t ld, int ln, int mi, int ni, int r) -> int64_t {
@@ -195,6 +199,24 @@ __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __rest
                 for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[mi][ni].v[r] = T(0);
+        } else if (interior && pair16) {
+            // fp64, 16 bytes per lane: the even lane of a pair fetches (c, c+1) of the row of register 2q, the odd lane
+            // (c-1, c) of the row of register 2q+1, and the two swap the halves that belong to the other (quad_perm DPP)
+            if constexpr (PAIR16) {
+                const bool odd = (lane & 1) != 0;
+                const T* pb = Cw + (int64_t)((odd ? 4 : 0) + (lane >> 4)) * ldc + ((lane & 15) & ~1);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const V2 v = *reinterpret_cast<const V2*>(pb + (int64_t)(mi * 16 + 8 * q) * ldc + ni * 16);
+                            const double recv = dpp_rot<0xB1>(odd ? v[0] : v[1]);  // the neighbour's half
+                            acc[mi][ni].v[2 * q] = odd ? recv : v[0];
+                            acc[mi][ni].v[2 * q + 1] = odd ? v[1] : recv;
+                        }
+            }
         } else if (interior) {
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
@@ -319,7 +341,26 @@ __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __rest
             int64_t ld2 = ldc;
             int ln2 = lane;
             asm volatile("" : "+s"(ld2), "+v"(ln2));
-            if (interior) {
+            if (interior && pair16) {
+                if constexpr (PAIR16) {
+                    const bool odd = (ln2 & 1) != 0;
+                    T* pb = Cw + (int64_t)((odd ? 4 : 0) + (ln2 >> 4)) * ld2 + ((ln2 & 15) & ~1);
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) {
+                                const double a0 = negate ? -acc[mi][ni].v[2 * q] : acc[mi][ni].v[2 * q];
+                                const double a1 = negate ? -acc[mi][ni].v[2 * q + 1] : acc[mi][ni].v[2 * q + 1];
+                                const double recv = dpp_rot<0xB1>(odd ? a0 : a1);
+                                V2 v;
+                                v[0] = odd ? recv : a0;
+                                v[1] = odd ? a1 : recv;
+                                *reinterpret_cast<V2*>(pb + (int64_t)(mi * 16 + 8 * q) * ld2 + ni * 16) = v;
+                            }
+                }
+            } else if (interior) {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -416,6 +457,8 @@ static void launch_persistent_ni(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, i
         // the chunk is smaller than the XCD's workgroup count): the word advances by `chunk` either way
         if (qa.use_queue) ctx->queue_base[x] += (unsigned long long)(qa.start[x + 1] - qa.start[x]);
     }
+    static const bool no_pair16 = getenv("GPMI_GEMM_NO_PAIR16") != nullptr;  // tools: A/B of the C access width
+    if (no_pair16) flags |= GEMM_NO_PAIR16;
     hipLaunchKernelGGL((gemm_nt_kernel<T, V, NI>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, C, ldc, A, lda, B, ldb, M, N,
                        K, shape, ctx->d_queue, qa, info, flags);
 }
