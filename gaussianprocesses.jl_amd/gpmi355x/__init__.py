@@ -5,7 +5,7 @@ hierarchy; all covariance / Cholesky / solve arithmetic runs in libgpmi.so (HIP,
 Importing this package never imports anything under oracle/ and there is no CPU fallback.
 """
 from ._lib import ArgumentError, Context, DeviceError, PosDefException, load  # noqa: F401
-from .gpe import (FITC, GP, GPE, HIPPDMat, get_params, logp_LOO, optimize, predict_f, predict_LOO, predict_y,  # noqa: F401
+from .gpe import (FITC, GP, GPE, HIPPDMat, get_params, logp_LOO, optimize, optimize_bounds, predict_f, predict_LOO, predict_y,  # noqa: F401
                   set_params,
                   update_mll, update_target)
 from .kernels import (RQ, SE, Const, FixedKernel, Kernel, Masked, Mat12Ard, Mat12Iso, Mat32Ard,  # noqa: F401

@@ -332,10 +332,44 @@ def set_params(gp, hyp, **kw):
     return gp.set_params(hyp, **kw)
 
 
-def optimize(gp, noise=True, domean=True, kern=True, method="L-BFGS-B", options=None):
+def optimize_bounds(gp, noisebounds=None, meanbounds=None, kernbounds=None, noise=True, domean=True, kern=True):
+    """bounds(gp, ...) — src/GPE.jl:467-490: lower/upper vectors in get_params order (noise, mean, kernel), infinite where
+    no pair is given.  Returns None when no bound is given at all (the reference then runs the unconstrained optimizer),
+    else a list of (lower, upper) per parameter."""
+    if noisebounds is None and meanbounds is None and kernbounds is None:
+        return None
+    lb, ub = [], []
+
+    def append(n, pair, what):
+        if n == 0:
+            return
+        if pair is None:
+            lb.extend([-math.inf] * n)
+            ub.extend([math.inf] * n)
+            return
+        lo, hi = (np.atleast_1d(np.asarray(v, dtype=float)) for v in pair)
+        if len(lo) != n or len(hi) != n:
+            raise _lib.ArgumentError("%s bounds need %d lower and %d upper values" % (what, n, n))
+        lb.extend(lo.tolist())
+        ub.extend(hi.tolist())
+
+    if noise:
+        append(gp.num_params(noise=True, domean=False, kern=False), noisebounds, "noise")
+    if domean:
+        append(gp.mean.num_params(), meanbounds, "mean")
+    if kern:
+        append(gp.kernel.num_params(), kernbounds, "kernel")
+    return list(zip(lb, ub))
+
+
+def optimize(gp, noise=True, domean=True, kern=True, method="L-BFGS-B", options=None, meanbounds=None, kernbounds=None,
+             noisebounds=None):
     """optimize!(gp) — src/optimize.jl:19-37 with its error contract (:48-58, :74-83): a PosDefException /
     ArgumentError during an evaluation restores the previous parameters and the point is reported as infeasible
-    (Inf, zero gradient).  Target and gradient come from the device (update_target_and_dtarget!, GPE.jl:387-392)."""
+    (Inf, zero gradient).  Target and gradient come from the device (update_target_and_dtarget!, GPE.jl:387-392).
+    `noisebounds` / `meanbounds` / `kernbounds` are (lower, upper) pairs of per-parameter vectors as in the reference
+    (GPE.jl:467-490: unbounded where a pair is missing); they switch the reference to Fminbox, here they go to the
+    bound-constrained L-BFGS-B."""
     from scipy.optimize import minimize
 
     kw = dict(noise=noise, domean=domean, kern=kern)
@@ -351,7 +385,8 @@ def optimize(gp, noise=True, domean=True, kern=True, method="L-BFGS-B", options=
             return math.inf, np.zeros(len(hyp))
 
     x0 = np.asarray(gp.get_params(**kw), dtype=float)
-    res = minimize(fg, x0, jac=True, method=method, options=options or {"maxiter": 20})
+    box = optimize_bounds(gp, noisebounds, meanbounds, kernbounds, **kw)
+    res = minimize(fg, x0, jac=True, method=method, bounds=box, options=options or {"maxiter": 20})
     gp.set_params(res.x, **kw)
     gp.update_target()
     return res
