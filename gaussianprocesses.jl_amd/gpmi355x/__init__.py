@@ -11,6 +11,8 @@ from .gpe import (FITC, GP, GPE, HIPPDMat, get_params, logp_LOO, optimize, optim
 from .kernels import (RQ, SE, Const, FixedKernel, Kernel, Masked, Mat12Ard, Mat12Iso, Mat32Ard,  # noqa: F401
                       Mat32Iso, Mat52Ard, Mat52Iso, Matern, Noise, ProdKernel, RQArd, RQIso, SEArd,
                       SEIso, SumKernel, fix, from_spec)
+from .priors import Normal, Uniform, get_priors, prior_gradlogpdf, prior_logpdf, set_priors  # noqa: F401
+from . import priors  # noqa: F401
 from .means import Mean, MeanConst, MeanLin, MeanPeriodic, MeanPoly, MeanZero, ProdMean, SumMean  # noqa: F401
 from .sparse import FullyIndepPDMat, FullyIndepStrat  # noqa: F401
 

@@ -23,6 +23,7 @@ import math
 import numpy as np
 
 from . import _lib
+from . import priors as _priors
 from .kernels import Kernel
 from .means import Mean, MeanZero
 
@@ -185,16 +186,41 @@ class GPE:
         self.target = self.mll
         return self.update_dmll(**kw)
 
-    update_target_and_dtarget = update_mll_and_dmll  # GPE.jl:387-392 (no priors on this path)
+    # -- target = mll + log prior : GPE.jl:346-392, 514-526 ----------------------
+    @property
+    def noise_param(self):
+        """gp.logNoise as a parameter object: set_priors(gp.noise_param, [Normal(-1.0, 0.5)])."""
+        if getattr(self, "_noise_param", None) is None:
+            self._noise_param = _priors.NoiseParam(self)
+        return self._noise_param
 
-    def initialise_target(self):  # GPE.jl:346-350 (no priors on this path)
+    def _prior_logpdf(self):
+        return _priors.prior_logpdf(self.mean) + _priors.prior_logpdf(self.kernel) + _priors.prior_logpdf(self.noise_param)
+
+    def prior_gradlogpdf(self, noise=True, domean=True, kern=True):  # GPE.jl:514-526
+        parts = []
+        if noise:
+            parts.append(_priors.prior_gradlogpdf(self.noise_param))
+        if domean:
+            parts.append(_priors.prior_gradlogpdf(self.mean))
+        if kern:
+            parts.append(_priors.prior_gradlogpdf(self.kernel))
+        return np.concatenate(parts) if parts else np.zeros(0)
+
+    def update_target_and_dtarget(self, **kw):  # GPE.jl:387-392
+        self.update_mll_and_dmll(**kw)
+        self.target = self.mll + self._prior_logpdf()
+        self.dtarget = self.dmll + self.prior_gradlogpdf(**kw)
+        return self
+
+    def initialise_target(self):  # GPE.jl:346-350
         self.update_mll()
-        self.target = self.mll
+        self.target = self.mll + self._prior_logpdf()
         return self
 
     def update_target(self, **kw):  # GPE.jl:361-365
         self.update_mll(**kw)
-        self.target = self.mll
+        self.target = self.mll + self._prior_logpdf()
         return self
 
     # -- predict : GP.jl:64-84, GPE.jl:408-416 ---------------------------------
