@@ -5,7 +5,7 @@ Mirrors, with the same argument meaning and error behaviour:
     GP(x, y, mean, kernel, logNoise=-2.0)      src/GPE.jl:92-120
     GPE.fit!(gp, x, y)                         src/GPE.jl:128-138
     update_cK! / update_mll!(gp; noise, domean, kern)   src/GPE.jl:169-212
-    initialise_target! / update_target!        src/GPE.jl:346-365 (no priors: target == mll)
+    initialise_target! / update_target!        src/GPE.jl:346-365 (target = mll + log prior, priors.py)
     predict_f / predict_y (full_cov)           src/GP.jl:64-84, src/GPE.jl:408-416
     get_params / set_params! / num_params      src/GPE.jl:447-512
     optimize!                                  src/optimize.jl:19-97 (error contract only)
