@@ -7,15 +7,25 @@ product path (``gaussianprocesses.jl_amd/``) never imports this module and has
 no CPU fallback.
 
 PARITY PINNING.  The reference (Julia) cannot be executed in the build
-container and its test-suite holds **no stored numeric golden for the exact
-path** (SURVEY.md §8c).  This restatement is therefore pinned by
+container, and its test-suite stores no numeric golden for the exact path
+(SURVEY.md §8c).  What the reference DOES hold are numbers it printed itself:
+the documentation transcripts ``docs/src/Regression.md`` (mll, 2 x 20
+predictive means / variances, the optimiser's minimum and minimiser for a
+1-d SEIso model; mll and optimum for a 2-d Mat52Ard + SEIso model) and
+``docs/src/sparse_example.md`` (exact mll at n = 5000 to 8 digits), plus the
+stored FITC value of ``test/test_sparse.jl:156``.  All sit on inputs drawn from
+Julia's RNG; ``oracle/julia_mt.py`` restates that RNG and the transcripts print
+enough of their inputs to prove the regenerated stream right.  This oracle is
+pinned by those reference-produced numbers
+(``tests/test_reference_goldens.py``, transcription with file:line in
+``tests/golden/reference_transcripts.py``), and additionally by
   (i)  the relational properties the reference tests assert (tests/test_oracle.py
        mirrors test/kernels.jl:39-41,55-60, test/gp.jl:47-53),
   (ii) an independent implementation of the same mathematics (scikit-learn's
        GaussianProcessRegressor, tests/test_oracle.py::test_vs_sklearn_*), and
   (iii) closed forms for N = 1, 2.
-There are no reference-produced outputs to compare with: *parity unpinned by
-reference outputs* (see DESIGN.md).
+Kernels the transcripts do not exercise (Mat12/Mat32, RQ, Noise, Const,
+Masked, Fixed, Prod) are pinned by (i)-(iii) only.
 
 Every function cites the reference file:line it follows (paths relative to
 /root/reference).  Arrays use the reference orientation: ``x`` is ``d × N``

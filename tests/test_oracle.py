@@ -1,7 +1,8 @@
 """Pins the CPU oracle (oracle/) — the checker every GPU parity test relies on.
 
-The reference stores no numeric golden for the exact-GP path, so
-the oracle is pinned by (i) the relational properties the reference's own tests
+Numbers the reference produced itself (documentation transcripts, the stored FITC
+value) are checked in tests/test_reference_goldens.py.  For everything those do not
+exercise the oracle is pinned here by (i) the relational properties the reference's own tests
 assert, (ii) scikit-learn as an independent implementation of the same maths,
 (iii) closed forms, (iv) agreement of the two restatements (NumPy vs scalar C).
 """
