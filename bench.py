@@ -4,26 +4,34 @@
 One "step" = the reference's steady-state unit of work:
     set_params!(gp, hyp)  ->  update_mll!(gp)  ->  predict_f(gp, xpred)      (full_cov=false)
 with x already resident in HBM (uploaded once by GP(), as fit! does) and the hyper-parameters
-perturbed every step so nothing can be cached.  Workload at N=1: BASELINE.json configs[1]
-(N=20000, d=8, SEArd, fp64, MeanZero, P=1024 test points, SURVEY §8d hyper-parameters).
+perturbed every step so nothing can be cached.
 
-N > 1 (one process per GPU, torchrun): by default every rank runs its own fit (the metric's unit is a fit, the
-units are independent: weak scaling, no data-path collective) and, as an extra "sharded_leg", ONE fit of the same
-size is also run row-block sharded over all GPUs with the RCCL panel all-gather (gpmi355x.dist); `--mode sharded`
-makes that the measured workload instead (strong scaling).  The extra leg runs AFTER the JSON line has been printed and
-reports on stderr / gpurun_out/sharded_leg_<N>.json.
+Workload (the configuration BASELINE.json's north-star target is quoted on):
+    N = 50 000, d = 8, SEArd + MeanZero, fp64, P = 1024 test points, SURVEY §8d hyper-parameters.
+The same JSON line carries secondary objects: "c2" (BASELINE configs[1], N = 20 000, a few steps) and, on one GPU,
+"c4_single_gpu" (N = 200 000, d = 16, fp32 — the size north_star's multi-GPU target is quoted on — as ONE fit on one
+GPU, so that a strong-scaling curve has its single-GPU point).
+
+`--gpus N` (N > 1): one process per GPU.  When no launcher set WORLD_SIZE this script re-executes itself under
+`python -m torch.distributed.run --nproc-per-node N` (and fails loudly if the box has fewer GPUs).  The measured
+workload is then ONE fit of the same N = 50 000 problem row-block SHARDED over the N GPUs (RCCL panel exchange,
+gpmi355x.dist): strong scaling, `value` = fits/s of the whole job.  `--mode replicas` runs N independent fits instead.
+A secondary object "c4_sharded" times one N = 200 000, d = 16, fp32 fit sharded over the same GPUs.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     — the dominant kernel (Cholesky trailing update, MFMA-bound): algorithmic flops per
                  launch / mean launch duration, measured live with HIP events on the library's
                  stream over the timed region (gpmi_profile_*).
-  cpu_baseline — the CPU oracle (a port: the Julia reference cannot run here) timed on this host
-                 on a bounded sample and scaled to the bench size stage by stage.
+  cpu_baseline — the CPU oracle (a port: the Julia reference cannot run here) MEASURED on this host at the bench size
+                 (one fit + predict; cov! single-threaded C like the reference's loop, LAPACK on the host's cores),
+                 with the CPU model, core count and BLAS thread count recorded.
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,21 +44,22 @@ for p in (ROOT, os.path.join(ROOT, "gaussianprocesses.jl_amd")):
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (v_mfma_f64_16x16x4_f64): 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: Peak FP32 (matrix)
+PMC_RECORD = os.path.join("profiles", "r02_bench_pmc_hbm.json")
 
 
 def _pmc_traffic(args, n, d, p):
     """HBM bytes per launch of the roofline kernel.  PMC counters cannot be read from inside the timed process, so the
     number comes from the committed summary of the separate rocprofv3 --pmc passes over THIS command
-    (tools/gpu_pmc_bench.sh -> profiles/r01_bench_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE in their own passes, the
+    (tools/gpu_pmc_bench.sh -> profiles/r02_bench_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE in their own passes, the
     gfx950 x2 read correction of MI355X_MICROARCH.md applied).  It only applies to the default workload; anything
     else reports null."""
-    path = os.path.join(ROOT, "profiles", "r01_bench_pmc_hbm.json")
-    default = (n, d, p, args.dtype) == (20000, 8, 1024, "f64")
+    path = os.path.join(ROOT, PMC_RECORD)
+    default = (n, d, p, args.dtype) == (50000, 8, 1024, "f64")
     if not default or not os.path.exists(path):
         return {"traffic": None}
     try:
         j = json.load(open(path))
-        return {"traffic": j["traffic_bytes_per_launch"], "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_bench_pmc_hbm.json)"}
+        return {"traffic": j["traffic_bytes_per_launch"], "traffic_unit": f"HBM bytes per launch (PMC, {PMC_RECORD})"}
     except Exception:
         return {"traffic": None}
 
@@ -65,24 +74,49 @@ def synthetic_inputs(n, d, p, seed=20240501):
     return x, y, xpred
 
 
-def cpu_baseline(n_bench, d, p, ll, n_sample):
-    """Oracle timed on the host: cov! as the reference's single-threaded scalar loop (C), LAPACK
-    dpotrf/dpotrs/dtrsm on all cores; scaled from n_sample to n_bench per stage (N^2 / N^3)."""
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle, measured
+# ----------------------------------------------------------------------------------------------------------------------
+def _host_description():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    blas = []
+    try:
+        import scipy.linalg  # noqa: F401  (loads the BLAS the oracle's LAPACK calls run on)
+        from threadpoolctl import threadpool_info
+
+        for lib in threadpool_info():
+            blas.append({k: lib.get(k) for k in ("internal_api", "version", "num_threads", "threading_layer") if lib.get(k) is not None})
+    except Exception:  # noqa: BLE001
+        pass
+    nthreads = max([b.get("num_threads", 1) for b in blas if b.get("internal_api") in ("openblas", "mkl", "blis")] or [1])
+    return model, blas, nthreads
+
+
+def _cpu_fit_predict(n, d, p, ll):
+    """One oracle fit + predict at size n, timed per stage.  Returns (seconds per stage, total)."""
     import scipy.linalg as sla
 
     from oracle import c_oracle
     from oracle import gp_oracle as G
 
-    x, y, xs = G.synthetic_inputs(n_sample, d, p)
+    x, y, xs = G.synthetic_inputs(n, d, p)
     spec = ("se_ard", ll, 0.0)
     t0 = time.perf_counter()
-    K = c_oracle.assemble(spec, x, math.log(0.1))
+    K = c_oracle.assemble(spec, x, math.log(0.1))           # cov! + nugget: the reference's single-threaded loop
     t1 = time.perf_counter()
-    U, info = sla.lapack.dpotrf(K, lower=0, clean=0, overwrite_a=1)
+    U, info = sla.lapack.dpotrf(K, lower=0, clean=0, overwrite_a=1)   # make_posdef! (LAPACK, all cores)
+    del K
     assert info == 0
     t2 = time.perf_counter()
     alpha = sla.cho_solve((U, False), y)
-    mll = -(float(y @ alpha) + 2.0 * np.sum(np.log(np.diag(U))) + G.LOG2PI * n_sample) / 2.0
+    mll = -(float(y @ alpha) + 2.0 * np.sum(np.log(np.diag(U))) + G.LOG2PI * n) / 2.0
     t3 = time.perf_counter()
     Kc = c_oracle.cov(spec, x, xs)
     mu = Kc.T @ alpha
@@ -90,76 +124,140 @@ def cpu_baseline(n_bench, d, p, ll, n_sample):
     s2 = np.maximum(1.0 - np.sum(Lck * Lck, axis=0), 0.0)
     t4 = time.perf_counter()
     assert np.isfinite(mll) and np.all(np.isfinite(mu)) and np.all(np.isfinite(s2))
-    r = n_bench / n_sample
-    t_cov, t_chol, t_solve, t_pred = t1 - t0, t2 - t1, t3 - t2, t4 - t3
-    est = t_cov * r**2 + t_chol * r**3 + t_solve * r**2 + t_pred * r**2
+    return {"cov": t1 - t0, "dpotrf": t2 - t1, "dpotrs_mll": t3 - t2, "predict": t4 - t3}, t4 - t0, mll
+
+
+def cpu_baseline(n_bench, d, p, ll, budget_s):
+    """The oracle MEASURED at the bench size when a probe says it fits `budget_s`, otherwise at N = 20 000 (stated).
+    Nothing is scaled: `value` is 1 / (measured seconds) of the run named in `sample`."""
+    model, blas, nthreads = _host_description()
+    probe_n = min(6000, n_bench)
+    st, tot, _ = _cpu_fit_predict(probe_n, d, p, ll)
+    r = n_bench / probe_n
+    est = st["cov"] * r**2 + st["dpotrf"] * r**3 + st["dpotrs_mll"] * r**2 + st["predict"] * r**2
+    free_gb = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                free_gb = int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    need_gb = 8.0 * n_bench * n_bench / 1e9 * 1.15
+    n_meas = n_bench
+    why = ""
+    if est > budget_s or (free_gb is not None and free_gb < need_gb):
+        n_meas = min(20000, n_bench)
+        why = (f" (the bench size N={n_bench} was estimated at {est:.0f} s from a N={probe_n} probe / needs {need_gb:.0f} GB of "
+               f"host RAM, over the {budget_s:.0f} s budget: measured at N={n_meas} instead — NOT the bench size)")
+    st, tot, mll = _cpu_fit_predict(n_meas, d, p, ll)
     return {
-        "value": 1.0 / est,
+        "value": 1.0 / tot,
         "unit": "GP fits/sec",
         "cores": os.cpu_count(),
+        "blas_threads": nthreads,
         "kind": "port",
-        "sample": (f"oracle fit+predict measured at N={n_sample} d={d} P={p} "
-                   f"(cov! 1-thread C loop {t_cov:.2f}s, dpotrf {t_chol:.2f}s, dpotrs+mll {t_solve:.2f}s, "
-                   f"predict {t_pred:.2f}s = {1.0/(t4-t0):.4f} fits/s), scaled to N={n_bench} per stage (N^2/N^3)"),
+        "n_measured": n_meas,
+        "cpu_model": model,
+        "blas": blas,
+        "stage_s": st,
+        "mll": mll,
+        "sample": (f"ONE oracle fit+predict MEASURED at N={n_meas} d={d} P={p} SEArd fp64 in {tot:.2f} s: cov! single-threaded C "
+                   f"loop (like the reference's) {st['cov']:.2f} s, LAPACK dpotrf {st['dpotrf']:.2f} s on {nthreads} BLAS "
+                   f"threads ({os.cpu_count()} logical cores, {model}), dpotrs+mll {st['dpotrs_mll']:.2f} s, predict "
+                   f"{st['predict']:.2f} s; nothing scaled" + why),
     }
 
 
-def _main_json(args, world, elapsed, gp, n, d, p, fl_syrk, ms_syrk, n_syrk, ms_cov, by_cov, ms_pan, ms_sol, ms_pre, t_build,
-               scaling, sharded=False):
-    peak = FP64_MFMA_PEAK_TFLOPS if args.dtype == "f64" else FP32_MFMA_PEAK_TFLOPS
-    achieved = (fl_syrk / max(ms_syrk, 1e-9)) * 1e-9  # flop/ms -> TFLOP/s
-    nfits = args.steps if sharded else world * args.steps
-    if world == 1:
-        par = "single GPU"
-    elif sharded:
-        par = f"ONE fit row-block sharded over {world} GPUs (block-cyclic 256-row blocks, RCCL panel all-gather per step)"
+# ----------------------------------------------------------------------------------------------------------------------
+# one timed workload on this rank's GPU
+# ----------------------------------------------------------------------------------------------------------------------
+def _ll(d):
+    return [math.log(0.5) + 0.05 * k for k in range(d)]
+
+
+def run_workload(g, ctx, n, d, p, dtype, steps, warmup, barrier, comm=None):
+    """set_params -> update_mll -> predict_f, `steps` timed.  comm != None: ONE fit sharded over comm's ranks."""
+    import gc
+
+    import torch
+
+    gc.collect()
+    torch.cuda.empty_cache()  # the sharded path allocates through torch: hand a previous workload's blocks back
+    np_dt = np.float64 if dtype == "f64" else np.float32
+    x, y, xpred = synthetic_inputs(n, d, p)
+    ll = _ll(d)
+    log_noise = math.log(0.1)
+    t_build0 = time.perf_counter()
+    if comm is not None:
+        from gpmi355x import dist as gd
+
+        gp = gd.ShardedGPE(x, y, g.MeanZero(), g.SEArd(ll, 0.0), log_noise, dtype=np_dt, comm=comm, ctx=ctx)
     else:
-        par = f"{world} independent fits, one per GPU (the metric's unit is a fit: no data-path collective)"
+        gp = g.GP(x, y, g.MeanZero(), g.SEArd(ll, 0.0), log_noise, dtype=np_dt, ctx=ctx)  # uploads x, first fit
+    t_build = time.perf_counter() - t_build0
+    base = np.asarray(gp.get_params())
+
+    def step(i):
+        gp.set_params(base + 1e-3 * ((i % 7) + 1) * np.where(np.arange(len(base)) == 0, 0.0, 1.0))
+        gp.update_mll()
+        return gp.predict_f(xpred)
+
+    for i in range(warmup):
+        step(i)
+    ctx.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        mu, s2 = step(warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = {name: ctx.profile_get(getattr(g._lib, "PROF_" + name)) for name in ("SYRK", "COV", "PANEL", "SOLVE", "PREDICT")}
+    ctx.profile_enable(False)
+    assert np.all(np.isfinite(mu)) and np.all(np.isfinite(s2)) and math.isfinite(gp.mll)
+    return {"elapsed": elapsed, "prof": prof, "t_build": t_build, "mll": gp.mll, "ll": ll}
+
+
+def roofline_object(args, res, n, d, p, dtype, steps):
+    peak = FP64_MFMA_PEAK_TFLOPS if dtype == "f64" else FP32_MFMA_PEAK_TFLOPS
+    n_syrk, ms_syrk, fl_syrk = res["prof"]["SYRK"]
+    achieved = (fl_syrk / max(ms_syrk, 1e-9)) * 1e-9  # flop/ms -> TFLOP/s
+    es = 8 if dtype == "f64" else 4
     return {
-        "metric": "GP fits/sec (update_mll!+predict_f)",
-        "value": nfits / elapsed,
-        "unit": "GP fits/sec",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True,
-        "scaling": scaling,
-        "vs_baseline": None,
-        "dtype": args.dtype,
-        "data": "synthetic",
-        "config": {
-            "workload": f"N={n}, d={d}, SEArd + MeanZero, {args.dtype}, P={p} test points, full_cov=false "
-                        "(BASELINE.json configs[1])",
-            "parallelism": par,
-            "mll": gp.mll,
-        },
-        "roofline": {
-            "kernel": "gemm_nt_kernel<T, 0, 4> (Cholesky trailing update, 128x128 tiles, K=256, v_mfma_f64_16x16x4)",
-            "bound": "mfma",
-            "achieved": achieved,
-            "peak": peak,
-            "unit": "TFLOP/s",
-            "frac": achieved / peak,
-            **_pmc_traffic(args, n, d, p),
-            "launches": n_syrk,
-            "avg_launch_ms": ms_syrk / max(n_syrk, 1),
-            "algorithmic_flops_per_launch": fl_syrk / max(n_syrk, 1),
-            # C tile read + write (8 B each) per 2 * 256 flops of an entry; the 256-column panel itself is read once
-            "algorithmic_bytes_per_launch": fl_syrk / max(n_syrk, 1) / (2.0 * 256.0) * 2 * (8 if args.dtype == "f64" else 4),
-        },
-        "stage_ms_per_step": {
-            "cov": ms_cov / args.steps,
-            "cov_GBps": (by_cov / max(ms_cov, 1e-9)) * 1e-6,
-            "chol_trailing_update": ms_syrk / args.steps,
-            "panel_potf2_trsm_update": ms_pan / args.steps,
-            "alpha_solve_mll": ms_sol / args.steps,
-            "predict": ms_pre / args.steps,
-            "note": "per-class sums of HIP-event intervals; the panel chain runs on a side stream UNDER the trailing update "
-                    "(look-ahead), so the classes overlap and do not add up to ms_per_step",
-        },
-        "first_fit_incl_upload_s": t_build,
+        "kernel": "gemm_nt_kernel<T, 0, 4> (Cholesky trailing update, 128x128 tiles, v_mfma_f64_16x16x4)",
+        "bound": "mfma",
+        "achieved": achieved,
+        "peak": peak,
+        "unit": "TFLOP/s",
+        "frac": achieved / peak,
+        **_pmc_traffic(args, n, d, p),
+        "launches": n_syrk,
+        "avg_launch_ms": ms_syrk / max(n_syrk, 1),
+        "algorithmic_flops_per_launch": fl_syrk / max(n_syrk, 1),
+        # C tile read + write (es bytes each) per 2 * 256 flops of an entry; the panel itself is read once
+        "algorithmic_bytes_per_launch": fl_syrk / max(n_syrk, 1) / (2.0 * 256.0) * 2 * es,
     }
+
+
+def stage_object(res, steps):
+    pr = res["prof"]
+    return {
+        "cov": pr["COV"][1] / steps,
+        "cov_GBps": (pr["COV"][2] / max(pr["COV"][1], 1e-9)) * 1e-6,
+        "chol_trailing_update": pr["SYRK"][1] / steps,
+        "panel_potf2_trsm_update": pr["PANEL"][1] / steps,
+        "alpha_solve_mll": pr["SOLVE"][1] / steps,
+        "predict": pr["PREDICT"][1] / steps,
+        "note": "per-class sums of HIP-event intervals; the panel chain runs on a side stream UNDER the trailing update "
+                "(look-ahead), so the classes overlap and do not add up to ms_per_step",
+    }
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
 
 def main():
@@ -167,23 +265,41 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=20000)
+    ap.add_argument("--n", type=int, default=50000)
     ap.add_argument("--d", type=int, default=8)
     ap.add_argument("--p", type=int, default=1024)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--cpu-sample-n", type=int, default=10000)
+    ap.add_argument("--cpu-budget-s", type=float, default=240.0,
+                    help="the CPU baseline is measured at the bench size when a probe estimates it under this many seconds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", default="replicas", choices=["replicas", "sharded"],
-                    help="N>1: independent fits per GPU (default, the metric's unit is a fit) or ONE fit row-block "
-                         "sharded over the GPUs with the RCCL panel all-gather (gpmi355x.dist)")
-    ap.add_argument("--no-sharded-leg", action="store_true", help="N>1 replicas mode: skip the extra sharded measurement")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the c2 / c4 secondary objects")
+    ap.add_argument("--mode", default=None, choices=["replicas", "sharded"],
+                    help="N>1: ONE fit row-block sharded over the GPUs with the RCCL panel exchange (default, strong scaling) "
+                         "or independent fits per GPU (replicas, weak scaling); N=1: sharded runs the sharded code path on one GPU")
     args = ap.parse_args()
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        # no launcher: start one process per GPU ourselves (the contract's torchrun line)
+        import torch
+
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: this box has {have} GPU(s) visible; refusing to run fewer ranks "
+                             "than asked (no silent downgrade)")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X: no GPU visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -196,114 +312,131 @@ def main():
 
     import gpmi355x as g
 
+    mode = args.mode or ("sharded" if world > 1 else "single")
+    sharded = mode == "sharded"
     n, d, p = args.n, args.d, args.p
-    np_dt = np.float64 if args.dtype == "f64" else np.float32
-    x, y, xpred = synthetic_inputs(n, d, p)
-    ll = [math.log(0.5) + 0.05 * k for k in range(d)]
-    log_noise = math.log(0.1)
     ctx = g.Context.default(local_rank)
-    t_build0 = time.perf_counter()
-    sharded = args.mode == "sharded"
-    if sharded:
-        from gpmi355x import dist as gd
-
-        comm = gd.TorchDistComm() if dist is not None else gd.SingleComm()
-        gp = gd.ShardedGPE(x, y, g.MeanZero(), g.SEArd(ll, 0.0), log_noise, dtype=np_dt, comm=comm, ctx=ctx)
-    else:
-        gp = g.GP(x, y, g.MeanZero(), g.SEArd(ll, 0.0), log_noise, dtype=np_dt, ctx=ctx)  # uploads x, first fit
-    t_build = time.perf_counter() - t_build0
-    base = np.asarray(gp.get_params())
-
-    def step(i):
-        gp.set_params(base + 1e-3 * ((i % 7) + 1) * np.where(np.arange(len(base)) == 0, 0.0, 1.0))
-        gp.update_mll()
-        return gp.predict_f(xpred)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    ctx.profile_enable(True)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        mu, s2 = step(args.warmup + i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    n_syrk, ms_syrk, fl_syrk = ctx.profile_get(g._lib.PROF_SYRK)
-    n_cov, ms_cov, by_cov = ctx.profile_get(g._lib.PROF_COV)
-    n_pan, ms_pan, fl_pan = ctx.profile_get(g._lib.PROF_PANEL)
-    n_sol, ms_sol, _ = ctx.profile_get(g._lib.PROF_SOLVE)
-    n_pre, ms_pre, _ = ctx.profile_get(g._lib.PROF_PREDICT)
-    ctx.profile_enable(False)
+    def make_comm():
+        from gpmi355x import dist as gd
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        return gd.TorchDistComm() if dist is not None else gd.SingleComm()
+
+    def max_over_ranks(v):
+        if dist is None:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
 
-    assert np.all(np.isfinite(mu)) and np.all(np.isfinite(s2)) and math.isfinite(gp.mll)
+    res = run_workload(g, ctx, n, d, p, args.dtype, args.steps, args.warmup, barrier, comm=make_comm() if sharded else None)
+    elapsed = max_over_ranks(res["elapsed"])
 
     out = None
     if rank == 0:
-        out = _main_json(args, world, elapsed, gp, n, d, p, fl_syrk, ms_syrk, n_syrk, ms_cov, by_cov, ms_pan, ms_sol, ms_pre,
-                         t_build, "strong" if sharded else "weak", sharded)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, d, p, ll, min(args.cpu_sample_n, n))
+        nfits = args.steps if (sharded or world == 1) else world * args.steps
+        if world == 1:
+            par = "single GPU" + (" (sharded code path, one rank)" if sharded else "")
+        elif sharded:
+            par = f"ONE fit row-block sharded over {world} GPUs (block-cyclic 256-row blocks, RCCL panel exchange per step)"
+        else:
+            par = f"{world} independent fits, one per GPU (no data-path collective)"
+        out = {
+            "metric": "GP fits/sec (update_mll!+predict_f)",
+            "value": nfits / elapsed,
+            "unit": "GP fits/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak" if (world > 1 and not sharded) else "strong",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": f"N={n}, d={d}, SEArd + MeanZero, {args.dtype}, P={p} test points, full_cov=false "
+                            "(the configuration BASELINE.json's north-star target is quoted on)",
+                "parallelism": par,
+                "mll": res["mll"],
+            },
+            "roofline": roofline_object(args, res, n, d, p, args.dtype, args.steps),
+            "stage_ms_per_step": stage_object(res, args.steps),
+            "first_fit_incl_upload_s": res["t_build"],
+        }
 
-    # The ONE JSON line of the contract goes out first: nothing after this point can cost the measurement.
-    if rank == 0:
+    def secondaries(sec):
+        """c2 / c4 objects (none of them is `value`)."""
+        try:
+            c2 = run_workload(g, ctx, 20000, 8, 1024, "f64", 5, 2, barrier, comm=make_comm() if sharded else None)
+            c2_el = max_over_ranks(c2["elapsed"])
+            sec["c2"] = {
+                "workload": "N=20000, d=8, SEArd + MeanZero, f64, P=1024 (BASELINE.json configs[1]), 5 steps after 2 warm-ups",
+                "ms_per_step": 1e3 * c2_el / 5,
+                "fits_per_sec": 5 / c2_el,
+                "roofline_frac": roofline_object(args, c2, 20000, 8, 1024, "f64", 5)["frac"],
+                "stage_ms_per_step": {k: v for k, v in stage_object(c2, 5).items() if k != "note"},
+            }
+        except Exception as e:  # noqa: BLE001
+            sec["c2"] = {"error": repr(e)[:300]}
+        try:
+            # north_star's multi-GPU size as ONE fit: on one GPU (160 GB of fp32 factor fit the 288 GB) or sharded
+            c4 = run_workload(g, ctx, 200000, 16, 1024, "f32", 1, 0, barrier, comm=make_comm() if sharded else None)
+            c4_el = max_over_ranks(c4["elapsed"])
+            sec["c4_sharded" if (sharded and world > 1) else "c4_single_gpu"] = {
+                "workload": f"N=200000, d=16, SEArd + MeanZero, f32, P=1024: ONE fit+predict on {world} GPU(s), 1 step after the "
+                            "constructor's fit (BASELINE.json configs[3]'s size)",
+                "s_per_step": c4_el,
+                "fits_per_sec": 1.0 / c4_el,
+                "chol_equiv_TFLOPs": (200000.0 ** 3 / 3.0) / c4_el * 1e-12,
+                "mll": c4["mll"],
+            }
+        except Exception as e:  # noqa: BLE001
+            sec["c4_error"] = repr(e)[:300]
+
+    if world == 1:
+        if not args.no_secondary:
+            sec = {}
+            secondaries(sec)
+            out.update(sec)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, d, p, res["ll"], args.cpu_budget_s)
         print(json.dumps(out), flush=True)
+    else:
+        # The ONE JSON line of the contract goes out first: nothing after this point can cost the measurement.  The
+        # secondary workloads of a multi-GPU run are reported on stderr and in gpurun_out/secondary_<N>.json, cut by a watchdog.
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if not args.no_secondary:
+            import threading
 
-    # Extra leg (N > 1, replicas mode): the SAME workload as ONE fit row-block sharded over all GPUs, so that the RCCL
-    # panel all-gather path is exercised and timed on real multi-GPU hardware (this build's containers have one GPU: the
-    # path is covered by gloo / virtual-rank tests only).  Reported on stderr and in gpurun_out/sharded_leg_<N>.json,
-    # never on stdout; a hang is cut by the watchdog.
-    if world > 1 and not sharded and not args.no_sharded_leg:
-        import threading
+            done = threading.Event()
 
-        done = threading.Event()
+            def watchdog():
+                if not done.wait(420.0):
+                    if rank == 0:
+                        sys.stderr.write('[secondary] {"error": "no result within 420 s (watchdog)"}\n')
+                        sys.stderr.flush()
+                    os._exit(0)
 
-        def report(leg):
+            threading.Thread(target=watchdog, daemon=True).start()
+            sec = {}
+            secondaries(sec)
+            done.set()
             if rank == 0:
-                sys.stderr.write("[sharded_leg] " + json.dumps(leg) + "\n")
+                sys.stderr.write("[secondary] " + json.dumps(sec) + "\n")
                 sys.stderr.flush()
                 try:
                     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-                    with open(os.path.join(ROOT, "gpurun_out", f"sharded_leg_{world}.json"), "w") as fh:
-                        json.dump(leg, fh)
+                    with open(os.path.join(ROOT, "gpurun_out", f"secondary_{world}.json"), "w") as fh:
+                        json.dump(sec, fh)
                 except OSError:
                     pass
-
-        def watchdog():
-            if not done.wait(240.0):
-                report({"error": "no result within 240 s (watchdog)"})
-                os._exit(0)
-
-        threading.Thread(target=watchdog, daemon=True).start()
-        try:
-            from gpmi355x import dist as gd
-
-            sgp = gd.ShardedGPE(x, y, g.MeanZero(), g.SEArd(ll, 0.0), log_noise, dtype=np_dt, comm=gd.TorchDistComm(), ctx=ctx)
-            barrier()
-            ts = time.perf_counter()
-            nrep = 2
-            for i in range(nrep):
-                sgp.set_params(base + 1e-3 * (i + 1) * np.where(np.arange(len(base)) == 0, 0.0, 1.0))
-                sgp.update_mll()
-                smu, ss2 = sgp.predict_f(xpred)
-            barrier()
-            dt = (time.perf_counter() - ts) / nrep
-            leg = {"workload": f"ONE fit+predict of N={n} row-block sharded over {world} GPUs (RCCL panel all-gather)",
-                   "fits_per_sec": 1.0 / dt, "ms_per_step": 1e3 * dt, "mll": sgp.mll,
-                   "finite": bool(np.all(np.isfinite(smu)) and np.all(np.isfinite(ss2)))}
-        except Exception as e:  # noqa: BLE001
-            leg = {"error": repr(e)[:300]}
-        done.set()
-        report(leg)
 
     if dist is not None:
         try:

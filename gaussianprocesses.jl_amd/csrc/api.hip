@@ -723,6 +723,21 @@ int gpmi_factor_to_host(gpmi_gp* gp, void* U_out) {
     return GPMI_OK;
 }
 
+int gpmi_factor_diag(gpmi_gp* gp, void* diag_out) {
+    int rc = need_fit(gp, "gpmi_factor_diag");
+    if (rc) return rc;
+    gpmi_ctx* c = gp->ctx;
+    if (!diag_out) {
+        c->err = "gpmi_factor_diag: null output";
+        return GPMI_EARG;
+    }
+    GPMI_HIP(c, hipSetDevice(c->device));
+    const size_t es = gp->dtype == 64 ? 8 : 4;
+    // one element per row, source pitch ld + 1 elements
+    GPMI_HIP(c, hipMemcpy2D(diag_out, es, gp->A, (size_t)(gp->ld + 1) * es, es, (size_t)gp->n, hipMemcpyDeviceToHost));
+    return GPMI_OK;
+}
+
 int gpmi_profile_enable(gpmi_ctx* c, int on) {
     if (!c) return GPMI_EARG;
     int rc = drain_profile(c);

@@ -22,7 +22,7 @@ SYMBOLS = [
     "gpmi_ctx_create", "gpmi_ctx_destroy", "gpmi_last_error", "gpmi_version",
     "gpmi_gp_create", "gpmi_gp_destroy", "gpmi_fit", "gpmi_predict", "gpmi_grad", "gpmi_cov",
     "gpmi_inv_diag", "gpmi_fitc_create", "gpmi_fitc_destroy", "gpmi_fitc_fit", "gpmi_fitc_predict", "gpmi_fitc_alpha_u",
-    "gpmi_solve", "gpmi_whiten", "gpmi_logdet", "gpmi_factor_to_host",
+    "gpmi_solve", "gpmi_whiten", "gpmi_logdet", "gpmi_factor_to_host", "gpmi_factor_diag",
     "gpmi_profile_enable", "gpmi_profile_get", "gpmi_mfma_peak", "gpmi_bench_gemm",
     "gpmi_dev_set_kernel", "gpmi_dev_assemble", "gpmi_dev_cov_rows", "gpmi_dev_potrf_block", "gpmi_dev_rows_solve",
     "gpmi_dev_update", "gpmi_dev_bsolve_block", "gpmi_dev_row_gemv", "gpmi_dev_row_var", "gpmi_dev_logdiag_sum",
@@ -95,6 +95,7 @@ def load():
     lib.gpmi_logdet.argtypes = [vp, C.POINTER(dbl)]
     lib.gpmi_inv_diag.argtypes = [vp, vp]
     lib.gpmi_factor_to_host.argtypes = [vp, vp]
+    lib.gpmi_factor_diag.argtypes = [vp, vp]
     lib.gpmi_profile_enable.argtypes = [vp, C.c_int]
     lib.gpmi_profile_get.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(dbl), C.POINTER(dbl)]
     lib.gpmi_mfma_peak.argtypes = [vp, C.c_int, C.POINTER(dbl)]

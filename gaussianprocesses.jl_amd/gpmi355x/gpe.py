@@ -79,6 +79,12 @@ class HIPPDMat:
         self.ctx.check(_lib.load().gpmi_inv_diag(self.h, out.ctypes.data))
         return out
 
+    def factor_diag(self):
+        """diag(cholfactors(cK)) without moving the n × n factor."""
+        out = np.empty(self.n, dtype=_lib.np_dtype(self.bits))
+        self.ctx.check(_lib.load().gpmi_factor_diag(self.h, out.ctypes.data))
+        return out
+
     def cholfactors(self):
         """Upper factor U (n × n), as Cholesky(factors, 'U', 0) holds it (GPE.jl:60)."""
         U = np.empty((self.n, self.n), dtype=_lib.np_dtype(self.bits), order="F")

@@ -170,6 +170,9 @@ int gpmi_logdet(gpmi_gp*, double* out);                 /* 2 sum log U_ii       
 /* U_out: n x n col-major with the upper factor in its upper triangle and zeros
  * below (== Cholesky(factors,'U',0), src/GPE.jl:60).                        */
 int gpmi_factor_to_host(gpmi_gp*, void* U_out);
+/* diag_out[i] = U_ii, n elements of the model's dtype: `diag(cholfactors(cK))` without moving the n x n factor
+ * (what PDMats.logdet sums, GPE.jl:210; lets a caller re-derive logdet on the host). */
+int gpmi_factor_diag(gpmi_gp*, void* diag_out);
 
 /* ---- measurement hooks (bench.py; no reference counterpart) --------------
  * When enabled, every launch of a profiled kernel class is bracketed by HIP

@@ -139,3 +139,32 @@ def test_fitc_large_n_woodbury_residual():
     logdet = 2 * np.log(np.diag(sla.cholesky(B))).sum() + np.log(lam).sum()
     mll = -(y @ a + logdet + n * math.log(2 * math.pi)) / 2
     assert abs(gp.mll - mll) <= 1e-6 * abs(mll)
+
+
+def test_fitc_c5_width_m4096_n262144_woodbury_residual():
+    """BASELINE config 5's inducing width (M = 4096) at N = 262 144, d = 8, SEArd: the same matrix-free host checks as above
+    (Woodbury residual of alpha, determinant lemma for the mll) with Kuf (8.6 GB) fetched from the device."""
+    import scipy.linalg as sla
+    n, m, d = 262144, 4096, 8
+    rng = np.random.default_rng(20240502)
+    x = rng.uniform(size=(d, n))
+    xu = rng.uniform(size=(d, m))
+    y = np.sin(2.0 * x.sum(axis=0)) + 0.1 * rng.standard_normal(n)
+    k = g.SEArd([math.log(0.5) + 0.05 * j for j in range(d)], 0.0)
+    gp = g.FITC(x, xu, y, g.MeanZero(), k, math.log(0.1))
+    a = np.asarray(gp.alpha, dtype=np.float64)
+    Kuu = np.asarray(g.cov(k, xu)) + 1e-10 * np.eye(m)
+    c = sla.cholesky(Kuu, lower=False)
+    W = np.asarray(g.cov(k, xu, x))                                  # Kuf, m x n
+    W = sla.solve_triangular(c, W, trans="T", lower=False, overwrite_b=True)
+    lam = math.exp(2 * math.log(0.1)) + 1.0 - np.einsum("ij,ij->j", W, W)
+    assert np.all(lam > 0)
+    res = W.T @ (W @ a) + lam * a - y
+    assert np.abs(res).max() <= 1e-6 * np.abs(y).max()
+    B = np.eye(m) + (W / lam) @ W.T
+    logdet = 2 * np.log(np.diag(sla.cholesky(B))).sum() + np.log(lam).sum()
+    mll = -(y @ a + logdet + n * math.log(2 * math.pi)) / 2
+    assert abs(gp.mll - mll) <= 1e-6 * abs(mll)
+    xs = rng.uniform(size=(d, 64))
+    mu, var = gp.predict_f(xs)
+    assert np.all(np.isfinite(mu)) and np.all(var >= 0) and np.all(var <= 1.0 + 1e-9)

@@ -59,8 +59,20 @@ def test_c3_n50000_composite_properties():
     # the factor: |L^-1 K v|^2 == v'Kv
     w = gp.cK.whiten(KV[:, 1])
     assert float(w @ w) == pytest.approx(float(v @ KV[:, 1]), rel=1e-10)
-    # mll assembled from its parts
-    assert gp.mll == pytest.approx(-(float(y @ gp.alpha) + gp.cK.logdet() + G.LOG2PI * n) / 2, rel=1e-12)
+    # logdet, independently of the device's reduction: 2 Σ log U_ii summed on the host from the factor's diagonal ...
+    dg = np.asarray(gp.cK.factor_diag(), dtype=np.float64)
+    assert np.all(dg > 0)
+    logdet_host = 2.0 * float(np.sum(np.log(dg)))
+    assert gp.cK.logdet() == pytest.approx(logdet_host, rel=1e-12)
+    # ... and the diagonal itself against LAPACK on a leading block: the first m pivots of the factor are the Cholesky of
+    # the leading m x m block of K + s2 I, so their partial log-determinant must be LAPACK's
+    m = 4096
+    Kb = G.cov(spec, x[:, :m]) + nv * np.eye(m)
+    Ub = np.linalg.cholesky(Kb)
+    np.testing.assert_allclose(dg[:m], np.diag(Ub), rtol=1e-9)
+    assert 2.0 * float(np.sum(np.log(dg[:m]))) == pytest.approx(2.0 * float(np.sum(np.log(np.diag(Ub)))), rel=1e-11)
+    # mll assembled from its parts, with the host-side logdet
+    assert gp.mll == pytest.approx(-(float(y @ gp.alpha) + logdet_host + G.LOG2PI * n) / 2, rel=1e-12)
     # predict
     mu, s2 = gp.predict_f(xs)
     kdiag = 1.0 + 0.25 + 0.05 ** 2
@@ -69,3 +81,73 @@ def test_c3_n50000_composite_properties():
     np.testing.assert_allclose(mu_t, y[:256], atol=0.5)
     # a second, independent route to mu: K*' alpha with K* from the oracle
     np.testing.assert_allclose(mu, G.cov(spec, xs, x) @ gp.alpha, rtol=1e-7, atol=1e-9)
+
+
+# --------------------------------------------------------------------------------------------
+# C4's precision and dimension (fp32, d = 16, SEArd) where it matters: at sizes where fp32 round-off has accumulated.
+# The reference has no fp32 path; north_star's bar is rtol 1e-2 against the fp64 result.
+# --------------------------------------------------------------------------------------------
+LL16 = [math.log(0.5) + 0.05 * k for k in range(16)]
+
+
+def test_c4_fp32_n20000_d16_vs_fp64_oracle():
+    x, y, xs = G.synthetic_inputs(20000, 16, p=256)
+    spec = ("se_ard", LL16, 0.0)
+    gp = g.GP(x, y, g.MeanZero(), g.from_spec(spec), math.log(0.1), dtype=np.float32)
+    mu, s2 = gp.predict_f(xs)
+    ref = G.update_mll(spec, x, y, math.log(0.1))
+    mu_o, s2_o = G.predict_f(spec, x, ref, xs)
+    print(f"[fp32 N=20000 d=16] mll {gp.mll:.4f} vs fp64 oracle {ref['mll']:.4f} (rel {abs(gp.mll / ref['mll'] - 1):.2e}); "
+          f"max|dmu| {np.abs(mu - mu_o).max():.2e}, max|ds2| {np.abs(s2 - s2_o).max():.2e}")
+    assert gp.mll == pytest.approx(ref["mll"], rel=1e-2)
+    np.testing.assert_allclose(mu, mu_o, rtol=1e-2, atol=1e-2 * np.abs(mu_o).max())
+    np.testing.assert_allclose(s2, s2_o, rtol=1e-2, atol=1e-2 * np.abs(s2_o).max())
+    np.testing.assert_allclose(gp.alpha, ref["alpha"], rtol=0, atol=1e-2 * np.abs(ref["alpha"]).max())
+
+
+def test_c4_fp32_n100000_d16_properties_and_fp64_device():
+    """N = 100 000, d = 16, fp32 (40 GB factor): positive definite, solve residual, factor identity and mll-from-parts on
+    sparse probes the oracle can rebuild, and agreement with the fp64 device path (80 GB) at rtol 1e-2."""
+    n, d = 100000, 16
+    x, y, xs = G.synthetic_inputs(n, d, p=256)
+    spec = ("se_ard", LL16, 0.0)
+    log_noise = math.log(0.1)
+    nv = math.exp(2 * log_noise)
+    gp = g.GP(x, y, g.MeanZero(), g.from_spec(spec), log_noise, dtype=np.float32)   # raises PosDefException if not PD
+    a = np.asarray(gp.alpha, dtype=np.float64)
+    rng = np.random.default_rng(5)
+    # residual of (K + s2 I) alpha = y on 512 random rows (K rows rebuilt by the oracle in fp64)
+    rows = np.sort(rng.choice(n, 512, replace=False))
+    r = G.cov(spec, x[:, rows], x) @ a + nv * a[rows] - y[rows]
+    print(f"[fp32 N=100000] residual max {np.abs(r).max():.3e} (|y| max {np.abs(y).max():.2f})")
+    assert np.abs(r).max() <= 1e-2 * np.abs(y).max()
+    # the factor: |L^-1 (K v)|^2 == v' K v for a v supported on 64 points (K v needs 64 columns of K only)
+    S = np.sort(rng.choice(n, 64, replace=False))
+    vS = rng.standard_normal(64)
+    KS = G.cov(spec, x, x[:, S])                       # n x 64
+    Kv = KS @ vS
+    Kv[S] += nv * vS
+    w = np.asarray(gp.cK.whiten(Kv.astype(np.float32)), dtype=np.float64)
+    assert float(w @ w) == pytest.approx(float(vS @ Kv[S]), rel=1e-2)
+    # logdet from the fetched diagonal, mll from its parts
+    dg = np.asarray(gp.cK.factor_diag(), dtype=np.float64)
+    assert np.all(dg > 0)
+    logdet_host = 2.0 * float(np.sum(np.log(dg)))
+    assert gp.cK.logdet() == pytest.approx(logdet_host, rel=1e-6)
+    assert gp.mll == pytest.approx(-(float(y @ a) + logdet_host + G.LOG2PI * n) / 2, rel=1e-5)
+    mu, s2 = gp.predict_f(xs)
+    assert np.all(np.isfinite(mu)) and np.all(s2 >= 0) and np.all(s2 <= 1.0 + 1e-5)
+    np.testing.assert_allclose(mu, G.cov(spec, xs, x) @ a, rtol=1e-2, atol=1e-3)
+    mll32, alpha32 = gp.mll, a
+    del gp
+    # the same model in fp64 on the device (itself checked against the oracle at N = 20 000 and by properties at 50 000)
+    gp64 = g.GP(x, y, g.MeanZero(), g.from_spec(spec), log_noise)
+    mu64, s264 = gp64.predict_f(xs)
+    print(f"[N=100000 d=16] mll fp32 {mll32:.3f} fp64 {gp64.mll:.3f} (rel {abs(mll32 / gp64.mll - 1):.2e}); "
+          f"max|dmu| {np.abs(mu - mu64).max():.2e}, max|ds2| {np.abs(s2 - s264).max():.2e}")
+    r64 = G.cov(spec, x[:, rows], x) @ gp64.alpha + nv * gp64.alpha[rows] - y[rows]
+    assert np.abs(r64).max() <= 1e-8 * np.abs(y).max()
+    assert mll32 == pytest.approx(gp64.mll, rel=1e-2)
+    np.testing.assert_allclose(mu, mu64, rtol=1e-2, atol=1e-2 * np.abs(mu64).max())
+    np.testing.assert_allclose(s2, s264, rtol=1e-2, atol=1e-2 * np.abs(s264).max())
+    np.testing.assert_allclose(alpha32, gp64.alpha, rtol=0, atol=1e-2 * np.abs(gp64.alpha).max())

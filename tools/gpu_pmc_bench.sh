@@ -6,7 +6,7 @@ set -u
 R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/pmc_bench"; mkdir -p "$O"
 cd /tmp; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/$c" -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$O/$c.log" 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/$c" -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > "$O/$c.log" 2>&1
   echo "pmc $c exit $?"
 done
 cd "$R"

@@ -9,7 +9,7 @@ import sys
 
 root = sys.argv[1]
 KERNEL = "gemm_nt_kernel<double, 0, 4>"
-out = {"kernel": KERNEL, "command": "python bench.py --steps 2 --warmup 1 --no-cpu-baseline", "units": "bytes per launch"}
+out = {"kernel": KERNEL, "command": "python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary", "units": "bytes per launch"}
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     vals = {}
     for f in glob.glob(os.path.join(root, counter, "**", "*counter_collection.csv"), recursive=True):
