@@ -417,6 +417,11 @@ def optimize(gp, noise=True, domean=True, kern=True, method="L-BFGS-B", options=
             return math.inf, np.zeros(len(hyp))
 
     x0 = np.asarray(gp.get_params(**kw), dtype=float)
+    # The starting point is evaluated OUTSIDE the error contract: an ArgumentError that does not depend on the parameter
+    # values (a model / size the device gradient does not cover, vector logNoise with noise=True — an @assert in the
+    # reference, GPE.jl:304) or a start that is not positive definite must surface, not come back as a "converged"
+    # result at x0 with fun = inf.
+    gp.update_target_and_dtarget(**kw)
     box = optimize_bounds(gp, noisebounds, meanbounds, kernbounds, **kw)
     res = minimize(fg, x0, jac=True, method=method, bounds=box, options=options or {"maxiter": 20})
     gp.set_params(res.x, **kw)

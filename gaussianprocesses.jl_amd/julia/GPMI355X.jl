@@ -19,7 +19,7 @@ import GaussianProcesses: alloc_cK, update_cK!, update_mll!, update_dmll!, grad_
 using PDMats
 import PDMats: dim, whiten!, whiten, unwhiten!
 using LinearAlgebra
-import LinearAlgebra: logdet, \, ldiv!
+import LinearAlgebra: logdet, \, ldiv!, tr
 
 const libgpmi = get(ENV, "LIBGPMI", "libgpmi.so")
 
@@ -103,13 +103,18 @@ end
 alloc_cK(::HIPCovariance, nobs) = HIPPDMat(nobs)                      # replaces src/GP.jl:14-20
 Base.size(a::HIPPDMat) = (a.n, a.n); Base.size(a::HIPPDMat, i::Int) = a.n; dim(a::HIPPDMat) = a.n
 
-function ensure_handle!(a::HIPPDMat, x::Matrix{Float64})
+# The handle is keyed on the IDENTITY of the caller's x (gp.x, whatever its array type): the dense Float64 copy the C ABI
+# needs is made only when x actually has to be uploaded, so repeated update_cK! / update_mll! calls with the same gp.x
+# (every optimiser / MCMC step) reuse the resident x and buffers.
+function ensure_handle!(a::HIPPDMat, x::AbstractMatrix)
     if a.handle == C_NULL || a.xref !== x
         a.handle == C_NULL || ccall((:gpmi_gp_destroy, libgpmi), Cvoid, (Ptr{Cvoid},), a.handle)
+        a.handle = C_NULL
+        xd = x isa Matrix{Float64} ? x : Matrix{Float64}(x)
         h = Ref{Ptr{Cvoid}}(C_NULL)
         rc = ccall((:gpmi_gp_create, libgpmi), Cint, (Ptr{Cvoid}, Cint, Cint, Int64, Ptr{Float64}, Ptr{Ptr{Cvoid}}),
-                   context(), 64, size(x, 1), size(x, 2), x, h)
-        check(context(), rc); a.handle = h[]; a.xref = x; a.n = size(x, 2)
+                   context(), 64, size(xd, 1), size(xd, 2), xd, h)
+        check(context(), rc); a.handle = h[]; a.xref = x; a.n = size(xd, 2)
     end
     a
 end
@@ -129,7 +134,7 @@ end
 
 # update_cK! alone (src/GPE.jl:169-195; callers: GPA with logNoise = -20, ElasticGPE): factor only
 function update_cK!(cK::HIPPDMat, x::AbstractMatrix, kernel::Kernel, logNoise, data::KernelData, ::HIPCovariance)
-    fit!(cK, Matrix{Float64}(x), kernel, logNoise, zeros(size(x, 2)), nothing)
+    fit!(cK, x, kernel, logNoise, zeros(size(x, 2)), nothing)
     cK
 end
 
@@ -201,25 +206,34 @@ function GaussianProcesses.predict_LOO(a::HIPPDMat, alpha::AbstractVector{<:Real
     return -alpha .* σi2 .+ y, σi2
 end
 Base.Matrix(a::HIPPDMat) = (U = UpperTriangular(cholfactors(a)); Matrix(U' * U))
+# unwhiten!(a, x) = L x with a = L Lᵀ (PDMats; the reference's only call is rand!, src/GP.jl:136, on the P x P predictive
+# covariance — a plain PDMat — so this method is for completeness of the AbstractPDMat surface: host product with the
+# fetched factor).  tr(a) as SubsetOfRegsPDMat defines it (subsetofregressors.jl:61-72): trace of the covariance itself,
+# = ‖U‖²_F.
+unwhiten!(a::HIPPDMat, b::DenseVecOrMat{Float64}) = lmul!(UpperTriangular(cholfactors(a))', b)
+tr(a::HIPPDMat) = sum(abs2, UpperTriangular(cholfactors(a)))
 mat(a::HIPPDMat) = Matrix(a)                                            # K is regenerated on demand, never resident
 
 # ---- predict: batches the full_cov=false branch (src/GP.jl:69-77 is P separate trsv) -----------
-function hip_predict(gp::GPE, x::AbstractMatrix, full_cov::Bool)
-    size(x, 1) == gp.dim || throw(ArgumentError("Gaussian Process object and input observations do not have consistent dimensions"))
+function hip_predict(cK::HIPPDMat, kernel::Kernel, meanf::Mean, x::AbstractMatrix, full_cov::Bool)
     xp = Matrix{Float64}(x); P = size(xp, 2)
-    mx = Vector{Float64}(mean(gp.mean, xp)); μ = Vector{Float64}(undef, P)
+    mx = Vector{Float64}(mean(meanf, xp)); μ = Vector{Float64}(undef, P)
     Σ = full_cov ? Matrix{Float64}(undef, P, P) : Vector{Float64}(undef, P)
-    rc = withkernel(descriptor(gp.kernel)) do ck
+    rc = withkernel(descriptor(kernel)) do ck
         ccall((:gpmi_predict, libgpmi), Cint,
               (Ptr{Cvoid}, Ref{CKernel}, Int64, Ptr{Float64}, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Float64}),
-              gp.cK.handle, ck, P, xp, mx, full_cov ? 1 : 0, μ, Σ)
+              cK.handle, ck, P, xp, mx, full_cov ? 1 : 0, μ, Σ)
     end
     check(context(), rc); μ, Σ
 end
-predict_f(gp::GPE{X,Y,M,K,HIPCovariance}, x::AbstractMatrix; full_cov::Bool=false) where {X,Y,M,K} = hip_predict(gp, x, full_cov)
+function predict_f(gp::GPE{X,Y,M,K,HIPCovariance}, x::AbstractMatrix; full_cov::Bool=false) where {X,Y,M,K}
+    size(x, 1) == gp.dim || throw(ArgumentError("Gaussian Process object and input observations do not have consistent dimensions"))
+    hip_predict(gp.cK, gp.kernel, gp.mean, x, full_cov)
+end
+# predictMVN (src/GP.jl:39-49; reached by predict_full, src/GPE.jl:399, for callers that bypass predict_f): the full
+# predictive covariance from the device.  `alpha` is the one the last gpmi_fit left in the handle (= gp.alpha).
 predictMVN(xpred::AbstractMatrix, xtrain::AbstractMatrix, ytrain::AbstractVector, kernel::Kernel, meanf::Mean,
-           alpha::AbstractVector, ::HIPCovariance, Ktrain::HIPPDMat) =
-    error("predictMVN(::HIPCovariance) is reached through predict_f, which this module overrides")
+           alpha::AbstractVector, ::HIPCovariance, Ktrain::HIPPDMat) = hip_predict(Ktrain, kernel, meanf, xpred, true)
 
 # convenience constructor, as SoR(...)/FITC(...) are (src/sparse/subsetofregressors.jl:324-327)
 GP_hip(x::AbstractMatrix, y::AbstractVector, m::Mean, k::Kernel, logNoise=-2.0) = GPE(x, y, m, k, logNoise, HIPCovariance())
@@ -245,14 +259,16 @@ end
 alloc_cK(s::HIPFITC, nobs) = HIPFITCPDMat(nobs, s.inducing)             # replaces fully_indep…:118-132
 GaussianProcesses.KernelData(k::Kernel, X1::AbstractMatrix, X2::AbstractMatrix, ::HIPFITC) = EmptyData()
 Base.size(a::HIPFITCPDMat) = (a.n, a.n); Base.size(a::HIPFITCPDMat, i::Int) = a.n; dim(a::HIPFITCPDMat) = a.n
-function ensure_handle!(a::HIPFITCPDMat, x::Matrix{Float64})
+function ensure_handle!(a::HIPFITCPDMat, x::AbstractMatrix)
     if a.handle == C_NULL || a.xref !== x
         a.handle == C_NULL || ccall((:gpmi_fitc_destroy, libgpmi), Cvoid, (Ptr{Cvoid},), a.handle)
+        a.handle = C_NULL
+        xd = x isa Matrix{Float64} ? x : Matrix{Float64}(x)
         h = Ref{Ptr{Cvoid}}(C_NULL)
         rc = ccall((:gpmi_fitc_create, libgpmi), Cint,
                    (Ptr{Cvoid}, Cint, Cint, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Ptr{Cvoid}}),
-                   context(), 64, size(x, 1), size(x, 2), x, size(a.inducing, 2), a.inducing, h)
-        check(context(), rc); a.handle = h[]; a.xref = x; a.n = size(x, 2)
+                   context(), 64, size(xd, 1), size(xd, 2), xd, size(a.inducing, 2), a.inducing, h)
+        check(context(), rc); a.handle = h[]; a.xref = x; a.n = size(xd, 2)
     end
     a
 end

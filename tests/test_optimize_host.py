@@ -108,3 +108,24 @@ def test_posdef_failure_is_an_infeasible_point_and_parameters_are_restored():
     res = g.optimize(gp, options={"maxiter": 50})
     assert math.isfinite(gp.target) and gp.get_params()[0] >= -1.0  # never left in the infeasible region
     assert res.x[0] >= -1.0 and res.x[0] < 0.0  # moved towards the optimum, stopped in front of the wall
+
+
+class _Unsupported(StandInGP):
+    """a model whose gradient the device does not cover: every evaluation raises ArgumentError, whatever the parameters"""
+
+    def update_target_and_dtarget(self, **kw):
+        self.evals += 1
+        raise g.ArgumentError("update_dmll: not supported for this model")
+
+
+def test_capability_errors_surface_instead_of_a_converged_result():
+    gp = _Unsupported(np.zeros(6))
+    with pytest.raises(g.ArgumentError, match="not supported"):
+        g.optimize(gp)
+    assert gp.evals == 1  # raised on the starting point, before the optimiser ran
+
+
+def test_start_that_is_not_positive_definite_raises():
+    gp = StandInGP(np.zeros(6), wall=1.0)  # logNoise = 0 lies left of the wall
+    with pytest.raises(g.PosDefException):
+        g.optimize(gp)
