@@ -513,8 +513,17 @@ int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
         }
         c->lookahead_slots = 8;
         if (const char* e = getenv("GPMI_LOOKAHEAD")) c->lookahead_slots = atoi(e) / 8 * 8;
-        if (const char* e = getenv("GPMI_LOOKAHEAD_MIN")) c->lookahead_min_trailing = atoll(e);
+        if (const char* e = getenv("GPMI_LOOKAHEAD_MIN")) {  // given as a trailing size, as in round 1
+            const double t = atof(e);
+            c->lookahead_min_tiles = (int64_t)(0.5 * t * t / (GEMM_BM * GEMM_BN));
+        }
     }
+    if (const char* e = getenv("GPMI_SUPER")) {  // "min512,min1024,min2048" (remaining rows from which each width is used)
+        long long a = 0, b = 0, d = 0;
+        sscanf(e, "%lld,%lld,%lld", &a, &b, &d);
+        c->super_min[0] = a; c->super_min[1] = b; c->super_min[2] = d;
+    }
+    if (const char* e = getenv("GPMI_WHITEN_SUPER")) c->whiten_super = std::max<long long>(NB, atoll(e) / NB * NB);
     if (const char* e = getenv("GPMI_REFINE")) c->refine_default = atoi(e) != 0;
     c->refine_solves = c->refine_default;
     if (const char* e = getenv("GPMI_GEMM_NI")) c->gemm_ni = atoi(e) == 2 ? 2 : atoi(e) == 4 ? 4 : 0;

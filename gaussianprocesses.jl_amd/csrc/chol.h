@@ -49,22 +49,35 @@ inline hipEvent_t la_event(gpmi_ctx* c) {
     return c->la_events[i];
 }
 
-// The same whitening through the explicit NB x NB inverses, out of place: V <- R L^-T with one product per NB columns
-//   V[:, k0:kend] = R[:, k0:kend] * Linv_k' ;  R[:, kend:npad] -= V[:, k0:kend] * A[kend:npad, k0:kend]'
+// The same whitening through the explicit NB x NB inverses, out of place: V <- R L^-T with one product per NB columns,
+// in two levels like cholesky_lower: blocks are grouped into super-blocks of WS = 1024 columns; inside a super-block
+// the solve is left-looking (block b first receives the products of the super-block's earlier blocks, K = 256 b), and the
+// columns beyond it get ONE update with K = WS when it is complete — the same number of launches as the one-level form, with
+// the bulk of the flops at the K = 1024 rate of gemm_nt_kernel:
+//   R[:, k0:k1] -= V[:, ks:k0] * A[k0:k1, ks:k0]' ;  V[:, k0:k1] = R[:, k0:k1] * Linv_k'        (k0 in the super-block [ks, ke))
+//   R[:, ke:npad] -= V[:, ks:ke] * A[ke:npad, ks:ke]'
 // (R is consumed).  Out of place because the two 128-column tiles of a block read each other's input columns.
-// rows_upto(kend) gives the number of leading rows that can be non-zero up to column kend (identity right-hand sides).
+// rows_upto(kend) gives the number of leading rows that can be non-zero up to column kend (identity right-hand sides);
+// a super-block works on rows_upto(its last column) rows throughout, so that V holds zeros — not stale data — wherever
+// the K = WS product reads it.
 // (A look-ahead of the next block's solve on the side stream, as in cholesky_lower, bought 1.6 ms per predict while the
 //  solve was a 49 us launch of 128 x 128 tiles; with 128 x 64 tiles it is 28 us and the look-ahead measured neutral: removed.)
 template <typename T, typename F>
 inline void whiten_rows_inv(gpmi_ctx* c, const T* A, int64_t ld, const T* linv256, int64_t npad, T* R, int64_t ldr, T* V,
                             int64_t ldv, F rows_upto) {
     const TileShape rect{0, 0, 0, 0, 1, 0};
-    for (int64_t k0 = 0; k0 < npad; k0 += NB) {
-        const int64_t nbk = std::min<int64_t>(NB, npad - k0), k1 = k0 + nbk;
-        const int64_t Mr = rows_upto(k1);
-        launch_gemm_shape<T>(c, V + k0, ldv, R + k0, ldr, linv256 + (k0 / NB) * NB * NB, NB, Mr, nbk, nbk, rect, nullptr,
-                             GEMM_OVERWRITE);
-        if (k1 < npad) launch_gemm_nt<T>(c, R + k1, ldr, V + k0, ldv, A + k1 * ld + k0, ld, Mr, npad - k1, nbk, 0, nullptr);
+    const int64_t WS = std::max<int64_t>(NB, c->whiten_super);
+    for (int64_t ks = 0; ks < npad; ks += WS) {
+        const int64_t ke = std::min<int64_t>(ks + WS, npad);
+        const int64_t Mr = rows_upto(ke);
+        for (int64_t k0 = ks; k0 < ke; k0 += NB) {
+            const int64_t nbk = std::min<int64_t>(NB, ke - k0);
+            if (k0 > ks)
+                launch_gemm_nt<T>(c, R + k0, ldr, V + ks, ldv, A + k0 * ld + ks, ld, Mr, nbk, k0 - ks, 0, nullptr);
+            launch_gemm_shape<T>(c, V + k0, ldv, R + k0, ldr, linv256 + (k0 / NB) * NB * NB, NB, Mr, nbk, nbk, rect, nullptr,
+                                 GEMM_OVERWRITE);
+        }
+        if (ke < npad) launch_gemm_nt<T>(c, R + ke, ldr, V + ks, ldv, A + ke * ld + ks, ld, Mr, npad - ke, ke - ks, 0, nullptr);
     }
 }
 
@@ -101,85 +114,124 @@ inline void factor_panel_diag(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag
             launch_rows64<T>(c, A + r0 * ld + k0, ld, kend - r0, (int)(j0 - k0), A + j0 * ld + k0, ld, linv_j, kend - r0, d_info);
     }
 }
-// ... and the rows below it (chip-wide), which only need the finished diagonal block and its inverses
+// ... and rows [r0, r1) below it (chip-wide), which only need the finished diagonal block and its inverses
 template <typename T>
-inline void factor_panel_below(gpmi_ctx* c, T* A, int64_t ld, const T* linv, int64_t k0, int64_t nbk, int64_t Mtot,
-                               const int* d_info) {
-    const int64_t kend = k0 + nbk;
+inline void factor_panel_rows(gpmi_ctx* c, T* A, int64_t ld, const T* linv, int64_t k0, int64_t nbk, int64_t r0, int64_t r1,
+                              const int* d_info) {
+    const int64_t kend = k0 + nbk, M = r1 - r0;
+    if (M <= 0) return;
     // one fused launch when every workgroup gets a CU to itself (rows256 keeps 64 x 256 of X in registers: one workgroup
     // per CU; with more row blocks than CUs it would run in two rounds and lose to the four rows64 launches);
     // the refinement step lives in rows64 only
-    if (!c->refine_solves && (Mtot - kend + IB - 1) / IB <= c->num_cus) {
-        launch_rows256<T>(c, A + kend * ld + k0, ld, Mtot - kend, (int)(nbk / IB), A + k0 * ld + k0, ld, linv + (k0 / IB) * IB * IB,
-                          d_info);
+    if (!c->refine_solves && (M + IB - 1) / IB <= c->num_cus) {
+        launch_rows256<T>(c, A + r0 * ld + k0, ld, M, (int)(nbk / IB), A + k0 * ld + k0, ld, linv + (k0 / IB) * IB * IB, d_info);
         return;
     }
     for (int64_t j0 = k0; j0 < kend; j0 += IB)
-        launch_rows64<T>(c, A + kend * ld + k0, ld, Mtot - kend, (int)(j0 - k0), A + j0 * ld + k0, ld,
-                         linv + (j0 / IB) * IB * IB, 0, d_info);
+        launch_rows64<T>(c, A + r0 * ld + k0, ld, M, (int)(j0 - k0), A + j0 * ld + k0, ld, linv + (j0 / IB) * IB * IB, 0, d_info);
+}
+template <typename T>
+inline void factor_panel_below(gpmi_ctx* c, T* A, int64_t ld, const T* linv, int64_t k0, int64_t nbk, int64_t Mtot,
+                               const int* d_info) {
+    factor_panel_rows<T>(c, A, ld, linv, k0, nbk, k0 + nbk, Mtot, d_info);
 }
 
-// blocked right-looking Cholesky, lower, in place; rows npad .. npad+extra-1 are carried along (forward solve for free).
+// Blocked Cholesky, lower, in place; rows npad .. npad+extra-1 are carried along (forward solve for free).
 //
-// Look-ahead: the serial part of panel k+1 — the diag64 / rows64 chain on its 256 x 256 diagonal block, one to three
-// workgroups per launch, ~150 us — runs on a second (high-priority) stream UNDER the trailing update by panel k.
-// For that the update is split by tiles, not by columns: the three 128 x 128 tiles of the next diagonal block go first
-// on the side stream (a 3-workgroup launch), everything else is one persistent launch on the main stream whose grid
-// leaves `lookahead_slots` workgroup slots of the chip free, which is where the side stream's small kernels land.
-// (Two measured dead ends, tools/cumask_probe.hip + profiles/: splitting off the next panel's 256 COLUMNS costs a
+// TWO LEVELS (round 2).  Right-looking over SUPER-PANELS of W = 256 * 2^s columns (W from the remaining size, super_width()):
+//   1. the W x W diagonal block is factored by the NB = 256 machinery (factor_diag_block: diag64 / rows64 chains and small
+//      updates, all latency-bound, a few workgroups per launch);
+//   2. the rows below it are solved against that block 256 columns at a time, left-looking (rows_below_super: block b first
+//      receives the products of the super-panel's earlier blocks in ONE update with K = 256 b, then the product with the
+//      stored inverses) — chip-wide launches;
+//   3. the trailing matrix gets ONE update with K = W.
+// Every trailing element is read and written once per W columns instead of once per 256: the update kernel's C traffic per
+// flop (25 % of its time at K = 256) drops by W / 256, and the bulk of the n^3 / 3 flops runs at the K = 1024
+// rate of gemm_nt_kernel (63 instead of 47 TFLOP/s isolated).  The skinny products of step 2 are (W / M) of the flops.
+//
+// LOOK-AHEAD at the super-panel level: step 1 of the NEXT super-panel — every latency-bound launch of the factorisation —
+// runs on a second, high-priority stream UNDER step 3 of the current one.  For that the update is split by tiles: the lower
+// tiles of the next W' x W' diagonal block go first on the side stream, everything else is one persistent launch on the
+// main stream (tile_order.h lower mode with a row offset) whose grid leaves `lookahead_slots` workgroup slots free, which
+// is where the side stream's small kernels land.  With W = 256 this is round 1's scheme.
+// (Two measured dead ends, tools/cumask_probe.hip + profiles/: splitting off the next panel's COLUMNS costs a
 // single-round GEMM launch as long as the chain it hides; CU-masked streams work but cost the GEMM 4 % for 8 CUs.)
+inline int64_t super_width(const gpmi_ctx* c, int64_t trailing) {
+    // widest first; widths are multiples of NB.  Below super_min[0] the factorisation is the plain NB = 256 one.
+    for (int i = 2; i >= 0; --i)
+        if (c->super_min[i] > 0 && trailing >= c->super_min[i]) return (int64_t)NB << (i + 1);
+    return NB;
+}
+
+// step 1: Cholesky of the w x w block at (k, k), in place, right-looking in NB panels (no rows below, nothing carried)
+template <typename T>
+inline void factor_diag_block(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, int64_t k, int64_t w, int* d_info) {
+    const int64_t kend = k + w;
+    for (int64_t k0 = k; k0 < kend; k0 += NB) {
+        const int64_t nbk = std::min<int64_t>(NB, kend - k0), k1 = k0 + nbk;
+        factor_panel_diag<T>(c, A, ld, linv, invdiag, k0, nbk, d_info);
+        if (k1 >= kend) break;
+        factor_panel_rows<T>(c, A, ld, linv, k0, nbk, k1, kend, d_info);
+        launch_gemm_shape<T>(c, A + k1 * ld + k1, ld, A + k1 * ld + k0, ld, A + k1 * ld + k0, ld, kend - k1, kend - k1, nbk,
+                             TileShape{0, 0, 1, 0, 1, 0}, d_info, GEMM_AUX);
+    }
+}
+
+// step 2: rows [ke, Mtot) of the super-panel's columns [ks, ke):  X <- X L^-T, left-looking by NB columns
+template <typename T>
+inline void rows_below_super(gpmi_ctx* c, T* A, int64_t ld, const T* linv, int64_t ks, int64_t ke, int64_t Mtot, const int* d_info) {
+    if (Mtot <= ke) return;
+    for (int64_t k0 = ks; k0 < ke; k0 += NB) {
+        const int64_t nbk = std::min<int64_t>(NB, ke - k0);
+        if (k0 > ks)
+            launch_gemm_shape<T>(c, A + ke * ld + k0, ld, A + ke * ld + ks, ld, A + k0 * ld + ks, ld, Mtot - ke, nbk, k0 - ks,
+                                 TileShape{0, 0, 0, 0, 1, 0}, d_info, GEMM_AUX);
+        factor_panel_rows<T>(c, A, ld, linv, k0, nbk, ke, Mtot, d_info);
+    }
+}
+
 template <typename T>
 inline void cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, int64_t npad, int64_t extra, int* d_info) {
     const int64_t Mtot = npad + extra;
-    if (c->lookahead_slots <= 0 || !c->side_stream || npad <= 4 * NB) {
-        for (int64_t k0 = 0; k0 < npad; k0 += NB) {
-            const int64_t nbk = std::min<int64_t>(NB, npad - k0);
-            const int64_t kend = k0 + nbk;
-            factor_panel<T>(c, A, ld, linv, invdiag, k0, nbk, Mtot, d_info);
-            const int64_t M = Mtot - kend;
-            if (M > 0 && kend < npad)  // trailing update (SYRK shape, K = nbk): the MFMA-bound bulk
-                launch_gemm_nt<T>(c, A + kend * ld + kend, ld, A + kend * ld + k0, ld, A + kend * ld + k0, ld, M, npad - kend,
-                                  nbk, 1, d_info);
-        }
-        return;
-    }
+    const bool can_look = c->lookahead_slots > 0 && c->side_stream && npad > 4 * NB;
     hipStream_t main_s = c->stream, side = c->side_stream;
-    bool panel_done = false;  // is panel k0 already factored (by the look-ahead of the previous step)?
-    for (int64_t k0 = 0; k0 < npad; k0 += NB) {
-        const int64_t nbk = std::min<int64_t>(NB, npad - k0);
-        const int64_t k1 = k0 + nbk;
-        if (!panel_done) factor_panel<T>(c, A, ld, linv, invdiag, k0, nbk, Mtot, d_info);
-        panel_done = false;
-        if (k1 >= npad) break;
-        const int64_t nb1 = std::min<int64_t>(NB, npad - k1);
-        const int64_t k2 = k1 + nb1;
-        // the chain takes ~0.4 ms beside the update (contended CUs): look ahead only while the update is longer
-        if (npad - k2 < c->lookahead_min_trailing) {
-            launch_gemm_nt<T>(c, A + k1 * ld + k1, ld, A + k1 * ld + k0, ld, A + k1 * ld + k0, ld, Mtot - k1, npad - k1, nbk, 1,
-                              d_info);
-            continue;
+
+    int64_t ks = 0, ke = std::min<int64_t>(super_width(c, npad), npad);
+    factor_diag_block<T>(c, A, ld, linv, invdiag, 0, ke, d_info);
+    for (;;) {
+        rows_below_super<T>(c, A, ld, linv, ks, ke, Mtot, d_info);
+        if (ke >= npad) break;
+        const int64_t ke2 = std::min<int64_t>(ke + super_width(c, npad - ke), npad);
+        const int64_t K = ke - ks, w2 = ke2 - ke;
+        // The side stream's chain takes ~0.4 ms per 256 columns beside the update (contended CUs): look ahead only while
+        // the update is longer.  Update length in units of a 128 x 128 x 256 tile product:
+        const double ntile = 0.5 * (double)(npad - ke2) * (double)(npad - ke2) / (GEMM_BM * GEMM_BN) * (double)K / NB;
+        if (!can_look || ntile < (double)c->lookahead_min_tiles * (double)((w2 + NB - 1) / NB)) {
+            launch_gemm_nt<T>(c, A + ke * ld + ke, ld, A + ke * ld + ks, ld, A + ke * ld + ks, ld, Mtot - ke, npad - ke, K, 1, d_info);
+            factor_diag_block<T>(c, A, ld, linv, invdiag, ke, w2, d_info);
+        } else {
+            hipEvent_t eb = la_event(c);  // columns [ks, ke) complete
+            (void)hipEventRecord(eb, main_s);
+            (void)hipStreamWaitEvent(side, eb, 0);
+            {
+                StreamScope sc(c, side, c->num_cus);
+                // the next diagonal block's own tiles, then its factorisation
+                launch_gemm_shape<T>(c, A + ke * ld + ke, ld, A + ke * ld + ks, ld, A + ke * ld + ks, ld, w2, w2, K,
+                                     TileShape{0, 0, 1, 0, 1, 0}, d_info, GEMM_AUX);
+                factor_diag_block<T>(c, A, ld, linv, invdiag, ke, w2, d_info);
+            }
+            hipEvent_t ec = la_event(c);
+            (void)hipEventRecord(ec, side);
+            // everything below the next diagonal block: rows ke2.., columns ke.. up to each row tile's diagonal tile
+            // (lower mode with offset: row tile ti keeps column tiles <= ti + g0)
+            c->gemm_reserve = c->lookahead_slots;
+            launch_gemm_shape<T>(c, A + ke2 * ld + ke, ld, A + ke2 * ld + ks, ld, A + ke * ld + ks, ld, Mtot - ke2, npad - ke, K,
+                                 TileShape{0, 0, 1, (int)((w2 + GEMM_BM - 1) / GEMM_BM), 1, 0}, d_info, 0);
+            c->gemm_reserve = 0;
+            (void)hipStreamWaitEvent(main_s, ec, 0);
         }
-        hipEvent_t eb = la_event(c);  // panel k complete
-        (void)hipEventRecord(eb, main_s);
-        (void)hipStreamWaitEvent(side, eb, 0);
-        {
-            StreamScope sc(c, side, c->num_cus);
-            // the next diagonal block's own tiles, then its factorisation chain
-            launch_gemm_shape<T>(c, A + k1 * ld + k1, ld, A + k1 * ld + k0, ld, A + k1 * ld + k0, ld, nb1, nb1, nbk,
-                                 TileShape{0, 0, 1, 0, 1, 0}, d_info, GEMM_AUX);
-            factor_panel_diag<T>(c, A, ld, linv, invdiag, k1, nb1, d_info);
-        }
-        hipEvent_t ec = la_event(c);
-        (void)hipEventRecord(ec, side);
-        // everything below the next diagonal block: rows k2.., columns k1.. up to each row tile's diagonal tile
-        // (lower mode with offset: row tile ti keeps column tiles <= ti + 2)
-        c->gemm_reserve = c->lookahead_slots;
-        launch_gemm_shape<T>(c, A + k2 * ld + k1, ld, A + k2 * ld + k0, ld, A + k1 * ld + k0, ld, Mtot - k2, npad - k1, nbk,
-                             TileShape{0, 0, 1, 2, 1, 0}, d_info, 0);
-        c->gemm_reserve = 0;
-        (void)hipStreamWaitEvent(main_s, ec, 0);
-        factor_panel_below<T>(c, A, ld, linv, k1, nb1, Mtot, d_info);
-        panel_done = true;
+        ks = ke;
+        ke = ke2;
     }
 }
 

@@ -86,7 +86,12 @@ struct gpmi_ctx {
     // trailing update, which leaves lookahead_slots workgroup slots free (gemm_reserve is set around that launch)
     hipStream_t side_stream = nullptr;
     int lookahead_slots = 0;
-    int64_t lookahead_min_trailing = 4608;  // trailing size below which the serial order is faster (update < chain)
+    int64_t lookahead_min_tiles = 650;   // update length (in 128 x 128 x 256 tile products) below which the serial order is
+                                         // faster (update < chain); 650 = the lower tiles of a 4608-row trailing matrix
+    // two-level factorisation (chol.h): a super-panel of 512 / 1024 / 2048 columns is used while the remaining matrix has
+    // at least super_min[0 / 1 / 2] rows (0 = never)
+    int64_t super_min[3] = {6144, 16384, 0};
+    int64_t whiten_super = 1024;         // super-block width of whiten_rows_inv (GPMI_WHITEN_SUPER; 256 = one level)
     int gemm_reserve = 0;
     std::vector<hipEvent_t> la_events;
     size_t la_next = 0;   // cross-stream dependencies, reused by every factorisation
