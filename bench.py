@@ -211,10 +211,11 @@ def run_workload(g, ctx, n, d, p, dtype, steps, warmup, barrier, comm=None):
         mu, s2 = step(warmup + i)
     barrier()
     elapsed = time.perf_counter() - t0
+    syrk_bytes = ctx.profile_get_bytes(g._lib.PROF_SYRK)
     prof = {name: ctx.profile_get(getattr(g._lib, "PROF_" + name)) for name in ("SYRK", "COV", "PANEL", "SOLVE", "PREDICT")}
     ctx.profile_enable(False)
     assert np.all(np.isfinite(mu)) and np.all(np.isfinite(s2)) and math.isfinite(gp.mll)
-    return {"elapsed": elapsed, "prof": prof, "t_build": t_build, "mll": gp.mll, "ll": ll}
+    return {"elapsed": elapsed, "prof": prof, "syrk_bytes": syrk_bytes, "t_build": t_build, "mll": gp.mll, "ll": ll}
 
 
 def roofline_object(args, res, n, d, p, dtype, steps):
@@ -223,7 +224,7 @@ def roofline_object(args, res, n, d, p, dtype, steps):
     achieved = (fl_syrk / max(ms_syrk, 1e-9)) * 1e-9  # flop/ms -> TFLOP/s
     es = 8 if dtype == "f64" else 4
     return {
-        "kernel": "gemm_nt_kernel<T, 0, 4> (Cholesky trailing update, 128x128 tiles, v_mfma_f64_16x16x4)",
+        "kernel": "gemm_nt_kernel<T, 0, 4> (Cholesky trailing update, 128x128 tiles, K = super-panel width, v_mfma_f64_16x16x4)",
         "bound": "mfma",
         "achieved": achieved,
         "peak": peak,
@@ -233,8 +234,8 @@ def roofline_object(args, res, n, d, p, dtype, steps):
         "launches": n_syrk,
         "avg_launch_ms": ms_syrk / max(n_syrk, 1),
         "algorithmic_flops_per_launch": fl_syrk / max(n_syrk, 1),
-        # C tile read + write (es bytes each) per 2 * 256 flops of an entry; the panel itself is read once
-        "algorithmic_bytes_per_launch": fl_syrk / max(n_syrk, 1) / (2.0 * 256.0) * 2 * es,
+        # every trailing entry read + written once per launch, the factored panel read once (K = 256 ... 1024 per launch)
+        "algorithmic_bytes_per_launch": res["syrk_bytes"] / max(n_syrk, 1),
     }
 
 

@@ -143,13 +143,14 @@ static hipEvent_t take_event(gpmi_ctx* c) {
     hipEventCreate(&e);
     return e;
 }
-ProfScope::ProfScope(gpmi_ctx* ctx, int cls, double work) : c(ctx) {
+ProfScope::ProfScope(gpmi_ctx* ctx, int cls, double work, double bytes) : c(ctx) {
     if (!c->prof_on) return;
     ProfRec r;
     r.a = take_event(c);
     r.b = take_event(c);
     r.cls = cls;
     r.work = work;
+    r.bytes = bytes;
     hipEventRecord(r.a, c->stream);
     idx = (int)c->prof.size();
     c->prof.push_back(r);
@@ -167,6 +168,7 @@ static int drain_profile(gpmi_ctx* c) {
         c->prof_n[r.cls] += 1;
         c->prof_ms[r.cls] += ms;
         c->prof_work[r.cls] += r.work;
+        c->prof_bytes[r.cls] += r.bytes;
         c->ev_pool.push_back(r.a);
         c->ev_pool.push_back(r.b);
     }
@@ -248,8 +250,9 @@ static int fit_t(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int
     // logNoise = -8 the mll error is -0.46 without it, -4e-6 with it, LAPACK's own +0.04).  The usual case does not pay.
     const bool refine = min_nugget < 1e-5 * c->h_prog->kdiag || c->refine_default;
     c->refine_solves = refine;
-    cholesky_lower<T>(c, A, ld, (T*)gp->linv, (T*)gp->invdiag, npad, 1, c->d_info);
+    const int rc_chol = cholesky_lower<T>(c, A, ld, (T*)gp->linv, (T*)gp->invdiag, npad, 1, c->d_info);
     c->refine_solves = c->refine_default;
+    if (rc_chol) return rc_chol;
 
     {
         ProfScope ps(c, GPMI_PROF_SOLVE, (double)npad * (double)npad * 0.5 * sizeof(T));
@@ -496,7 +499,9 @@ int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
         hipMalloc(&c->d_scal, 8 * sizeof(double)) != hipSuccess ||
         hipHostMalloc(&c->h_scal, 8 * sizeof(double)) != hipSuccess ||
         hipMalloc(&c->d_queue, (64 + 4 * 1024) * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(c->d_queue, 0, (64 + 4 * 1024) * sizeof(unsigned long long)) != hipSuccess) {
+        hipMemset(c->d_queue, 0, (64 + 4 * 1024) * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc(&c->d_queue_side, 64 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(c->d_queue_side, 0, 64 * sizeof(unsigned long long)) != hipSuccess) {
         gpmi_ctx_destroy(c);
         return GPMI_EDEVICE;
     }
@@ -511,7 +516,7 @@ int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
             (void)hipGetLastError();
             c->side_stream = nullptr;
         }
-        c->lookahead_slots = 8;
+        c->lookahead_slots = 16;  // 8 in round 1 (a 7-launch chain per panel); the super-block factorisation has launches of up to 28 workgroups
         if (const char* e = getenv("GPMI_LOOKAHEAD")) c->lookahead_slots = atoi(e) / 8 * 8;
         if (const char* e = getenv("GPMI_LOOKAHEAD_MIN")) {  // given as a trailing size, as in round 1
             const double t = atof(e);
@@ -523,6 +528,7 @@ int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
         sscanf(e, "%lld,%lld,%lld", &a, &b, &d);
         c->super_min[0] = a; c->super_min[1] = b; c->super_min[2] = d;
     }
+    if (const char* e = getenv("GPMI_SUPER_INV")) c->super_inverse = atoi(e) != 0;
     if (const char* e = getenv("GPMI_WHITEN_SUPER")) c->whiten_super = std::max<long long>(NB, atoll(e) / NB * NB);
     if (const char* e = getenv("GPMI_REFINE")) c->refine_default = atoi(e) != 0;
     c->refine_solves = c->refine_default;
@@ -544,12 +550,15 @@ void gpmi_ctx_destroy(gpmi_ctx* c) {
     for (auto e : c->ev_pool) hipEventDestroy(e);
     for (auto e : c->la_events) hipEventDestroy(e);
     if (c->side_stream) hipStreamDestroy(c->side_stream);
+    for (void* p : {c->sup_lw, c->sup_lwt, c->sup_l256, c->sup_ut, c->sup_s})
+        if (p) hipFree(p);
     if (c->d_prog) hipFree(c->d_prog);
     if (c->h_prog) hipHostFree(c->h_prog);
     if (c->d_info) hipFree(c->d_info);
     if (c->d_scal) hipFree(c->d_scal);
     if (c->h_scal) hipHostFree(c->h_scal);
     if (c->d_queue) hipFree(c->d_queue);
+    if (c->d_queue_side) hipFree(c->d_queue_side);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -755,6 +764,7 @@ int gpmi_profile_enable(gpmi_ctx* c, int on) {
         c->prof_n[i] = 0;
         c->prof_ms[i] = 0;
         c->prof_work[i] = 0;
+        c->prof_bytes[i] = 0;
     }
     return rc;
 }
@@ -769,6 +779,18 @@ int gpmi_profile_get(gpmi_ctx* c, int cls, int64_t* launches, double* total_ms, 
     c->prof_n[cls] = 0;
     c->prof_ms[cls] = 0;
     c->prof_work[cls] = 0;
+    return GPMI_OK;
+}
+
+int gpmi_profile_get_bytes(gpmi_ctx* c, int cls, double* bytes) {
+    if (!c || cls < 0 || cls >= GPMI_PROF_NCLASS || !bytes) {
+        if (c) c->err = "gpmi_profile_get_bytes: bad class or null output";
+        return GPMI_EARG;
+    }
+    int rc = drain_profile(c);
+    if (rc) return rc;
+    *bytes = c->prof_bytes[cls];
+    c->prof_bytes[cls] = 0;
     return GPMI_OK;
 }
 

@@ -123,7 +123,8 @@ inline void factor_panel_rows(gpmi_ctx* c, T* A, int64_t ld, const T* linv, int6
     // one fused launch when every workgroup gets a CU to itself (rows256 keeps 64 x 256 of X in registers: one workgroup
     // per CU; with more row blocks than CUs it would run in two rounds and lose to the four rows64 launches);
     // the refinement step lives in rows64 only
-    if (!c->refine_solves && (M + IB - 1) / IB <= c->num_cus) {
+    // (and never beside the persistent update: a 512-register workgroup needs a whole CU and would wait for the update to end)
+    if (!c->refine_solves && !c->beside_update && (M + IB - 1) / IB <= c->num_cus) {
         launch_rows256<T>(c, A + r0 * ld + k0, ld, M, (int)(nbk / IB), A + k0 * ld + k0, ld, linv + (k0 / IB) * IB * IB, d_info);
         return;
     }
@@ -151,9 +152,9 @@ inline void factor_panel_below(gpmi_ctx* c, T* A, int64_t ld, const T* linv, int
 //
 // LOOK-AHEAD at the super-panel level: step 1 of the NEXT super-panel — every latency-bound launch of the factorisation —
 // runs on a second, high-priority stream UNDER step 3 of the current one.  For that the update is split by tiles: the lower
-// tiles of the next W' x W' diagonal block go first on the side stream, everything else is one persistent launch on the
-// main stream (tile_order.h lower mode with a row offset) whose grid leaves `lookahead_slots` workgroup slots free, which
-// is where the side stream's small kernels land.  With W = 256 this is round 1's scheme.
+// tiles of the next W' x W' diagonal block go first (their own short launch on the main stream), everything else is one
+// persistent launch on the main stream (tile_order.h lower mode with a row offset) whose grid leaves `lookahead_slots`
+// workgroup slots free, which is where the side stream's small kernels land.
 // (Two measured dead ends, tools/cumask_probe.hip + profiles/: splitting off the next panel's COLUMNS costs a
 // single-round GEMM launch as long as the chain it hides; CU-masked streams work but cost the GEMM 4 % for 8 CUs.)
 inline int64_t super_width(const gpmi_ctx* c, int64_t trailing) {
@@ -177,29 +178,92 @@ inline void factor_diag_block(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag
     }
 }
 
-// step 2: rows [ke, Mtot) of the super-panel's columns [ks, ke):  X <- X L^-T, left-looking by NB columns
+// The explicit inverse LW of the w x w diagonal super-block at (k, k), w = NB * 2^s, on the CURRENT stream:
+//   level 0   the NB x NB diagonal inverses (linv256_kernel over the block's own 64 x 64 inverses), placed on the diagonal
+//             of LW and, transposed, of LWT (everything else zeroed);
+//   level h   pairs of h x h blocks merge into 2h x 2h:  [A 0; C B]^-1 = [A^-1 0; -B^-1 C A^-1  B^-1].  With NT products only
+//             (both operands K-contiguous) this takes the transposes along:  U' = A^-T C' ,  X = -B^-1 (U')' ,  X' = -U' B^-T.
+// A dozen tiny launches (2 x 2 to 4 x 4 tiles): on the side stream they ride under the trailing update.
 template <typename T>
-inline void rows_below_super(gpmi_ctx* c, T* A, int64_t ld, const T* linv, int64_t ks, int64_t ke, int64_t Mtot, const int* d_info) {
+inline void build_super_inverse(gpmi_ctx* c, const T* A, int64_t ld, const T* linv64, int64_t k, int64_t w, const int* d_info) {
+    T* LW = (T*)c->sup_lw;
+    T* LWT = (T*)c->sup_lwt;
+    T* UT = (T*)c->sup_ut;
+    const int64_t wld = c->sup_wld;
+    const TileShape rect{0, 0, 0, 0, 1, 0};
+    launch_linv256<T>(c, A + k * ld + k, ld, linv64 + (k / IB) * IB * IB, (T*)c->sup_l256, w, d_info);
+    launch_place_inv_blocks<T>(c, (const T*)c->sup_l256, LW, LWT, wld, (int)(w / NB));
+    for (int64_t h = NB; h < w; h *= 2)
+        for (int64_t p = 0; p < w; p += 2 * h) {
+            const T* AinvT = LWT + p * wld + p;
+            const T* Binv = LW + (p + h) * wld + (p + h);
+            const T* C = A + (k + p + h) * ld + (k + p);
+            launch_gemm_shape<T>(c, UT, h, AinvT, wld, C, ld, h, h, h, rect, d_info, GEMM_OVERWRITE | GEMM_AUX);
+            launch_gemm_shape<T>(c, LW + (p + h) * wld + p, wld, Binv, wld, UT, h, h, h, h, rect, d_info, GEMM_AUX);
+            if (2 * h < w) launch_gemm_shape<T>(c, LWT + p * wld + (p + h), wld, UT, h, Binv, wld, h, h, h, rect, d_info, GEMM_AUX);
+        }
+}
+
+// step 2: rows [ke, Mtot) of the super-panel's columns [ks, ke):  X <- X L^-T.
+//   by_inverse: ONE product with the explicit inverse of the diagonal super-block, whose K loop ends at each column tile's
+//   last column (LW is lower triangular: the same flops as the substitution), out of place into S and copied back;
+//   otherwise left-looking by NB columns through the stored 64 x 64 inverses (the form that carries the refinement step).
+template <typename T>
+inline void rows_below_super(gpmi_ctx* c, T* A, int64_t ld, const T* linv, int64_t ks, int64_t ke, int64_t Mtot, const int* d_info,
+                             bool by_inverse) {
     if (Mtot <= ke) return;
+    const int64_t M = Mtot - ke, w = ke - ks;
+    if (by_inverse) {
+        T* S = (T*)c->sup_s;
+        launch_gemm_shape<T>(c, S, w, A + ke * ld + ks, ld, (const T*)c->sup_lw, c->sup_wld, M, w, w, TileShape{0, 0, 0, 0, 1, 0}, d_info,
+                             GEMM_OVERWRITE | GEMM_KEND_COL | GEMM_AUX);
+        (void)hipMemcpy2DAsync(A + ke * ld + ks, (size_t)ld * sizeof(T), S, (size_t)w * sizeof(T), (size_t)w * sizeof(T), (size_t)M,
+                               hipMemcpyDeviceToDevice, c->stream);
+        return;
+    }
     for (int64_t k0 = ks; k0 < ke; k0 += NB) {
         const int64_t nbk = std::min<int64_t>(NB, ke - k0);
         if (k0 > ks)
-            launch_gemm_shape<T>(c, A + ke * ld + k0, ld, A + ke * ld + ks, ld, A + k0 * ld + ks, ld, Mtot - ke, nbk, k0 - ks,
+            launch_gemm_shape<T>(c, A + ke * ld + k0, ld, A + ke * ld + ks, ld, A + k0 * ld + ks, ld, M, nbk, k0 - ks,
                                  TileShape{0, 0, 0, 0, 1, 0}, d_info, GEMM_AUX);
         factor_panel_rows<T>(c, A, ld, linv, k0, nbk, ke, Mtot, d_info);
     }
 }
 
+// scratch of the inverse path for super-panels up to wmax columns and mrows rows below; GPMI_OK / GPMI_EDEVICE
 template <typename T>
-inline void cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, int64_t npad, int64_t extra, int* d_info) {
+inline int super_scratch(gpmi_ctx* c, int64_t wmax, int64_t mrows) {
+    int rc;
+    if ((rc = grow(c, &c->sup_lw, &c->sup_lw_cap, wmax * wmax * (int64_t)sizeof(T)))) return rc;
+    if ((rc = grow(c, &c->sup_lwt, &c->sup_lwt_cap, wmax * wmax * (int64_t)sizeof(T)))) return rc;
+    if ((rc = grow(c, &c->sup_l256, &c->sup_l256_cap, wmax * NB * (int64_t)sizeof(T)))) return rc;
+    if ((rc = grow(c, &c->sup_ut, &c->sup_ut_cap, (wmax / 2) * (wmax / 2) * (int64_t)sizeof(T)))) return rc;
+    if ((rc = grow(c, &c->sup_s, &c->sup_s_cap, mrows * wmax * (int64_t)sizeof(T)))) return rc;
+    c->sup_wld = wmax;
+    return GPMI_OK;
+}
+
+template <typename T>
+inline int cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, int64_t npad, int64_t extra, int* d_info) {
     const int64_t Mtot = npad + extra;
     const bool can_look = c->lookahead_slots > 0 && c->side_stream && npad > 4 * NB;
     hipStream_t main_s = c->stream, side = c->side_stream;
 
-    int64_t ks = 0, ke = std::min<int64_t>(super_width(c, npad), npad);
+    // the inverse path serves super-panels of NB * 2^s > NB columns; factorisations that carry the refinement step
+    // (nugget-regularised matrices) keep the substitution through the 64 x 64 inverses
+    const int64_t w0 = super_width(c, npad);
+    const bool inv_ok = c->super_inverse && !c->refine_solves && w0 > NB;
+    if (inv_ok) {
+        const int rc = super_scratch<T>(c, w0, Mtot);
+        if (rc) return rc;
+    }
+    auto by_inverse = [&](int64_t w) { return inv_ok && w > NB && (w & (w - 1)) == 0; };  // NB * 2^s only
+
+    int64_t ks = 0, ke = std::min<int64_t>(w0, npad);
     factor_diag_block<T>(c, A, ld, linv, invdiag, 0, ke, d_info);
+    if (by_inverse(ke) && Mtot > ke) build_super_inverse<T>(c, A, ld, linv, 0, ke, d_info);
     for (;;) {
-        rows_below_super<T>(c, A, ld, linv, ks, ke, Mtot, d_info);
+        rows_below_super<T>(c, A, ld, linv, ks, ke, Mtot, d_info, by_inverse(ke - ks));
         if (ke >= npad) break;
         const int64_t ke2 = std::min<int64_t>(ke + super_width(c, npad - ke), npad);
         const int64_t K = ke - ks, w2 = ke2 - ke;
@@ -209,16 +273,29 @@ inline void cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, i
         if (!can_look || ntile < (double)c->lookahead_min_tiles * (double)((w2 + NB - 1) / NB)) {
             launch_gemm_nt<T>(c, A + ke * ld + ke, ld, A + ke * ld + ks, ld, A + ke * ld + ks, ld, Mtot - ke, npad - ke, K, 1, d_info);
             factor_diag_block<T>(c, A, ld, linv, invdiag, ke, w2, d_info);
+            if (by_inverse(w2) && Mtot > ke2) build_super_inverse<T>(c, A, ld, linv, ke, w2, d_info);
         } else {
-            hipEvent_t eb = la_event(c);  // columns [ks, ke) complete
+            // The next diagonal block's own tiles go FIRST.  A 256-wide block (6 workgroups of 128 x 64 tiles) fits the
+            // reserved slots and rides on the side stream, as in round 1.  Wider blocks go on the main stream at full speed
+            // (one under-filled round: <= 272 workgroups, ~0.2 ms) instead of trickling through 8 slots.
+            // (profiles/r02_twolevel_critical_path.txt: the first version launched them on the side stream and they ended
+            // only when the update did; so did rows256 — 512 registers, a whole CU — which the side stream never uses now.)
+            const bool tiles_on_side = w2 <= NB;
+            if (!tiles_on_side)
+                launch_gemm_shape<T>(c, A + ke * ld + ke, ld, A + ke * ld + ks, ld, A + ke * ld + ks, ld, w2, w2, K,
+                                     TileShape{0, 0, 1, 0, 1, 0}, d_info, GEMM_AUX);
+            hipEvent_t eb = la_event(c);  // columns [ks, ke) complete and their inverse consumed
             (void)hipEventRecord(eb, main_s);
             (void)hipStreamWaitEvent(side, eb, 0);
             {
-                StreamScope sc(c, side, c->num_cus);
-                // the next diagonal block's own tiles, then its factorisation
-                launch_gemm_shape<T>(c, A + ke * ld + ke, ld, A + ke * ld + ks, ld, A + ke * ld + ks, ld, w2, w2, K,
-                                     TileShape{0, 0, 1, 0, 1, 0}, d_info, GEMM_AUX);
+                StreamScope sc(c, side, c->num_cus);  // the block's factorisation and its inverse: small launches
+                c->beside_update = true;  // only kernels that fit a half-free CU (<= 256 registers)
+                if (tiles_on_side)
+                    launch_gemm_shape<T>(c, A + ke * ld + ke, ld, A + ke * ld + ks, ld, A + ke * ld + ks, ld, w2, w2, K,
+                                         TileShape{0, 0, 1, 0, 1, 0}, d_info, GEMM_AUX);
                 factor_diag_block<T>(c, A, ld, linv, invdiag, ke, w2, d_info);
+                if (by_inverse(w2) && Mtot > ke2) build_super_inverse<T>(c, A, ld, linv, ke, w2, d_info);
+                c->beside_update = false;
             }
             hipEvent_t ec = la_event(c);
             (void)hipEventRecord(ec, side);
@@ -233,6 +310,7 @@ inline void cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, i
         ks = ke;
         ke = ke2;
     }
+    return GPMI_OK;
 }
 
 

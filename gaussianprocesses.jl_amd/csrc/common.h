@@ -60,6 +60,7 @@ struct ProfRec {
     hipEvent_t a, b;
     int cls;
     double work;
+    double bytes;
 };
 
 }  // namespace gpmi
@@ -75,6 +76,8 @@ struct gpmi_ctx {
     double* h_scal = nullptr;            // pinned
     unsigned long long* d_queue = nullptr;  // 8 per-XCD tile-queue words, 64 B apart (never reset)
     unsigned long long queue_base[8] = {0}; // value of each word when the next launch starts
+    unsigned long long* d_queue_side = nullptr;   // a second set for persistent launches beside the update (side stream):
+    unsigned long long queue_base_side[8] = {0};  // the two run concurrently and must not share queue words
     bool refine_default = false;         // GPMI_REFINE=1: refine everywhere (bring-up / accuracy studies)
     bool refine_solves = false;          // rows64: one refinement step on every product with a stored inverse
                                          // (set for factorisations regularised only by a nugget; panel.hip)
@@ -90,9 +93,20 @@ struct gpmi_ctx {
                                          // faster (update < chain); 650 = the lower tiles of a 4608-row trailing matrix
     // two-level factorisation (chol.h): a super-panel of 512 / 1024 / 2048 columns is used while the remaining matrix has
     // at least super_min[0 / 1 / 2] rows (0 = never)
-    int64_t super_min[3] = {6144, 16384, 0};
+    int64_t super_min[3] = {8192, 12288, 24576};  // swept on N = 50 000 and N = 20 000 (profiles/r02_super_sweep.log)
+    // scratch of the two-level factorisation (grown on demand, chol.h): the explicit inverse of the current W x W diagonal
+    // super-block (sup_lw, leading dimension sup_wld) and its transpose, the packed 256-inverses it is built from, an
+    // (W/2)^2 product buffer, and the out-of-place image of the solved rows below (rows x W)
+    void* sup_lw = nullptr;  int64_t sup_lw_cap = 0;
+    void* sup_lwt = nullptr; int64_t sup_lwt_cap = 0;
+    void* sup_l256 = nullptr; int64_t sup_l256_cap = 0;
+    void* sup_ut = nullptr;  int64_t sup_ut_cap = 0;
+    void* sup_s = nullptr;   int64_t sup_s_cap = 0;
+    int64_t sup_wld = 0;
+    int super_inverse = 1;               // rows below a super-panel through its explicit inverse (GPMI_SUPER_INV=0: NB-block substitution)
     int64_t whiten_super = 1024;         // super-block width of whiten_rows_inv (GPMI_WHITEN_SUPER; 256 = one level)
     int gemm_reserve = 0;
+    bool beside_update = false;          // launches made now run in the reserved slots beside the persistent update: no whole-CU kernels
     std::vector<hipEvent_t> la_events;
     size_t la_next = 0;   // cross-stream dependencies, reused by every factorisation
     bool prof_on = false;
@@ -101,7 +115,18 @@ struct gpmi_ctx {
     int64_t prof_n[GPMI_PROF_NCLASS] = {0};
     double prof_ms[GPMI_PROF_NCLASS] = {0};
     double prof_work[GPMI_PROF_NCLASS] = {0};
+    double prof_bytes[GPMI_PROF_NCLASS] = {0};  // algorithmic HBM bytes (trailing update: C read + write, operand panels once)
 };
+
+namespace gpmi {
+// Launches made beside the persistent trailing update (chol.h: beside_update) must not have more workgroups than the slots
+// that update leaves free: measured (profiles/r02_twolevel_critical_path.txt), a 12-workgroup rows64 launch on the side
+// stream ended only when the update did, 25 ms later, while launches of <= 8 workgroups ran in ~0.1 ms.  Capped launches
+// walk their work items grid-stride.
+inline int64_t side_cap(const gpmi_ctx* c, int64_t nwg) {
+    return c->beside_update && nwg > c->lookahead_slots ? (int64_t)c->lookahead_slots : nwg;
+}
+}  // namespace gpmi
 
 struct gpmi_gp {
     gpmi_ctx* ctx = nullptr;
@@ -149,7 +174,7 @@ namespace gpmi {
 struct ProfScope {
     gpmi_ctx* c;
     int idx = -1;
-    ProfScope(gpmi_ctx* ctx, int cls, double work);
+    ProfScope(gpmi_ctx* ctx, int cls, double work, double bytes = 0.0);
     ~ProfScope();
 };
 
@@ -187,6 +212,7 @@ template <typename T>
 void launch_gemm_shape(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M,
                        int64_t N, int64_t K, TileShape shape, const int* info, int flags = 0, const GemmBatch* batch = nullptr);
 enum GemmFlags { GEMM_OVERWRITE = 1 /* C = A B' instead of C -= A B' */, GEMM_KSTART_ROW = 2 /* A[i][k] = 0 for k < i: start K at the tile's first row */,
+                 GEMM_KEND_COL = 8 /* B[j][k] = 0 for k > j: end K at the tile's last column */,
                  GEMM_AUX = 4 /* no effect on the kernel: account the launch to the panel class, not to the trailing update */,
                  GEMM_NO_PAIR16 = 32 /* tools: 8-byte instead of 16-byte C accesses in fp64 (A/B of the access width) */ };
 
@@ -218,6 +244,9 @@ void launch_bsolve_step(gpmi_ctx* ctx, const T* Arow, int64_t ld, int64_t j0, co
 // mll / logdet / y'alpha  ->  out[0] = mll, out[1] = logdet, out[2] = y'alpha
 template <typename T>
 void launch_linv256(gpmi_ctx* ctx, const T* A, int64_t ld, const T* linv64, T* out, int64_t npad, const int* info);
+// level 0 of the super-panel inverse: packed NB x NB inverses onto the diagonal of LW and (transposed) LWT
+template <typename T>
+void launch_place_inv_blocks(gpmi_ctx* ctx, const T* l256, T* LW, T* LWT, int64_t wld, int nblk);
 template <typename T>
 void launch_bsolve256(gpmi_ctx* ctx, const T* Arow, int64_t ld, int64_t k0, int nbk, const T* linv256, T* z, T* alpha);
 template <typename T>

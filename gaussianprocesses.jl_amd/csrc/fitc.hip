@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void fitc_negate_kernel(T* __restrict__ A, int
 template <typename T>
 void factor_dense(gpmi_ctx* c, T* A, int64_t ld, int64_t mpad, int64_t extra, T* linv, T* linv256, T* invdiag) {
     c->refine_solves = true;  // the only regularisation of Kuu / SigmaQR is make_posdef!'s 1e-10 nugget
-    cholesky_lower<T>(c, A, ld, linv, invdiag, mpad, extra, c->d_info);
+    (void)cholesky_lower<T>(c, A, ld, linv, invdiag, mpad, extra, c->d_info);  // refinement on: no scratch, cannot fail
     c->refine_solves = c->refine_default;
     launch_linv256<T>(c, A, ld, linv, linv256, mpad, c->d_info);
 }
@@ -311,7 +311,7 @@ int fitc_fit_t(gpmi_fitc* f, const gpmi_kernel* k, double log_noise, const void*
                            AS, ldm, (const T*)f->Cpart, f->nsplit, mpad * ldm, (const T*)f->G1, 1e-10);
     }
     // chol(B) carries t -> z = L_B^-1 t; back-substitution -> cvec = B^-1 t
-    cholesky_lower<T>(c, AS, ldm, (T*)f->linv_S, (T*)f->invdiag_S, mpad, 1, c->d_info);
+    if (const int rc_chol = cholesky_lower<T>(c, AS, ldm, (T*)f->linv_S, (T*)f->invdiag_S, mpad, 1, c->d_info)) return rc_chol;
     launch_linv256<T>(c, AS, ldm, (const T*)f->linv_S, (T*)f->linv256_S, mpad, c->d_info);
     for (int64_t k0 = (mpad - 1) / NB * NB; k0 >= 0; k0 -= NB)
         launch_bsolve256<T>(c, AS + k0 * ldm, ldm, k0, (int)std::min<int64_t>(NB, mpad - k0),

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __rest
     const int wm = wv >> 1, wn = wv & 1;
     const int wvu = __builtin_amdgcn_readfirstlane(wv);  // provably wave-uniform (LDS-DMA base goes to M0)
     const int r16 = lane & 15, g = lane >> 4;
-    const int nk = (int)(K / BK);
+    const int nk_full = (int)(K / BK);
     // fragment read offsets inside a row for the two k-halves: logical chunk 4h + g, swizzled by the row
     const int fo[2] = {((g) ^ (r16 & 7)) * E, ((4 + g) ^ (r16 & 7)) * E};
 
@@ -190,6 +190,9 @@ __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __rest
         // GEMM_KSTART_ROW: A is upper-triangular-by-rows (A[i][k] = 0 for k < i), so the products below the
         // tile's first row vanish — start the K loop there (this is what makes K^-1 = L^-T L^-1 cost N^3/3)
         const int kbeg = (flags & GEMM_KSTART_ROW) ? (int)(m0 / BK) : 0;
+        // GEMM_KEND_COL: B is lower-triangular-by-rows (B[j][k] = 0 for k > j): the products right of the tile's last
+        // column vanish — stop the K loop there (product with an explicit triangular inverse, chol.h rows_below_super)
+        const int nk = (flags & GEMM_KEND_COL) ? (int)(((n0 + BN < K ? n0 + BN : K)) / BK) : nk_full;
         stage(kbeg & 1, kbeg * BK);
         Acc acc[4][NI];
         if ((VARIANT & 1) || overwrite) {
@@ -441,9 +444,12 @@ static void launch_persistent_ni(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, i
     const int64_t ntiles = tiles_per * (batch ? batch->count : 1);
     if (ntiles <= 0) return;
     const int per_cu = NI == 2 ? (ctx->gemm_wgs_per_cu == 1 ? 1 : 3) : ctx->gemm_wgs_per_cu;
-    const int slots = per_cu * ctx->num_cus - ctx->gemm_reserve;  // both multiples of 8
+    // beside the persistent update (side stream): no more workgroups than the slots it leaves free, and a queue of its own
+    const bool side = ctx->beside_update;
+    const int slots = side ? ctx->lookahead_slots : per_cu * ctx->num_cus - ctx->gemm_reserve;  // multiples of 8
     // small launches: one workgroup per tile (rounded up to a multiple of 8 so XCD chunks stay contiguous)
     const int grid = (int)std::min<int64_t>(slots, (ntiles + 7) / 8 * 8);
+    unsigned long long* const qbase = side ? ctx->queue_base_side : ctx->queue_base;
     QueueArgs qa;
     qa.use_queue = ntiles > grid;
     qa.tiles_per = tiles_per;
@@ -452,15 +458,15 @@ static void launch_persistent_ni(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, i
     qa.strideC = batch ? batch->strideC : 0;
     for (int x = 0; x <= 8; ++x) qa.start[x] = ntiles * x / 8;
     for (int x = 0; x < 8; ++x) {
-        qa.base[x] = ctx->queue_base[x];
+        qa.base[x] = qbase[x];
         // (chunk - nloc) successful pulls + one failing pull per workgroup (or `chunk` failing pulls when
         // the chunk is smaller than the XCD's workgroup count): the word advances by `chunk` either way
-        if (qa.use_queue) ctx->queue_base[x] += (unsigned long long)(qa.start[x + 1] - qa.start[x]);
+        if (qa.use_queue) qbase[x] += (unsigned long long)(qa.start[x + 1] - qa.start[x]);
     }
     static const bool no_pair16 = getenv("GPMI_GEMM_NO_PAIR16") != nullptr;  // tools: A/B of the C access width
     if (no_pair16) flags |= GEMM_NO_PAIR16;
     hipLaunchKernelGGL((gemm_nt_kernel<T, V, NI>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, C, ldc, A, lda, B, ldb, M, N,
-                       K, shape, ctx->d_queue, qa, info, flags);
+                       K, shape, side ? ctx->d_queue_side : ctx->d_queue, qa, info, flags);
 }
 // 128 x 64 tiles with three workgroups per CU for launches that do not fill the chip for long: measured at K = 256
 // (tools/gemm_phases.py) 16 tiles 49 -> 28 us, 310 tiles 92 -> 70 us, 780 lower tiles 34.5 -> 42 TFLOP/s, and no
@@ -506,8 +512,12 @@ void launch_gemm_shape(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda
     // launches run as narrow tiles and are accounted with the panel), <T, 64, *> every other product.
     const bool narrow = use_narrow_tiles(ctx, M, N, shape, batch);
     const bool trailing = shape.mode && !flags && !narrow;
-    ProfScope ps(ctx, trailing ? GPMI_PROF_SYRK : GPMI_PROF_PANEL,
-                 2.0 * shape_entries(M, N, shape) * (double)K * (batch ? batch->count : 1));
+    // algorithmic bytes: every output entry read and written once, the operand panels once (B inside A for the SYRK shape)
+    const double entries = shape_entries(M, N, shape) * (batch ? batch->count : 1);
+    const bool b_in_a = B >= A && B < A + M * lda;
+    const double abytes = sizeof(T) * ((flags & GEMM_OVERWRITE ? 1.0 : 2.0) * entries +
+                                       ((double)M + (b_in_a ? 0.0 : (double)N)) * (double)K * (batch ? batch->count : 1));
+    ProfScope ps(ctx, trailing ? GPMI_PROF_SYRK : GPMI_PROF_PANEL, 2.0 * entries * (double)K, abytes);
     if (trailing)
         launch_persistent<T, 0>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags, batch, false);
     else

@@ -218,7 +218,11 @@ __global__ __launch_bounds__(256, 2) void rows64_kernel(T* __restrict__ Xp, int6
     __shared__ T buf2[64 * LD];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv >> 1, wn = wv & 1;
-    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    // one 64-row block per workgroup, or — when the launch is capped to the slots the persistent update leaves free
+    // (chol.h: beside_update) — a grid-stride walk over the row blocks
+    const int64_t nblk = (M + 63) / 64;
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t row0 = blk * 64;
 
     Acc acc[2][2];
 #pragma unroll
@@ -370,6 +374,8 @@ __global__ __launch_bounds__(256, 2) void rows64_kernel(T* __restrict__ Xp, int6
                     Dg[(int64_t)row * ldx + col] -= acc_get<T>(acc[mi][ni], r);
                 }
             }
+    }
+    __syncthreads();  // the next row block reuses buf1 / buf2
     }
 }
 
@@ -534,17 +540,14 @@ __global__ __launch_bounds__(256) void bsolve_step_kernel(const T* __restrict__ 
 // triangular solve against the factor (predict whitening, back-substitution) is ONE product per NB columns.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void linv256_kernel(const T* __restrict__ A, int64_t ld, const T* __restrict__ linv64,
-                                                      T* __restrict__ out, int64_t npad, const int* __restrict__ info) {
-    if (info && *info != 0) return;
+__device__ __forceinline__ void linv256_block(int vb, T* __restrict__ bufW, T* __restrict__ bufL, const T* __restrict__ A, int64_t ld,
+                                              const T* __restrict__ linv64, T* __restrict__ out, int64_t npad) {
     using MF = Mfma<T>;
     using Acc = typename MF::Acc;
     constexpr int LD = 65;
-    __shared__ T bufW[64 * LD];
-    __shared__ T bufL[64 * LD];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv >> 1, wn = wv & 1;
-    const int b = blockIdx.x >> 2, j = blockIdx.x & 3;
+    const int b = vb >> 2, j = vb & 3;
     const int64_t k0 = (int64_t)b * NB;
     const int64_t rem = npad - k0;
     const int nb = (int)((rem < NB ? rem : NB) / 64);
@@ -623,6 +626,53 @@ __global__ __launch_bounds__(256) void linv256_kernel(const T* __restrict__ A, i
                 }
             }
         }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void linv256_kernel(const T* __restrict__ A, int64_t ld, const T* __restrict__ linv64,
+                                                      T* __restrict__ out, int64_t npad, const int* __restrict__ info) {
+    if (info && *info != 0) return;
+    __shared__ T bufW[64 * 65];
+    __shared__ T bufL[64 * 65];
+    const int nvb = 4 * (int)((npad + NB - 1) / NB);  // (block, column block) pairs; grid-stride when the launch is capped
+    for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+        linv256_block<T>(vb, bufW, bufL, A, ld, linv64, out, npad);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// place_inv_blocks: level 0 of the super-panel inverse (chol.h build_super_inverse).  The packed NB x NB inverses (linv256
+// layout) go onto the diagonal of the w x w matrix LW (leading dimension wld) and, transposed, of LWT; every other 64 x 64
+// tile of both is zeroed (the merge products accumulate into them, and the triangular product reads the zeros above the
+// diagonal of its diagonal tiles).  Grid-stride over the (w/64)^2 tiles: the launch may be capped to a few workgroups.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void place_inv_blocks_kernel(const T* __restrict__ l256, T* __restrict__ LW, T* __restrict__ LWT,
+                                                               int64_t wld, int w64) {
+    __shared__ T tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int t = blockIdx.x; t < w64 * w64; t += gridDim.x) {
+        const int gi = t / w64, gj = t % w64;  // 64 x 64 tile (gi, gj) of the w x w matrix
+        if ((gi >> 2) != (gj >> 2)) {
+            for (int r = ty; r < 64; r += 4) {
+                LW[(int64_t)(gi * 64 + r) * wld + gj * 64 + tx] = T(0);
+                LWT[(int64_t)(gi * 64 + r) * wld + gj * 64 + tx] = T(0);
+            }
+            continue;
+        }
+        const int b = gi >> 2, ti = gi & 3, tj = gj & 3;
+        const T* src = l256 + (int64_t)b * NB * NB;
+        for (int r = ty; r < 64; r += 4) {
+            const T v = src[(int64_t)(ti * 64 + r) * NB + tj * 64 + tx];
+            LW[(int64_t)(gi * 64 + r) * wld + gj * 64 + tx] = v;
+            tile[r][tx] = v;
+        }
+        __syncthreads();
+        // LWT tile (gj, gi) = transpose of LW tile (gi, gj); every diagonal-block tile position is written exactly once
+        for (int r = ty; r < 64; r += 4) LWT[(int64_t)(gj * 64 + r) * wld + gi * 64 + tx] = tile[tx][r];
+        __syncthreads();
     }
 }
 
@@ -794,6 +844,13 @@ __global__ __launch_bounds__(256) void row_sumsq_kernel(const T* __restrict__ R,
 }  // namespace
 
 template <typename T>
+void launch_place_inv_blocks(gpmi_ctx* ctx, const T* l256, T* LW, T* LWT, int64_t wld, int nblk) {
+    const int w64 = nblk * (NB / 64);
+    hipLaunchKernelGGL(place_inv_blocks_kernel<T>, dim3((unsigned)side_cap(ctx, (int64_t)w64 * w64)), dim3(256), 0, ctx->stream, l256, LW, LWT,
+                       wld, w64);
+}
+
+template <typename T>
 void launch_diag64(gpmi_ctx* ctx, T* A, int64_t ld, T* linv, T* invdiag, int* info, int64_t pivot_base) {
     ProfScope ps(ctx, GPMI_PROF_PANEL, 2.0 * 64.0 * 64.0 * 64.0 / 3.0);
     hipLaunchKernelGGL(diag64_kernel<T>, dim3(1), dim3(256), 0, ctx->stream, A, ld, linv, invdiag, info, pivot_base);
@@ -803,7 +860,7 @@ void launch_rows64(gpmi_ctx* ctx, T* Xp, int64_t ldx, int64_t M, int K1, const T
                    int64_t diag_rows, const int* info) {
     if (M <= 0) return;
     ProfScope ps(ctx, GPMI_PROF_PANEL, 2.0 * (double)M * 64.0 * (double)(K1 + 64));
-    hipLaunchKernelGGL(rows64_kernel<T>, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, ctx->stream, Xp, ldx, M, K1, Lp, ldl,
+    hipLaunchKernelGGL(rows64_kernel<T>, dim3((unsigned)side_cap(ctx, (M + 63) / 64)), dim3(256), 0, ctx->stream, Xp, ldx, M, K1, Lp, ldl,
                        linv, diag_rows, info, ctx->refine_solves ? 1 : 0);
 }
 template <typename T>
@@ -822,7 +879,7 @@ void launch_bsolve_step(gpmi_ctx* ctx, const T* Arow, int64_t ld, int64_t j0, co
 template <typename T>
 void launch_linv256(gpmi_ctx* ctx, const T* A, int64_t ld, const T* linv64, T* out, int64_t npad, const int* info) {
     const unsigned nblk = (unsigned)((npad + NB - 1) / NB);
-    hipLaunchKernelGGL(linv256_kernel<T>, dim3(4 * nblk), dim3(256), 0, ctx->stream, A, ld, linv64, out, npad, info);
+    hipLaunchKernelGGL(linv256_kernel<T>, dim3((unsigned)side_cap(ctx, 4 * nblk)), dim3(256), 0, ctx->stream, A, ld, linv64, out, npad, info);
 }
 template <typename T>
 void launch_bsolve256(gpmi_ctx* ctx, const T* Arow, int64_t ld, int64_t k0, int nbk, const T* linv256, T* z, T* alpha) {
@@ -863,6 +920,7 @@ void launch_logdiag(gpmi_ctx* ctx, const T* A, int64_t ld, int64_t nrows, int64_
     template void launch_rows256<T>(gpmi_ctx*, T*, int64_t, int64_t, int, const T*, int64_t, const T*, const int*); \
     template void launch_bsolve_step<T>(gpmi_ctx*, const T*, int64_t, int64_t, const T*, T*, T*);                 \
     template void launch_linv256<T>(gpmi_ctx*, const T*, int64_t, const T*, T*, int64_t, const int*);             \
+    template void launch_place_inv_blocks<T>(gpmi_ctx*, const T*, T*, T*, int64_t, int);             \
     template void launch_bsolve256<T>(gpmi_ctx*, const T*, int64_t, int64_t, int, const T*, T*, T*);              \
     template void launch_finalize<T>(gpmi_ctx*, const T*, int64_t, int64_t, const T*, const T*, double*);         \
     template void launch_row_gemv<T>(gpmi_ctx*, const T*, int64_t, int64_t, int64_t, const T*, const T*, T*);     \

@@ -23,7 +23,7 @@ SYMBOLS = [
     "gpmi_gp_create", "gpmi_gp_destroy", "gpmi_fit", "gpmi_predict", "gpmi_grad", "gpmi_cov",
     "gpmi_inv_diag", "gpmi_fitc_create", "gpmi_fitc_destroy", "gpmi_fitc_fit", "gpmi_fitc_predict", "gpmi_fitc_alpha_u",
     "gpmi_solve", "gpmi_whiten", "gpmi_logdet", "gpmi_factor_to_host", "gpmi_factor_diag",
-    "gpmi_profile_enable", "gpmi_profile_get", "gpmi_mfma_peak", "gpmi_bench_gemm",
+    "gpmi_profile_enable", "gpmi_profile_get", "gpmi_profile_get_bytes", "gpmi_mfma_peak", "gpmi_bench_gemm",
     "gpmi_dev_set_kernel", "gpmi_dev_assemble", "gpmi_dev_cov_rows", "gpmi_dev_potrf_block", "gpmi_dev_rows_solve",
     "gpmi_dev_update", "gpmi_dev_bsolve_block", "gpmi_dev_row_gemv", "gpmi_dev_row_var", "gpmi_dev_logdiag_sum",
     "gpmi_dev_info", "gpmi_dev_sync",
@@ -98,6 +98,7 @@ def load():
     lib.gpmi_factor_diag.argtypes = [vp, vp]
     lib.gpmi_profile_enable.argtypes = [vp, C.c_int]
     lib.gpmi_profile_get.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(dbl), C.POINTER(dbl)]
+    lib.gpmi_profile_get_bytes.argtypes = [vp, C.c_int, C.POINTER(dbl)]
     lib.gpmi_mfma_peak.argtypes = [vp, C.c_int, C.POINTER(dbl)]
     lib.gpmi_bench_gemm.argtypes = [vp, C.c_int, i64, i64, i64, C.c_int, C.c_int, C.c_int, C.POINTER(dbl)]
     ci = C.c_int
@@ -159,6 +160,11 @@ class Context:
         n, ms, work = C.c_int64(), C.c_double(), C.c_double()
         self.check(load().gpmi_profile_get(self.h, cls_id, C.byref(n), C.byref(ms), C.byref(work)))
         return n.value, ms.value, work.value
+
+    def profile_get_bytes(self, cls_id):
+        b = C.c_double()
+        self.check(load().gpmi_profile_get_bytes(self.h, cls_id, C.byref(b)))
+        return b.value
 
     def mfma_peak(self, dtype=64):
         out = C.c_double()

@@ -189,6 +189,9 @@ int gpmi_profile_enable(gpmi_ctx*, int on);
 /* launches, total milliseconds and algorithmic work (flops for SYRK/PANEL/
  * PREDICT, bytes for COV/SOLVE) accumulated since the last call for `cls`.  */
 int gpmi_profile_get(gpmi_ctx*, int cls, int64_t* launches, double* total_ms, double* work);
+/* algorithmic HBM bytes of the MFMA products of `cls` accumulated since the last call (every output entry read and
+ * written once, the operand panels read once; K varies per launch since the two-level factorisation).             */
+int gpmi_profile_get_bytes(gpmi_ctx*, int cls, double* bytes);
 /* Peak-rate micro-benchmark of v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32:
  * returns measured TFLOP/s with every SIMD issuing back-to-back MFMAs.      */
 int gpmi_mfma_peak(gpmi_ctx*, int dtype, double* tflops_out);

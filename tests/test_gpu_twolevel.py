@@ -1,0 +1,120 @@
+"""The two-level factorisation and whitening (chol.h: super-panels of 512 / 1024 / 2048 columns, the next diagonal
+super-block factored and inverted on the side stream under the K = W trailing update, rows below solved through the
+explicit inverse of the super-block) at sizes the oracle finishes in seconds: the width thresholds are lowered through
+the bring-up environment of a fresh context so that every width, every transition between widths, ragged last blocks,
+the substitution fall-back and a pivot failing on the side stream are exercised.  Reference semantics:
+make_posdef! / dpotrf info (src/GP.jl:101-112), update_mll! (src/GPE.jl:202-212), predict_f (src/GP.jl:64-79)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+import gpmi355x as g
+from oracle import gp_oracle as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(monkeypatch, **env):
+    for k, v in env.items():
+        monkeypatch.setenv(k, str(v))
+    return g.Context(0)  # the knobs are read once per context
+
+
+def _close(a, b, rtol, atol, what):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    err = np.abs(a - b)
+    assert np.all(err <= atol + rtol * np.abs(b)), f"{what}: max abs err {err.max():.3e}"
+
+
+SPEC = ("sum", ("se_ard", [math.log(0.4), math.log(0.5), math.log(0.6), math.log(0.7)], 0.0), ("mat32_iso", math.log(0.8), -0.5))
+
+
+def _check(ctx, n, p, ln=math.log(0.15), noise_vec=False):
+    x, y, xs = G.synthetic_inputs(n, 4, p=p)
+    log_noise = ln + 0.3 * np.sin(np.arange(n)) if noise_vec else ln
+    gp = g.GP(x, y, g.MeanZero(), g.from_spec(SPEC), log_noise, ctx=ctx)
+    ref = G.update_mll(SPEC, x, y, log_noise)
+    assert gp.mll == pytest.approx(ref["mll"], rel=1e-9)
+    assert gp.cK.logdet() == pytest.approx(ref["logdet"], rel=1e-10)
+    _close(gp.alpha, ref["alpha"], 1e-6, 1e-8 * np.abs(ref["alpha"]).max(), "alpha")
+    mu, s2 = gp.predict_f(xs)
+    mu_o, s2_o = G.predict_f(SPEC, x, ref, xs)
+    _close(mu, mu_o, 1e-6, 1e-8, "mu")
+    _close(s2, s2_o, 1e-5, 1e-9, "sigma2")
+    return gp, ref
+
+
+@pytest.mark.parametrize("n,sup,la_min", [
+    (2900, "512,1024,2048", 256),    # 2048 + 512 + 256 + a ragged 128-column block, look-ahead everywhere
+    (2900, "512,1024,2048", 100000), # the same widths, serial order (no look-ahead)
+    (4100, "600,1500,3000", 256),    # 2048, 1024, 512, 512, then the plain NB = 256 tail
+    (3333, "0,1024,0", 256),         # only 1024-wide super-panels; n not a multiple of 64
+    (1600, "512,0,0", 256),          # 512-wide only
+])
+def test_every_width_and_transition_vs_oracle(monkeypatch, n, sup, la_min):
+    ctx = _ctx(monkeypatch, GPMI_SUPER=sup, GPMI_LOOKAHEAD_MIN=la_min)
+    _check(ctx, n, 300)
+
+
+def test_substitution_fallback_matches_the_inverse_path(monkeypatch):
+    """GPMI_SUPER_INV=0: rows below a super-panel by NB-block substitution (the form nugget-regularised matrices use)."""
+    a = _ctx(monkeypatch, GPMI_SUPER="512,1024,2048", GPMI_LOOKAHEAD_MIN=256, GPMI_SUPER_INV=0)
+    gp_a, _ = _check(a, 3000, 64)
+    b = _ctx(monkeypatch, GPMI_SUPER="512,1024,2048", GPMI_LOOKAHEAD_MIN=256, GPMI_SUPER_INV=1)
+    gp_b, _ = _check(b, 3000, 64)
+    assert gp_a.mll == pytest.approx(gp_b.mll, rel=1e-12)
+
+
+def test_vector_noise_and_the_refined_substitution_for_tiny_noise(monkeypatch):
+    ctx = _ctx(monkeypatch, GPMI_SUPER="512,1024,2048", GPMI_LOOKAHEAD_MIN=256)
+    _check(ctx, 2700, 100, noise_vec=True)
+    # sigma^2 = e^-14 < 1e-5 k(x,x): refine_solves, i.e. no explicit super-block inverse (api.hip fit_t)
+    x, y, _ = G.synthetic_inputs(2300, 4, p=4)
+    gp = g.GP(x, y, g.MeanZero(), g.from_spec(SPEC), -7.0, ctx=ctx)
+    ref = G.update_mll(SPEC, x, y, -7.0)
+    assert gp.mll == pytest.approx(ref["mll"], rel=1e-7)
+
+
+@pytest.mark.parametrize("pivot", [700, 1301, 2600])
+def test_failing_pivot_inside_a_super_block_on_the_side_stream(monkeypatch, pivot):
+    """dpotrf's info (src/GP.jl:110): the first non-positive pivot, 1-based — here inside the first super-block (main
+    stream), inside the second (factored on the side stream under the first K = 1024 update) and inside the third."""
+    ctx = _ctx(monkeypatch, GPMI_SUPER="0,1024,0", GPMI_LOOKAHEAD_MIN=256)
+    n = 3300
+    x = np.arange(n, dtype=np.float64)[None, :]
+    x[0, pivot - 1] = x[0, 40]  # a duplicated point: with no noise the pivot of the second copy is exactly <= 0
+    y = np.random.default_rng(1).standard_normal(n)
+    with pytest.raises(g.PosDefException) as ei:
+        g.GP(x, y, g.MeanZero(), g.SEIso(-3.0, 0.0), -400.0, ctx=ctx)
+    assert ei.value.info == pivot
+    gp = g.GP(x, y, g.MeanZero(), g.SEIso(-3.0, 0.0), -1.0, ctx=ctx)  # the context is still usable afterwards
+    assert np.isfinite(gp.mll)
+
+
+def test_gradient_and_loo_through_the_two_level_whitening(monkeypatch):
+    ctx = _ctx(monkeypatch, GPMI_SUPER="512,1024,2048", GPMI_LOOKAHEAD_MIN=256, GPMI_WHITEN_SUPER=512)
+    x, y, _ = G.synthetic_inputs(1900, 4, p=4)
+    ln = math.log(0.15)
+    gp = g.GP(x, y, g.MeanZero(), g.from_spec(SPEC), ln, ctx=ctx)
+    ref = G.update_mll(SPEC, x, y, ln)
+    gp.update_dmll()
+    d_o = G.update_dmll(SPEC, x, y, ln, fit=ref)["dmll"]
+    _close(gp.dmll, d_o, 1e-7, 1e-8 * np.abs(d_o).max(), "dmll")
+    mu, s2 = gp.predict_LOO()
+    mu_o, s2_o = G.predict_loo(ref, y)
+    _close(s2, s2_o, 1e-7, 1e-12, "loo variance")
+    _close(mu, mu_o, 1e-7, 1e-9, "loo mean")
+
+
+def test_fp32_two_level_vs_fp64_oracle(monkeypatch):
+    ctx = _ctx(monkeypatch, GPMI_SUPER="512,1024,2048", GPMI_LOOKAHEAD_MIN=256)
+    x, y, xs = G.synthetic_inputs(3100, 4, p=50)
+    gp = g.GP(x.astype(np.float32), y, g.MeanZero(), g.from_spec(SPEC), math.log(0.15), dtype=np.float32, ctx=ctx)
+    ref = G.update_mll(SPEC, x, y, math.log(0.15))
+    assert gp.mll == pytest.approx(ref["mll"], rel=1e-2)
+    mu, s2 = gp.predict_f(xs.astype(np.float32))
+    mu_o, s2_o = G.predict_f(SPEC, x, ref, xs)
+    _close(mu, mu_o, 1e-2, 1e-3, "mu fp32")
+    _close(s2, s2_o, 1e-2, 1e-3, "sigma2 fp32")
