@@ -250,7 +250,20 @@ static int fit_t(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int
     // logNoise = -8 the mll error is -0.46 without it, -4e-6 with it, LAPACK's own +0.04).  The usual case does not pay.
     const bool refine = min_nugget < 1e-5 * c->h_prog->kdiag || c->refine_default;
     c->refine_solves = refine;
-    const int rc_chol = cholesky_lower<T>(c, A, ld, (T*)gp->linv, (T*)gp->invdiag, npad, 1, c->d_info);
+    // the super-block inverses the factorisation builds are kept for predict_f / the gradient / predict_LOO (chol.h SuperStore)
+    SuperStore<T> store;
+    gp->sup_parts.clear();
+    {
+        const int64_t w0 = super_width(c, npad);
+        if (w0 > NB && !refine && c->super_inverse) {
+            const int rc_s = grow(c, &gp->supinv, &gp->supinv_cap, npad * w0 * (int64_t)sizeof(T));
+            if (rc_s) return rc_s;
+            store.buf = (T*)gp->supinv;
+            store.cap = npad * w0;
+            store.parts = &gp->sup_parts;
+        }
+    }
+    const int rc_chol = cholesky_lower<T>(c, A, ld, (T*)gp->linv, (T*)gp->invdiag, npad, 1, c->d_info, store.buf ? &store : nullptr);
     c->refine_solves = c->refine_default;
     if (rc_chol) return rc_chol;
 
@@ -281,6 +294,15 @@ static int fit_t(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int
 }
 
 // gradient of the mll with respect to the kernel hyper-parameters and log-noise (update_dmll!, GPE.jl:298-324)
+// the column ranges of the factor that still have their explicit super-block inverse from the last fit (chol.h)
+template <typename T>
+static std::vector<WhitenSeg<T>> whiten_segments(const gpmi_gp* gp) {
+    std::vector<WhitenSeg<T>> v;
+    if (gp->ctx->whiten_by_super_inverse)
+        for (const auto& p : gp->sup_parts) v.push_back(WhitenSeg<T>{p.ks, p.ks + p.w, (const T*)gp->supinv + p.off});
+    return v;
+}
+
 template <typename T>
 static int grad_t(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, double* dkern_out, double* dnoise_out) {
     gpmi_ctx* c = gp->ctx;
@@ -313,7 +335,8 @@ static int grad_t(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, do
         // rows of L^-T: the whiten sequence applied to an identity (in G2, consumed); row i is zero left of column i,
         // so block k only has to process rows < kend
         launch_set_identity<T>(c, G2, ld, npad);
-        whiten_rows_inv<T>(c, A, ld, (const T*)gp->linv256, npad, G2, ld, G1, ld, [](int64_t kend) { return kend; });
+        const auto segs = whiten_segments<T>(gp);
+        whiten_rows_inv<T>(c, A, ld, (const T*)gp->linv256, npad, G2, ld, G1, ld, [](int64_t kend) { return kend; }, &segs);
         // K^-1 = L^-T L^-1 = G1 G1'  (lower tiles; K loop starts at the tile's first row)
         launch_gemm_shape<T>(c, G2, ld, G1, ld, G1, ld, npad, npad, npad, TileShape{0, 0, 1, 0, 1, 0}, nullptr,
                              GEMM_OVERWRITE | GEMM_KSTART_ROW);
@@ -341,7 +364,8 @@ static int inv_diag_t(gpmi_gp* gp, void* out) {
     T* G1 = (T*)gp->g1;
     T* G2 = (T*)gp->g2;
     launch_set_identity<T>(c, G2, ld, npad);
-    whiten_rows_inv<T>(c, (const T*)gp->A, ld, (const T*)gp->linv256, npad, G2, ld, G1, ld, [](int64_t kend) { return kend; });
+    const auto segs = whiten_segments<T>(gp);
+    whiten_rows_inv<T>(c, (const T*)gp->A, ld, (const T*)gp->linv256, npad, G2, ld, G1, ld, [](int64_t kend) { return kend; }, &segs);
     // row i of G1 is written from the first column of its own NB-block on (zero left of that in exact arithmetic)
     launch_row_sumsq<T>(c, G1, ld, n, npad, NB, G2);  // G2 is free again: result vector
     GPMI_HIP(c, hipMemcpyAsync(out, G2, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, c->stream));
@@ -391,7 +415,8 @@ static int predict_t(gpmi_gp* gp, const gpmi_kernel* k, int64_t P, const void* x
         launch_cov<T>(c, xp, P, (const T*)gp->x, n, d, R, ld, P, npad, 0, 0.0, nullptr);
         launch_row_gemv<T>(c, R, ld, P, n, (const T*)gp->alpha, d_mean, d_mu);  // mu = mx + Kfx' alpha, GP.jl:26
         // Lck = whiten!(Kff, Kfx), GP.jl:27
-        whiten_rows_inv<T>(c, A, ld, (const T*)gp->linv256, npad, R, ld, V, ld, [P](int64_t) { return P; });
+        const auto segs = whiten_segments<T>(gp);
+        whiten_rows_inv<T>(c, A, ld, (const T*)gp->linv256, npad, R, ld, V, ld, [P](int64_t) { return P; }, &segs);
         if (!full_cov) launch_row_var<T>(c, V, ld, P, npad, kdiag, d_var);
     }
     GPMI_HIP(c, hipMemcpyAsync(mu_out, d_mu, (size_t)P * sizeof(T), hipMemcpyDeviceToHost, c->stream));
@@ -529,6 +554,7 @@ int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
         c->super_min[0] = a; c->super_min[1] = b; c->super_min[2] = d;
     }
     if (const char* e = getenv("GPMI_SUPER_INV")) c->super_inverse = atoi(e) != 0;
+    if (const char* e = getenv("GPMI_WHITEN_INV")) c->whiten_by_super_inverse = atoi(e) != 0;
     if (const char* e = getenv("GPMI_WHITEN_SUPER")) c->whiten_super = std::max<long long>(NB, atoll(e) / NB * NB);
     if (const char* e = getenv("GPMI_REFINE")) c->refine_default = atoi(e) != 0;
     c->refine_solves = c->refine_default;
@@ -607,7 +633,7 @@ void gpmi_gp_destroy(gpmi_gp* gp) {
         hipSetDevice(gp->ctx->device);
         hipStreamSynchronize(gp->ctx->stream);
     }
-    void* ptrs[] = {gp->x, gp->A, gp->ymu, gp->alpha, gp->invdiag, gp->linv, gp->linv256, gp->noise, gp->rows, gp->xp, gp->small,
+    void* ptrs[] = {gp->x, gp->A, gp->ymu, gp->alpha, gp->invdiag, gp->linv, gp->linv256, gp->noise, gp->rows, gp->xp, gp->small, gp->supinv,
                     gp->g1, gp->g2, gp->gpart};
     for (void* p : ptrs)
         if (p) hipFree(p);

@@ -49,36 +49,59 @@ inline hipEvent_t la_event(gpmi_ctx* c) {
     return c->la_events[i];
 }
 
-// The same whitening through the explicit NB x NB inverses, out of place: V <- R L^-T with one product per NB columns,
-// in two levels like cholesky_lower: blocks are grouped into super-blocks of WS = 1024 columns; inside a super-block
-// the solve is left-looking (block b first receives the products of the super-block's earlier blocks, K = 256 b), and the
-// columns beyond it get ONE update with K = WS when it is complete — the same number of launches as the one-level form, with
-// the bulk of the flops at the K = 1024 rate of gemm_nt_kernel:
-//   R[:, k0:k1] -= V[:, ks:k0] * A[k0:k1, ks:k0]' ;  V[:, k0:k1] = R[:, k0:k1] * Linv_k'        (k0 in the super-block [ks, ke))
-//   R[:, ke:npad] -= V[:, ks:ke] * A[ke:npad, ks:ke]'
-// (R is consumed).  Out of place because the two 128-column tiles of a block read each other's input columns.
+// A column range of the factor whose diagonal block has a stored explicit inverse (lw != nullptr: w x w, leading dimension
+// w, kept from the factorisation's super-panel, cholesky_lower) or not (solved through the NB x NB inverses).
+template <typename T>
+struct WhitenSeg {
+    int64_t ks, ke;
+    const T* lw;
+};
+
+// The same whitening through explicit inverses, out of place: V <- R L^-T, in two levels like cholesky_lower.
+//   * a segment with a stored super-block inverse is TWO launches: V[:, ks:ke] = R[:, ks:ke] * LW' (the K loop of a column
+//     tile ends at its last column: LW is lower triangular), then R[:, ke:npad] -= V[:, ks:ke] * A[ke:npad, ks:ke]'  (K = w);
+//   * elsewhere NB-blocks are grouped into super-blocks of up to WS = 1024 columns; inside one the solve is left-looking
+//     (block b first receives the products of the super-block's earlier blocks, K = 256 b), and the columns beyond it get
+//     ONE update with K = WS when it is complete:
+//       R[:, k0:k1] -= V[:, ks:k0] * A[k0:k1, ks:k0]' ;  V[:, k0:k1] = R[:, k0:k1] * Linv_k'      (k0 in the super-block [ks, ke))
+//       R[:, ke:npad] -= V[:, ks:ke] * A[ke:npad, ks:ke]'
+// (R is consumed).  Out of place because the column tiles of a block read each other's input columns.
 // rows_upto(kend) gives the number of leading rows that can be non-zero up to column kend (identity right-hand sides);
-// a super-block works on rows_upto(its last column) rows throughout, so that V holds zeros — not stale data — wherever
-// the K = WS product reads it.
+// a segment works on rows_upto(its last column) rows throughout, so that V holds zeros — not stale data — wherever
+// the K = w product reads it.  `segs` = nullptr: no stored inverses (one plain range).
 // (A look-ahead of the next block's solve on the side stream, as in cholesky_lower, bought 1.6 ms per predict while the
 //  solve was a 49 us launch of 128 x 128 tiles; with 128 x 64 tiles it is 28 us and the look-ahead measured neutral: removed.)
 template <typename T, typename F>
 inline void whiten_rows_inv(gpmi_ctx* c, const T* A, int64_t ld, const T* linv256, int64_t npad, T* R, int64_t ldr, T* V,
-                            int64_t ldv, F rows_upto) {
+                            int64_t ldv, F rows_upto, const std::vector<WhitenSeg<T>>* segs = nullptr) {
     const TileShape rect{0, 0, 0, 0, 1, 0};
     const int64_t WS = std::max<int64_t>(NB, c->whiten_super);
-    for (int64_t ks = 0; ks < npad; ks += WS) {
-        const int64_t ke = std::min<int64_t>(ks + WS, npad);
-        const int64_t Mr = rows_upto(ke);
-        for (int64_t k0 = ks; k0 < ke; k0 += NB) {
-            const int64_t nbk = std::min<int64_t>(NB, ke - k0);
-            if (k0 > ks)
-                launch_gemm_nt<T>(c, R + k0, ldr, V + ks, ldv, A + k0 * ld + ks, ld, Mr, nbk, k0 - ks, 0, nullptr);
-            launch_gemm_shape<T>(c, V + k0, ldv, R + k0, ldr, linv256 + (k0 / NB) * NB * NB, NB, Mr, nbk, nbk, rect, nullptr,
-                                 GEMM_OVERWRITE);
+    auto plain_range = [&](int64_t r0, int64_t r1) {
+        for (int64_t ks = r0; ks < r1; ks += WS) {
+            const int64_t ke = std::min<int64_t>(ks + WS, r1);
+            const int64_t Mr = rows_upto(ke);
+            for (int64_t k0 = ks; k0 < ke; k0 += NB) {
+                const int64_t nbk = std::min<int64_t>(NB, ke - k0);
+                if (k0 > ks)
+                    launch_gemm_nt<T>(c, R + k0, ldr, V + ks, ldv, A + k0 * ld + ks, ld, Mr, nbk, k0 - ks, 0, nullptr);
+                launch_gemm_shape<T>(c, V + k0, ldv, R + k0, ldr, linv256 + (k0 / NB) * NB * NB, NB, Mr, nbk, nbk, rect, nullptr,
+                                     GEMM_OVERWRITE);
+            }
+            if (ke < npad) launch_gemm_nt<T>(c, R + ke, ldr, V + ks, ldv, A + ke * ld + ks, ld, Mr, npad - ke, ke - ks, 0, nullptr);
         }
-        if (ke < npad) launch_gemm_nt<T>(c, R + ke, ldr, V + ks, ldv, A + ke * ld + ks, ld, Mr, npad - ke, ke - ks, 0, nullptr);
-    }
+    };
+    int64_t pos = 0;
+    if (segs)
+        for (const auto& sg : *segs) {
+            if (!sg.lw || sg.ks < pos) continue;
+            if (sg.ks > pos) plain_range(pos, sg.ks);
+            const int64_t w = sg.ke - sg.ks, Mr = rows_upto(sg.ke);
+            launch_gemm_shape<T>(c, V + sg.ks, ldv, R + sg.ks, ldr, sg.lw, w, Mr, w, w, rect, nullptr, GEMM_OVERWRITE | GEMM_KEND_COL);
+            if (sg.ke < npad)
+                launch_gemm_nt<T>(c, R + sg.ke, ldr, V + sg.ks, ldv, A + sg.ke * ld + sg.ks, ld, Mr, npad - sg.ke, w, 0, nullptr);
+            pos = sg.ke;
+        }
+    if (pos < npad) plain_range(pos, npad);
 }
 
 template <typename T>
@@ -185,11 +208,12 @@ inline void factor_diag_block(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag
 //             (both operands K-contiguous) this takes the transposes along:  U' = A^-T C' ,  X = -B^-1 (U')' ,  X' = -U' B^-T.
 // A dozen tiny launches (2 x 2 to 4 x 4 tiles): on the side stream they ride under the trailing update.
 template <typename T>
-inline void build_super_inverse(gpmi_ctx* c, const T* A, int64_t ld, const T* linv64, int64_t k, int64_t w, const int* d_info) {
-    T* LW = (T*)c->sup_lw;
+inline void build_super_inverse(gpmi_ctx* c, const T* A, int64_t ld, const T* linv64, int64_t k, int64_t w, T* LW, int64_t wld,
+                                const int* d_info) {
+    // LW: w x w with leading dimension wld (the context's scratch, or the caller's store so that it survives the
+    // factorisation); its transpose always lives in the scratch LWT with the same leading dimension
     T* LWT = (T*)c->sup_lwt;
     T* UT = (T*)c->sup_ut;
-    const int64_t wld = c->sup_wld;
     const TileShape rect{0, 0, 0, 0, 1, 0};
     launch_linv256<T>(c, A + k * ld + k, ld, linv64 + (k / IB) * IB * IB, (T*)c->sup_l256, w, d_info);
     launch_place_inv_blocks<T>(c, (const T*)c->sup_l256, LW, LWT, wld, (int)(w / NB));
@@ -210,12 +234,12 @@ inline void build_super_inverse(gpmi_ctx* c, const T* A, int64_t ld, const T* li
 //   otherwise left-looking by NB columns through the stored 64 x 64 inverses (the form that carries the refinement step).
 template <typename T>
 inline void rows_below_super(gpmi_ctx* c, T* A, int64_t ld, const T* linv, int64_t ks, int64_t ke, int64_t Mtot, const int* d_info,
-                             bool by_inverse) {
+                             const T* LW, int64_t wld) {
     if (Mtot <= ke) return;
     const int64_t M = Mtot - ke, w = ke - ks;
-    if (by_inverse) {
+    if (LW) {
         T* S = (T*)c->sup_s;
-        launch_gemm_shape<T>(c, S, w, A + ke * ld + ks, ld, (const T*)c->sup_lw, c->sup_wld, M, w, w, TileShape{0, 0, 0, 0, 1, 0}, d_info,
+        launch_gemm_shape<T>(c, S, w, A + ke * ld + ks, ld, LW, wld, M, w, w, TileShape{0, 0, 0, 0, 1, 0}, d_info,
                              GEMM_OVERWRITE | GEMM_KEND_COL | GEMM_AUX);
         (void)hipMemcpy2DAsync(A + ke * ld + ks, (size_t)ld * sizeof(T), S, (size_t)w * sizeof(T), (size_t)w * sizeof(T), (size_t)M,
                                hipMemcpyDeviceToDevice, c->stream);
@@ -243,11 +267,23 @@ inline int super_scratch(gpmi_ctx* c, int64_t wmax, int64_t mrows) {
     return GPMI_OK;
 }
 
+// Where cholesky_lower keeps the super-block inverses it builds, so that later whitening (predict_f, the gradient's
+// L^-T, predict_LOO) can use them: `buf` holds the w x w inverses back to back (leading dimension w each), `parts` their
+// column ranges.  Without a store (or when it is full) the inverse of the current super-panel lives in the context's scratch.
 template <typename T>
-inline int cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, int64_t npad, int64_t extra, int* d_info) {
+struct SuperStore {
+    T* buf = nullptr;
+    int64_t cap = 0;  // elements
+    std::vector<SuperPart>* parts = nullptr;
+};
+
+template <typename T>
+inline int cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, int64_t npad, int64_t extra, int* d_info,
+                          SuperStore<T>* store = nullptr) {
     const int64_t Mtot = npad + extra;
     const bool can_look = c->lookahead_slots > 0 && c->side_stream && npad > 4 * NB;
     hipStream_t main_s = c->stream, side = c->side_stream;
+    if (store && store->parts) store->parts->clear();
 
     // the inverse path serves super-panels of NB * 2^s > NB columns; factorisations that carry the refinement step
     // (nugget-regularised matrices) keep the substitution through the 64 x 64 inverses
@@ -258,28 +294,48 @@ inline int cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, in
         if (rc) return rc;
     }
     auto by_inverse = [&](int64_t w) { return inv_ok && w > NB && (w & (w - 1)) == 0; };  // NB * 2^s only
+    // the inverse of the super-panel at k: in the store when there is room (recorded), else in the scratch
+    int64_t used = 0;
+    auto place = [&](int64_t k, int64_t w, int64_t* wld) -> T* {
+        if (store && store->buf && used + w * w <= store->cap) {
+            T* p = store->buf + used;
+            if (store->parts) store->parts->push_back(SuperPart{k, w, used});
+            used += w * w;
+            *wld = w;
+            return p;
+        }
+        *wld = c->sup_wld;
+        return (T*)c->sup_lw;
+    };
 
     int64_t ks = 0, ke = std::min<int64_t>(w0, npad);
+    const T* LW = nullptr;  // inverse of the diagonal block of the current super-panel [ks, ke), or null
+    int64_t wld = 0;
     factor_diag_block<T>(c, A, ld, linv, invdiag, 0, ke, d_info);
-    if (by_inverse(ke) && Mtot > ke) build_super_inverse<T>(c, A, ld, linv, 0, ke, d_info);
+    if (by_inverse(ke) && Mtot > ke) {
+        T* p = place(0, ke, &wld);
+        build_super_inverse<T>(c, A, ld, linv, 0, ke, p, wld, d_info);
+        LW = p;
+    }
     for (;;) {
-        rows_below_super<T>(c, A, ld, linv, ks, ke, Mtot, d_info, by_inverse(ke - ks));
+        rows_below_super<T>(c, A, ld, linv, ks, ke, Mtot, d_info, LW, wld);
         if (ke >= npad) break;
         const int64_t ke2 = std::min<int64_t>(ke + super_width(c, npad - ke), npad);
         const int64_t K = ke - ks, w2 = ke2 - ke;
+        const bool inv2 = by_inverse(w2) && Mtot > ke2;
+        int64_t wld2 = 0;
+        T* LW2 = inv2 ? place(ke, w2, &wld2) : nullptr;
         // The side stream's chain takes ~0.4 ms per 256 columns beside the update (contended CUs): look ahead only while
         // the update is longer.  Update length in units of a 128 x 128 x 256 tile product:
         const double ntile = 0.5 * (double)(npad - ke2) * (double)(npad - ke2) / (GEMM_BM * GEMM_BN) * (double)K / NB;
         if (!can_look || ntile < (double)c->lookahead_min_tiles * (double)((w2 + NB - 1) / NB)) {
             launch_gemm_nt<T>(c, A + ke * ld + ke, ld, A + ke * ld + ks, ld, A + ke * ld + ks, ld, Mtot - ke, npad - ke, K, 1, d_info);
             factor_diag_block<T>(c, A, ld, linv, invdiag, ke, w2, d_info);
-            if (by_inverse(w2) && Mtot > ke2) build_super_inverse<T>(c, A, ld, linv, ke, w2, d_info);
+            if (inv2) build_super_inverse<T>(c, A, ld, linv, ke, w2, LW2, wld2, d_info);
         } else {
             // The next diagonal block's own tiles go FIRST.  A 256-wide block (6 workgroups of 128 x 64 tiles) fits the
             // reserved slots and rides on the side stream, as in round 1.  Wider blocks go on the main stream at full speed
-            // (one under-filled round: <= 272 workgroups, ~0.2 ms) instead of trickling through 8 slots.
-            // (profiles/r02_twolevel_critical_path.txt: the first version launched them on the side stream and they ended
-            // only when the update did; so did rows256 — 512 registers, a whole CU — which the side stream never uses now.)
+            // (one under-filled round: <= 272 workgroups, ~0.2 ms) instead of trickling through the reserved slots.
             const bool tiles_on_side = w2 <= NB;
             if (!tiles_on_side)
                 launch_gemm_shape<T>(c, A + ke * ld + ke, ld, A + ke * ld + ks, ld, A + ke * ld + ks, ld, w2, w2, K,
@@ -289,12 +345,12 @@ inline int cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, in
             (void)hipStreamWaitEvent(side, eb, 0);
             {
                 StreamScope sc(c, side, c->num_cus);  // the block's factorisation and its inverse: small launches
-                c->beside_update = true;  // only kernels that fit a half-free CU (<= 256 registers)
+                c->beside_update = true;  // no launch larger than the reserved slots, no whole-CU kernels (common.h side_cap)
                 if (tiles_on_side)
                     launch_gemm_shape<T>(c, A + ke * ld + ke, ld, A + ke * ld + ks, ld, A + ke * ld + ks, ld, w2, w2, K,
                                          TileShape{0, 0, 1, 0, 1, 0}, d_info, GEMM_AUX);
                 factor_diag_block<T>(c, A, ld, linv, invdiag, ke, w2, d_info);
-                if (by_inverse(w2) && Mtot > ke2) build_super_inverse<T>(c, A, ld, linv, ke, w2, d_info);
+                if (inv2) build_super_inverse<T>(c, A, ld, linv, ke, w2, LW2, wld2, d_info);
                 c->beside_update = false;
             }
             hipEvent_t ec = la_event(c);
@@ -309,6 +365,8 @@ inline int cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, in
         }
         ks = ke;
         ke = ke2;
+        LW = LW2;
+        wld = wld2;
     }
     return GPMI_OK;
 }

@@ -65,6 +65,12 @@ struct ProfRec {
 
 }  // namespace gpmi
 
+namespace gpmi {
+struct SuperPart {
+    int64_t ks, w, off;  // columns [ks, ks + w), offset (elements) of the w x w inverse in the store
+};
+}  // namespace gpmi
+
 struct gpmi_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -104,6 +110,7 @@ struct gpmi_ctx {
     void* sup_s = nullptr;   int64_t sup_s_cap = 0;
     int64_t sup_wld = 0;
     int super_inverse = 1;               // rows below a super-panel through its explicit inverse (GPMI_SUPER_INV=0: NB-block substitution)
+    int whiten_by_super_inverse = 1;     // predict / gradient whitening through the stored super-block inverses (GPMI_WHITEN_INV=0: NB blocks)
     int64_t whiten_super = 1024;         // super-block width of whiten_rows_inv (GPMI_WHITEN_SUPER; 256 = one level)
     int gemm_reserve = 0;
     bool beside_update = false;          // launches made now run in the reserved slots beside the persistent update: no whole-CU kernels
@@ -144,6 +151,9 @@ struct gpmi_gp {
     void* g2 = nullptr;      // gradient path: (K + noise)^-1, lower triangle (npad x ld)
     double* gpart = nullptr; // gradient path: per-block partial sums
     int64_t gpart_cap = 0;
+    void* supinv = nullptr;  // explicit inverses of the diagonal super-blocks of the last factorisation, back to back (chol.h SuperStore)
+    int64_t supinv_cap = 0;
+    std::vector<gpmi::SuperPart> sup_parts;  // their column ranges
     void* linv256 = nullptr; // explicit inverses of the NB x NB diagonal blocks, ceil(npad / NB) x NB x NB (linv256_kernel)
     void* linv = nullptr;    // inverses of the 64 x 64 diagonal blocks, (npad / 64) x 64 x 64 (every later solve is a GEMM)
     double* noise = nullptr; // per-point nugget (heteroscedastic) or nullptr

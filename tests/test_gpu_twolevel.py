@@ -118,3 +118,13 @@ def test_fp32_two_level_vs_fp64_oracle(monkeypatch):
     mu_o, s2_o = G.predict_f(SPEC, x, ref, xs)
     _close(mu, mu_o, 1e-2, 1e-3, "mu fp32")
     _close(s2, s2_o, 1e-2, 1e-3, "sigma2 fp32")
+
+
+def test_whitening_through_nb_blocks_matches_the_stored_super_inverses(monkeypatch):
+    """GPMI_WHITEN_INV=0: predict_f whitens through the 256-block inverses although the fit kept its super-block inverses."""
+    a = _ctx(monkeypatch, GPMI_SUPER="512,1024,2048", GPMI_LOOKAHEAD_MIN=256, GPMI_WHITEN_INV=0)
+    gp_a, _ = _check(a, 3000, 200)
+    b = _ctx(monkeypatch, GPMI_SUPER="512,1024,2048", GPMI_LOOKAHEAD_MIN=256, GPMI_WHITEN_INV=1)
+    gp_b, _ = _check(b, 3000, 200)
+    xs = G.synthetic_inputs(3000, 4, p=200)[2]
+    np.testing.assert_allclose(gp_a.predict_f(xs)[1], gp_b.predict_f(xs)[1], rtol=1e-9, atol=1e-12)
