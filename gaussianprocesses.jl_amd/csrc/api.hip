@@ -504,6 +504,34 @@ static int solve_t(gpmi_gp* gp, int64_t nrhs, void* b_inout, bool backward) {
 // =============================================================================================
 // C ABI
 // =============================================================================================
+// ---- two-level sharded factorisation building blocks (gpmi_dev_super_*) ----
+template <typename T>
+static int super_factor_t(gpmi_ctx* c, T* blk, int64_t ld, int64_t w, T* linv, T* invdiag, T* lw, int64_t pivot_base) {
+    int rc;  // scratch of build_super_inverse: the transposed inverse, the packed 256-inverses, one product buffer
+    if ((rc = grow(c, &c->sup_lwt, &c->sup_lwt_cap, w * w * (int64_t)sizeof(T)))) return rc;
+    if ((rc = grow(c, &c->sup_l256, &c->sup_l256_cap, w * NB * (int64_t)sizeof(T)))) return rc;
+    if ((rc = grow(c, &c->sup_ut, &c->sup_ut_cap, std::max<int64_t>(1, (w / 2) * (w / 2)) * (int64_t)sizeof(T)))) return rc;
+    // factor_diag_block / build_super_inverse address the block as (k, k) of a matrix and the inverses by global index:
+    // shift the bases so that k = pivot_base lands on the caller's buffers (nothing outside them is dereferenced)
+    const int64_t k = pivot_base;
+    T* Av = blk - (k * ld + k);
+    T* linv_v = linv - (k / IB) * IB * IB;
+    T* invd_v = invdiag - k;
+    factor_diag_block<T>(c, Av, ld, linv_v, invd_v, k, w, c->d_info);
+    build_super_inverse<T>(c, Av, ld, linv_v, k, w, lw, w, c->d_info);
+    return GPMI_OK;
+}
+template <typename T>
+static int super_rows_t(gpmi_ctx* c, T* X, int64_t ldx, int64_t M, int64_t w, const T* lw) {
+    int rc;
+    if ((rc = grow(c, &c->sup_s, &c->sup_s_cap, M * w * (int64_t)sizeof(T)))) return rc;
+    T* S = (T*)c->sup_s;
+    launch_gemm_shape<T>(c, S, w, X, ldx, lw, w, M, w, w, TileShape{0, 0, 0, 0, 1, 0}, c->d_info, GEMM_OVERWRITE | GEMM_KEND_COL | GEMM_AUX);
+    GPMI_HIP(c, hipMemcpy2DAsync(X, (size_t)ldx * sizeof(T), S, (size_t)w * sizeof(T), (size_t)w * sizeof(T), (size_t)M, hipMemcpyDeviceToDevice,
+                                 c->stream));
+    return GPMI_OK;
+}
+
 extern "C" {
 
 const char* gpmi_version(void) { return "gpmi 0.1 (gfx950)"; }
@@ -518,7 +546,7 @@ int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
     if (dev < 0 || dev >= count) return GPMI_EARG;
     gpmi_ctx* c = new gpmi_ctx();
     c->device = dev;
-    if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+    if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc(&c->d_prog, sizeof(DevProgram)) != hipSuccess ||
         hipHostMalloc(&c->h_prog, sizeof(DevProgram)) != hipSuccess || hipMalloc(&c->d_info, sizeof(int)) != hipSuccess ||
         hipMalloc(&c->d_scal, 8 * sizeof(double)) != hipSuccess ||
@@ -527,9 +555,11 @@ int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
         hipMemset(c->d_queue, 0, (64 + 4 * 1024) * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&c->d_queue_side, 64 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(c->d_queue_side, 0, 64 * sizeof(unsigned long long)) != hipSuccess) {
+        c->stream = c->own_stream;
         gpmi_ctx_destroy(c);
         return GPMI_EDEVICE;
     }
+    c->stream = c->own_stream;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
     // look-ahead Cholesky: a high-priority side stream for the next panel's serial chain, and how many of the chip's
@@ -585,7 +615,7 @@ void gpmi_ctx_destroy(gpmi_ctx* c) {
     if (c->h_scal) hipHostFree(c->h_scal);
     if (c->d_queue) hipFree(c->d_queue);
     if (c->d_queue_side) hipFree(c->d_queue_side);
-    if (c->stream) hipStreamDestroy(c->stream);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }
 
@@ -910,19 +940,92 @@ int gpmi_dev_rows_solve(gpmi_ctx* c, int dtype, void* X_dev, int64_t ldx, int64_
     return GPMI_OK;
 }
 
-int gpmi_dev_update(gpmi_ctx* c, int dtype, void* C_dev, int64_t ldc, const void* A_dev, int64_t lda, const void* B_dev,
-                    int64_t ldb, int64_t M, int64_t N, int64_t K, int mode, int g0, int G, int nstair_tiles) {
-    if (!c || !C_dev || !A_dev || !B_dev || K <= 0 || K % IB || mode < 0 || mode > 2 || (mode == 2 && G <= 0)) return GPMI_EARG;
+int gpmi_dev_update_blocks(gpmi_ctx* c, int dtype, void* C_dev, int64_t ldc, const void* A_dev, int64_t lda, const void* B_dev,
+                           int64_t ldb, int64_t M, int64_t N, int64_t K, int mode, int g0, int G, int nstair_tiles, int tpb, int flags) {
+    if (!c || !C_dev || !A_dev || !B_dev || K <= 0 || K % IB || mode < 0 || mode > 2 || (mode == 2 && (G <= 0 || tpb <= 0))) {
+        if (c) c->err = "gpmi_dev_update: bad argument";
+        return GPMI_EARG;
+    }
     if (M <= 0 || N <= 0) return GPMI_OK;
     GPMI_HIP(c, hipSetDevice(c->device));
-    TileShape sh{0, 0, mode, g0, G, nstair_tiles};
+    TileShape sh{0, 0, mode, g0, G, nstair_tiles, tpb > 0 ? tpb : 2};
+    const int gflags = (flags & 1) ? GEMM_OVERWRITE : 0;
+    // a side section is pending (gpmi_dev_side_end): this main-stream update leaves its slots free
+    if (c->side_pending && !c->beside_update) c->gemm_reserve = c->lookahead_slots;
     if (dtype == 64)
-        launch_gemm_shape<double>(c, (double*)C_dev, ldc, (const double*)A_dev, lda, (const double*)B_dev, ldb, M, N, K, sh, c->d_info);
+        launch_gemm_shape<double>(c, (double*)C_dev, ldc, (const double*)A_dev, lda, (const double*)B_dev, ldb, M, N, K, sh, c->d_info, gflags);
     else
-        launch_gemm_shape<float>(c, (float*)C_dev, ldc, (const float*)A_dev, lda, (const float*)B_dev, ldb, M, N, K, sh, c->d_info);
+        launch_gemm_shape<float>(c, (float*)C_dev, ldc, (const float*)A_dev, lda, (const float*)B_dev, ldb, M, N, K, sh, c->d_info, gflags);
+    c->gemm_reserve = 0;
     return GPMI_OK;
 }
+int gpmi_dev_update(gpmi_ctx* c, int dtype, void* C_dev, int64_t ldc, const void* A_dev, int64_t lda, const void* B_dev,
+                    int64_t ldb, int64_t M, int64_t N, int64_t K, int mode, int g0, int G, int nstair_tiles) {
+    return gpmi_dev_update_blocks(c, dtype, C_dev, ldc, A_dev, lda, B_dev, ldb, M, N, K, mode, g0, G, nstair_tiles, 2, 0);
+}
 
+int gpmi_dev_super_factor(gpmi_ctx* c, int dtype, void* blk_dev, int64_t ld, int64_t w, void* linv_dev, void* invdiag_dev,
+                          void* lw_dev, int64_t pivot_base) {
+    if (!c || !blk_dev || !linv_dev || !invdiag_dev || !lw_dev || w < NB || w % NB || (w / NB & (w / NB - 1)) || pivot_base % IB) {
+        if (c) c->err = "gpmi_dev_super_factor: the block width must be 256 * 2^s, the pivot base a multiple of 64";
+        return GPMI_EARG;
+    }
+    GPMI_HIP(c, hipSetDevice(c->device));
+    return dtype == 64 ? super_factor_t<double>(c, (double*)blk_dev, ld, w, (double*)linv_dev, (double*)invdiag_dev, (double*)lw_dev, pivot_base)
+                       : super_factor_t<float>(c, (float*)blk_dev, ld, w, (float*)linv_dev, (float*)invdiag_dev, (float*)lw_dev, pivot_base);
+}
+int gpmi_dev_super_rows(gpmi_ctx* c, int dtype, void* X_dev, int64_t ldx, int64_t M, int64_t w, const void* lw_dev) {
+    if (!c || !X_dev || !lw_dev || w <= 0 || w % IB) {
+        if (c) c->err = "gpmi_dev_super_rows: bad argument";
+        return GPMI_EARG;
+    }
+    if (M <= 0) return GPMI_OK;
+    GPMI_HIP(c, hipSetDevice(c->device));
+    return dtype == 64 ? super_rows_t<double>(c, (double*)X_dev, ldx, M, w, (const double*)lw_dev)
+                       : super_rows_t<float>(c, (float*)X_dev, ldx, M, w, (const float*)lw_dev);
+}
+int gpmi_dev_side_begin(gpmi_ctx* c) {
+    if (!c) return GPMI_EARG;
+    if (!c->side_stream || c->lookahead_slots <= 0 || c->beside_update) return GPMI_OK;  // no look-ahead: the section runs in line
+    GPMI_HIP(c, hipSetDevice(c->device));
+    hipEvent_t e = la_event(c);
+    GPMI_HIP(c, hipEventRecord(e, c->stream));
+    GPMI_HIP(c, hipStreamWaitEvent(c->side_stream, e, 0));
+    c->side_saved_stream = c->stream;
+    c->stream = c->side_stream;
+    c->beside_update = true;
+    return GPMI_OK;
+}
+int gpmi_dev_side_end(gpmi_ctx* c) {
+    if (!c) return GPMI_EARG;
+    if (!c->beside_update) return GPMI_OK;
+    GPMI_HIP(c, hipSetDevice(c->device));
+    c->side_event = la_event(c);
+    GPMI_HIP(c, hipEventRecord(c->side_event, c->stream));
+    c->stream = c->side_saved_stream;
+    c->beside_update = false;
+    c->side_pending = true;
+    return GPMI_OK;
+}
+int gpmi_dev_side_join(gpmi_ctx* c) {
+    if (!c) return GPMI_EARG;
+    if (!c->side_pending) return GPMI_OK;
+    GPMI_HIP(c, hipSetDevice(c->device));
+    GPMI_HIP(c, hipStreamWaitEvent(c->stream, c->side_event, 0));
+    c->side_pending = false;
+    return GPMI_OK;
+}
+int gpmi_ctx_set_stream(gpmi_ctx* c, void* hip_stream) {
+    if (!c) return GPMI_EARG;
+    if (c->beside_update || c->side_pending) {
+        c->err = "gpmi_ctx_set_stream: a side section is open";
+        return GPMI_EARG;
+    }
+    GPMI_HIP(c, hipSetDevice(c->device));
+    GPMI_HIP(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return GPMI_OK;
+}
 int gpmi_dev_bsolve_block(gpmi_ctx* c, int dtype, const void* Lrows_dev, int64_t ld, int64_t c0, int64_t nb,
                           const void* linv_dev, void* z_dev, void* alpha_dev) {
     if (!c || !Lrows_dev || !linv_dev || !z_dev || !alpha_dev || nb <= 0 || nb % IB) return GPMI_EARG;
@@ -976,7 +1079,10 @@ int gpmi_dev_logdiag_sum(gpmi_ctx* c, int dtype, const void* A_dev, int64_t ld, 
 int gpmi_dev_info(gpmi_ctx* c, int reset, int64_t* info_out) {
     if (!c) return GPMI_EARG;
     GPMI_HIP(c, hipSetDevice(c->device));
-    if (reset) GPMI_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
+    if (reset) {
+        GPMI_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
+        if (!c->beside_update && !c->side_pending) la_reset(c);  // a new factorisation: the cross-stream events are free again
+    }
     if (info_out) {
         int h = 0;
         GPMI_HIP(c, hipMemcpyAsync(&h, c->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));

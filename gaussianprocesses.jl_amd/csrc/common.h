@@ -113,6 +113,10 @@ struct gpmi_ctx {
     int whiten_by_super_inverse = 1;     // predict / gradient whitening through the stored super-block inverses (GPMI_WHITEN_INV=0: NB blocks)
     int64_t whiten_super = 1024;         // super-block width of whiten_rows_inv (GPMI_WHITEN_SUPER; 256 = one level)
     int gemm_reserve = 0;
+    hipStream_t own_stream = nullptr;    // the stream created with the context (stream may be switched to a caller's, gpmi_ctx_set_stream)
+    hipStream_t side_saved_stream = nullptr;  // gpmi_dev_side_begin / _end / _join (look-ahead driven by the caller's step loop)
+    hipEvent_t side_event = nullptr;
+    bool side_pending = false;
     bool beside_update = false;          // launches made now run in the reserved slots beside the persistent update: no whole-CU kernels
     std::vector<hipEvent_t> la_events;
     size_t la_next = 0;   // cross-stream dependencies, reused by every factorisation

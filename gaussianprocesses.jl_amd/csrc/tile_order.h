@@ -7,9 +7,10 @@
 //     mode 0 (rectangle)   cmax = ntn - 1
 //     mode 1 (lower)       cmax = ti + g0               (C is a trailing square, single GPU; g0 > 0: the block
 //                                                       starts g0 tile-rows below the square's top)
-//     mode 2 (staircase)   cmax = 2*(g0 + (ti>>1)*G) + (ti&1) for ti < nstair, ntn - 1 beyond
-//                          (row-block-cyclic shard: local 256-row block i is global block g0 + i*G;
-//                           two 128-row tiles per block; rows past the staircase are carried rows)
+//     mode 2 (staircase)   cmax = tpb*(g0 + (ti/tpb)*G) + ti%tpb for ti < nstair, ntn - 1 beyond
+//                          (row-block-cyclic shard: local block i — tpb 128-row tiles, 2 for the 256-row blocks of round
+//                           1, 4 / 8 / 16 for the super-panel blocks — is global block g0 + i*G; rows past the staircase
+//                           are carried rows)
 //     mode 3 (lower, half-width column tiles: 128 x 64 output tiles)   cmax = 2*(ti + g0) + 1
 // Order: strips of GROUP tile-rows.  Modes 0/1: column-major inside a strip, so GROUP consecutive
 // tiles share one B panel and the strip's GROUP A panels stay hot.  Mode 2: row-major inside a strip.
@@ -28,13 +29,15 @@ constexpr int TILE_GROUP = 8;
 
 struct TileShape {
     int ntm, ntn, mode;
-    int g0, G, nstair;  // mode 2 only
+    int g0, G, nstair;  // mode 2 only (g0 also: row offset of the lower modes)
+    int tpb = 2;        // mode 2: 128-row tiles per distributed block
 };
 
 GPMI_HD int stair_cmax(const TileShape& s, int ti) {
     int c = s.ntn - 1;
     if (ti < s.nstair) {
-        const int64_t v = 2 * ((int64_t)s.g0 + (int64_t)(ti >> 1) * s.G) + (ti & 1);
+        const int tpb = s.tpb > 0 ? s.tpb : 2;
+        const int64_t v = (int64_t)tpb * ((int64_t)s.g0 + (int64_t)(ti / tpb) * s.G) + (ti % tpb);
         if (v < c) c = (int)v;
     }
     return c;

@@ -26,7 +26,8 @@ SYMBOLS = [
     "gpmi_profile_enable", "gpmi_profile_get", "gpmi_profile_get_bytes", "gpmi_mfma_peak", "gpmi_bench_gemm",
     "gpmi_dev_set_kernel", "gpmi_dev_assemble", "gpmi_dev_cov_rows", "gpmi_dev_potrf_block", "gpmi_dev_rows_solve",
     "gpmi_dev_update", "gpmi_dev_bsolve_block", "gpmi_dev_row_gemv", "gpmi_dev_row_var", "gpmi_dev_logdiag_sum",
-    "gpmi_dev_info", "gpmi_dev_sync",
+    "gpmi_dev_info", "gpmi_dev_sync", "gpmi_dev_update_blocks", "gpmi_dev_super_factor", "gpmi_dev_super_rows",
+    "gpmi_dev_side_begin", "gpmi_dev_side_end", "gpmi_dev_side_join", "gpmi_ctx_set_stream",
 ]
 
 
@@ -114,6 +115,13 @@ def load():
     lib.gpmi_dev_logdiag_sum.argtypes = [vp, ci, vp, i64, i64, i64, C.POINTER(dbl)]
     lib.gpmi_dev_info.argtypes = [vp, ci, C.POINTER(i64)]
     lib.gpmi_dev_sync.argtypes = [vp]
+    lib.gpmi_dev_update_blocks.argtypes = [vp, ci, vp, i64, vp, i64, vp, i64, i64, i64, i64, ci, ci, ci, ci, ci, ci]
+    lib.gpmi_dev_super_factor.argtypes = [vp, ci, vp, i64, i64, vp, vp, vp, i64]
+    lib.gpmi_dev_super_rows.argtypes = [vp, ci, vp, i64, i64, i64, vp]
+    lib.gpmi_dev_side_begin.argtypes = [vp]
+    lib.gpmi_dev_side_end.argtypes = [vp]
+    lib.gpmi_dev_side_join.argtypes = [vp]
+    lib.gpmi_ctx_set_stream.argtypes = [vp, vp]
     _lib = lib
     return lib
 

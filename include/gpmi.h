@@ -227,6 +227,30 @@ int gpmi_dev_rows_solve(gpmi_ctx*, int dtype, void* X_dev, int64_t ldx, int64_t 
  * column), rows past nstair_tiles*128 are carried rows and get every column.                   */
 int gpmi_dev_update(gpmi_ctx*, int dtype, void* C_dev, int64_t ldc, const void* A_dev, int64_t lda, const void* B_dev,
                     int64_t ldb, int64_t M, int64_t N, int64_t K, int mode, int g0, int G, int nstair_tiles);
+/* the same with distributed blocks of tiles_per_block * 128 rows (the super-panel blocks of the two-level sharded
+ * factorisation: 256 * 2^s rows); flags: 1 = C = A B' instead of C -= A B'                                        */
+int gpmi_dev_update_blocks(gpmi_ctx*, int dtype, void* C_dev, int64_t ldc, const void* A_dev, int64_t lda, const void* B_dev,
+                           int64_t ldb, int64_t M, int64_t N, int64_t K, int mode, int g0, int G, int nstair_tiles,
+                           int tiles_per_block, int flags);
+/* Two-level sharded factorisation (gpmi355x/dist.py, DESIGN.md "Row-block sharding"): the w x w diagonal block at
+ * blk_dev (w = 256 * 2^s) is factored in place (dpotrf semantics, pivot indices offset by pivot_base), linv_dev gets
+ * its w/64 64 x 64 inverses, invdiag_dev 1 / L_ii, and lw_dev (w x w, leading dimension w) the explicit inverse of the
+ * whole block — what the owner broadcasts, so that every rank solves its rows with ONE product.                       */
+int gpmi_dev_super_factor(gpmi_ctx*, int dtype, void* blk_dev, int64_t ld, int64_t w, void* linv_dev, void* invdiag_dev,
+                          void* lw_dev, int64_t pivot_base);
+/* X[M x w] <- X * LW'  (LW lower triangular: the K loop of a column tile ends at its last column), through the
+ * context's scratch: the panel solve of the rows below a super-panel, and whiten! of predict rows (GP.jl:27)        */
+int gpmi_dev_super_rows(gpmi_ctx*, int dtype, void* X_dev, int64_t ldx, int64_t M, int64_t w, const void* lw_dev);
+/* Look-ahead for the caller's step loop.  Between side_begin and side_end every gpmi_dev_* launch goes to the context's
+ * side stream (ordered after everything enqueued before side_begin) and is capped to the workgroup slots the next
+ * gpmi_dev_update* on the main stream leaves free; side_join makes the main stream wait for that work.  Typical step:
+ * update(the next diagonal block's own tiles); side_begin; super_factor(next block); side_end; update(the rest); side_join. */
+int gpmi_dev_side_begin(gpmi_ctx*);
+int gpmi_dev_side_end(gpmi_ctx*);
+int gpmi_dev_side_join(gpmi_ctx*);
+/* Run the context's launches on the caller's stream (a hipStream_t, e.g. torch's current stream, so that RCCL
+ * collectives and gpmi kernels are ordered without host synchronisation); NULL restores the context's own stream.   */
+int gpmi_ctx_set_stream(gpmi_ctx*, void* hip_stream);
 /* backward substitution through ONE block-row [c0, c0+nb) of the factor held at Lrows_dev:
  * alpha[c0..) = L_cc^-T z[c0..)  (through the block's linv);  z[0..c0) -= L[c-rows, 0..c0)' alpha_c  */
 int gpmi_dev_bsolve_block(gpmi_ctx*, int dtype, const void* Lrows_dev, int64_t ld, int64_t c0, int64_t nb,

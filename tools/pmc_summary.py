@@ -10,20 +10,27 @@ import sys
 root = sys.argv[1]
 KERNEL = "gemm_nt_kernel<double, 0, 4>"
 out = {"kernel": KERNEL, "command": "python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary", "units": "bytes per launch"}
-for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+for counter, folder in (("FETCH_SIZE", "FETCH_SIZE"), ("WRITE_SIZE", "WRITE_SIZE"), ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES"),
+                        ("SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES"), ("GRBM_GUI_ACTIVE", "GRBM_GUI_ACTIVE")):
     vals = {}
-    for f in glob.glob(os.path.join(root, counter, "**", "*counter_collection.csv"), recursive=True):
+    for f in glob.glob(os.path.join(root, folder, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             if KERNEL in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
                 key = row.get("Dispatch_Id")
                 vals[key] = vals.get(key, 0.0) + float(row["Counter_Value"])
     n = len(vals)
     out[counter + "_launches"] = n
-    out[counter + "_KiB_avg"] = (sum(vals.values()) / n) if n else None
+    out[counter + ("_KiB_avg" if counter.endswith("_SIZE") else "_avg")] = (sum(vals.values()) / n) if n else None
 if out.get("FETCH_SIZE_KiB_avg") and out.get("WRITE_SIZE_KiB_avg"):
     rd = 2.0 * out["FETCH_SIZE_KiB_avg"] * 1024.0
     wr = out["WRITE_SIZE_KiB_avg"] * 1024.0
     out["read_bytes_corrected"] = rd
     out["write_bytes"] = wr
     out["traffic_bytes_per_launch"] = rd + wr
+if out.get("SQ_VALU_MFMA_BUSY_CYCLES_avg") and out.get("GRBM_GUI_ACTIVE_avg"):
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs; the chip has 256 CUs x 4 SIMDs whose MFMA pipes each count busy cycles
+    cycles = out["GRBM_GUI_ACTIVE_avg"] / 8.0
+    out["mfma_busy_frac"] = out["SQ_VALU_MFMA_BUSY_CYCLES_avg"] / (1024.0 * cycles)
+    if out.get("SQ_INSTS_MFMA_avg"):
+        out["mfma_busy_cycles_per_instruction"] = out["SQ_VALU_MFMA_BUSY_CYCLES_avg"] / out["SQ_INSTS_MFMA_avg"]
 print(json.dumps(out))
