@@ -344,7 +344,7 @@ def main():
         if world == 1:
             par = "single GPU" + (" (sharded code path, one rank)" if sharded else "")
         elif sharded:
-            par = f"ONE fit row-block sharded over {world} GPUs (block-cyclic 256-row blocks, RCCL panel exchange per step)"
+            par = f"ONE fit row-block sharded over {world} GPUs (block-cyclic super-panel blocks of 1024 rows, RCCL inverse broadcast + panel all-gather per block)"
         else:
             par = f"{world} independent fits, one per GPU (no data-path collective)"
         out = {

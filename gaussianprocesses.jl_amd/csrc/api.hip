@@ -256,10 +256,10 @@ static int fit_t(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int
     {
         const int64_t w0 = super_width(c, npad);
         if (w0 > NB && !refine && c->super_inverse) {
-            const int rc_s = grow(c, &gp->supinv, &gp->supinv_cap, npad * w0 * (int64_t)sizeof(T));
+            const int rc_s = grow(c, &gp->supinv, &gp->supinv_cap, npad * (w0 + IB) * (int64_t)sizeof(T));
             if (rc_s) return rc_s;
             store.buf = (T*)gp->supinv;
-            store.cap = npad * w0;
+            store.cap = npad * (w0 + IB);
             store.parts = &gp->sup_parts;
         }
     }
@@ -1015,7 +1015,7 @@ int gpmi_dev_side_join(gpmi_ctx* c) {
     c->side_pending = false;
     return GPMI_OK;
 }
-int gpmi_ctx_set_stream(gpmi_ctx* c, void* hip_stream) {
+int gpmi_ctx_set_stream(gpmi_ctx* c, void* hip_stream, int use_caller_stream) {
     if (!c) return GPMI_EARG;
     if (c->beside_update || c->side_pending) {
         c->err = "gpmi_ctx_set_stream: a side section is open";
@@ -1023,7 +1023,7 @@ int gpmi_ctx_set_stream(gpmi_ctx* c, void* hip_stream) {
     }
     GPMI_HIP(c, hipSetDevice(c->device));
     GPMI_HIP(c, hipStreamSynchronize(c->stream));
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    c->stream = use_caller_stream ? (hipStream_t)hip_stream : c->own_stream;  // NULL is a stream too (the default one)
     return GPMI_OK;
 }
 int gpmi_dev_bsolve_block(gpmi_ctx* c, int dtype, const void* Lrows_dev, int64_t ld, int64_t c0, int64_t nb,

@@ -50,7 +50,7 @@ inline hipEvent_t la_event(gpmi_ctx* c) {
 }
 
 // A column range of the factor whose diagonal block has a stored explicit inverse (lw != nullptr: w x w, leading dimension
-// w, kept from the factorisation's super-panel, cholesky_lower) or not (solved through the NB x NB inverses).
+// w + 64, kept from the factorisation's super-panel, cholesky_lower) or not (solved through the NB x NB inverses).
 template <typename T>
 struct WhitenSeg {
     int64_t ks, ke;
@@ -96,7 +96,7 @@ inline void whiten_rows_inv(gpmi_ctx* c, const T* A, int64_t ld, const T* linv25
             if (!sg.lw || sg.ks < pos) continue;
             if (sg.ks > pos) plain_range(pos, sg.ks);
             const int64_t w = sg.ke - sg.ks, Mr = rows_upto(sg.ke);
-            launch_gemm_shape<T>(c, V + sg.ks, ldv, R + sg.ks, ldr, sg.lw, w, Mr, w, w, rect, nullptr, GEMM_OVERWRITE | GEMM_KEND_COL);
+            launch_gemm_shape<T>(c, V + sg.ks, ldv, R + sg.ks, ldr, sg.lw, w + IB, Mr, w, w, rect, nullptr, GEMM_OVERWRITE | GEMM_KEND_COL);
             if (sg.ke < npad)
                 launch_gemm_nt<T>(c, R + sg.ke, ldr, V + sg.ks, ldv, A + sg.ke * ld + sg.ks, ld, Mr, npad - sg.ke, w, 0, nullptr);
             pos = sg.ke;
@@ -258,12 +258,12 @@ inline void rows_below_super(gpmi_ctx* c, T* A, int64_t ld, const T* linv, int64
 template <typename T>
 inline int super_scratch(gpmi_ctx* c, int64_t wmax, int64_t mrows) {
     int rc;
-    if ((rc = grow(c, &c->sup_lw, &c->sup_lw_cap, wmax * wmax * (int64_t)sizeof(T)))) return rc;
-    if ((rc = grow(c, &c->sup_lwt, &c->sup_lwt_cap, wmax * wmax * (int64_t)sizeof(T)))) return rc;
+    if ((rc = grow(c, &c->sup_lw, &c->sup_lw_cap, wmax * (wmax + IB) * (int64_t)sizeof(T)))) return rc;
+    if ((rc = grow(c, &c->sup_lwt, &c->sup_lwt_cap, wmax * (wmax + IB) * (int64_t)sizeof(T)))) return rc;
     if ((rc = grow(c, &c->sup_l256, &c->sup_l256_cap, wmax * NB * (int64_t)sizeof(T)))) return rc;
     if ((rc = grow(c, &c->sup_ut, &c->sup_ut_cap, (wmax / 2) * (wmax / 2) * (int64_t)sizeof(T)))) return rc;
     if ((rc = grow(c, &c->sup_s, &c->sup_s_cap, mrows * wmax * (int64_t)sizeof(T)))) return rc;
-    c->sup_wld = wmax;
+    c->sup_wld = wmax + IB;
     return GPMI_OK;
 }
 
@@ -297,11 +297,12 @@ inline int cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, in
     // the inverse of the super-panel at k: in the store when there is room (recorded), else in the scratch
     int64_t used = 0;
     auto place = [&](int64_t k, int64_t w, int64_t* wld) -> T* {
-        if (store && store->buf && used + w * w <= store->cap) {
+        const int64_t wl = w + IB;  // never a 4 KiB-multiple row stride (HBM channel conflicts on the B operand)
+        if (store && store->buf && used + w * wl <= store->cap) {
             T* p = store->buf + used;
             if (store->parts) store->parts->push_back(SuperPart{k, w, used});
-            used += w * w;
-            *wld = w;
+            used += w * wl;
+            *wld = wl;
             return p;
         }
         *wld = c->sup_wld;

@@ -440,6 +440,7 @@ static void launch_persistent_ni(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, i
     shape.ntm = (int)((M + GEMM_BM - 1) / GEMM_BM);
     shape.ntn = (int)((N + BN - 1) / BN);
     if (NI == 2 && shape.mode == 1) shape.mode = 3;  // the same lower region in 128 x 64 tiles
+    stair_finalize(shape);
     const int64_t tiles_per = tile_count(shape);
     const int64_t ntiles = tiles_per * (batch ? batch->count : 1);
     if (ntiles <= 0) return;
@@ -500,6 +501,7 @@ static double shape_entries(int64_t M, int64_t N, const TileShape& s) {
     TileShape t = s;  // staircase: count whole tiles
     t.ntm = (int)((M + GEMM_BM - 1) / GEMM_BM);
     t.ntn = (int)((N + GEMM_BN - 1) / GEMM_BN);
+    stair_finalize(t);
     return (double)tile_count(t) * GEMM_BM * GEMM_BN;
 }
 

@@ -13,7 +13,7 @@
 //                           are carried rows)
 //     mode 3 (lower, half-width column tiles: 128 x 64 output tiles)   cmax = 2*(ti + g0) + 1
 // Order: strips of GROUP tile-rows.  Modes 0/1: column-major inside a strip, so GROUP consecutive
-// tiles share one B panel and the strip's GROUP A panels stay hot.  Mode 2: row-major inside a strip.
+// tiles share one B panel and the strip's GROUP A panels stay hot (all modes).
 #pragma once
 #include <stdint.h>
 
@@ -31,6 +31,7 @@ struct TileShape {
     int ntm, ntn, mode;
     int g0, G, nstair;  // mode 2 only (g0 also: row offset of the lower modes)
     int tpb = 2;        // mode 2: 128-row tiles per distributed block
+    int rc = -1;        // mode 2: first tile-row that keeps every column (stair_finalize; rows from there on are 'capped')
 };
 
 GPMI_HD int stair_cmax(const TileShape& s, int ti) {
@@ -58,15 +59,38 @@ GPMI_HD int64_t lower_tiles_before_row(int r, const TileShape& s) {
     return rt * (rt + 1) / 2 + off * rt + ((int64_t)r - rt) * s.ntn;
 }
 
+// mode 2: the staircase's cmax is non-decreasing, so the rows that keep all ntn columns (diagonal at or past the last
+// column, and the carried rows past the staircase) are a suffix [rc, ntm).  Set once on the host.
+GPMI_HD void stair_finalize(TileShape& s) {
+    if (s.mode != 2) return;
+    int rc = s.nstair < s.ntm ? s.nstair : s.ntm;
+    // first staircase row whose cmax reaches ntn - 1 (bisection: cmax is monotone)
+    int lo = 0, hi = rc;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const int tpb = s.tpb > 0 ? s.tpb : 2;
+        const int64_t v = (int64_t)tpb * ((int64_t)s.g0 + (int64_t)(mid / tpb) * s.G) + (mid % tpb);
+        if (v >= s.ntn - 1) hi = mid;
+        else lo = mid + 1;
+    }
+    s.rc = lo;
+}
+// mode 2: number of tiles in tile-rows < r, closed form (rows < rc: block b = r / tpb contributes
+// tpb^2 (g0 + b G) + tpb (tpb + 1) / 2 tiles, the partial block j = r % tpb rows of tpb (g0 + b G) + jj + 1)
+GPMI_HD int64_t stair_tiles_before_row(int r, const TileShape& s) {
+    const int64_t tpb = s.tpb > 0 ? s.tpb : 2;
+    const int64_t ru = r < s.rc ? r : s.rc;
+    const int64_t b = ru / tpb, j = ru % tpb;
+    const int64_t u = tpb * tpb * (b * s.g0 + (int64_t)s.G * b * (b - 1) / 2) + b * tpb * (tpb + 1) / 2 +
+                      j * tpb * ((int64_t)s.g0 + b * s.G) + j * (j + 1) / 2;
+    return u + (r > s.rc ? (int64_t)(r - s.rc) * s.ntn : 0);
+}
+
 GPMI_HD int64_t strip_count(int st, const TileShape& s) {
     const int r0 = st * TILE_GROUP;
     const int h = (s.ntm - r0 < TILE_GROUP) ? (s.ntm - r0) : TILE_GROUP;
     if (s.mode == 0) return (int64_t)h * s.ntn;
-    if (s.mode == 2) {
-        int64_t c = 0;
-        for (int i = 0; i < h; ++i) c += stair_cmax(s, r0 + i) + 1;
-        return c;
-    }
+    if (s.mode == 2) return stair_tiles_before_row(r0 + h, s) - stair_tiles_before_row(r0, s);
     const int off = s.g0;
     if (s.mode == 3) return lower_tiles_before_row(r0 + h, s) - lower_tiles_before_row(r0, s);
     const int nfull = (r0 + off + 1 < s.ntn) ? (r0 + off + 1) : s.ntn;
@@ -96,22 +120,18 @@ GPMI_HD void tile_decode(int64_t t, const TileShape& s, int* ti, int* tj) {
         return;
     }
     int st = 0;
-    if (s.mode == 1 || s.mode == 3) {  // closed-form prefix count + bisection over the strips (782 tile rows at N = 100 000)
+    {  // closed-form prefix count + bisection over the strips (782 tile rows at N = 100 000); a linear scan over the strips
+       // cost the staircase mode 15 % of the K = 1024 update (profiles/r02_sharded_world1.log)
         const int ns = (s.ntm + TILE_GROUP - 1) / TILE_GROUP;
         int lo = 0, hi = ns - 1;
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
-            if (lower_tiles_before_row(mid * TILE_GROUP, s) <= t) lo = mid;
+            const int64_t before = s.mode == 2 ? stair_tiles_before_row(mid * TILE_GROUP, s) : lower_tiles_before_row(mid * TILE_GROUP, s);
+            if (before <= t) lo = mid;
             else hi = mid - 1;
         }
         st = lo;
-        t -= lower_tiles_before_row(st * TILE_GROUP, s);
-    } else {
-        for (;; ++st) {
-            const int64_t c = strip_count(st, s);
-            if (t < c) break;
-            t -= c;
-        }
+        t -= s.mode == 2 ? stair_tiles_before_row(st * TILE_GROUP, s) : lower_tiles_before_row(st * TILE_GROUP, s);
     }
     const int r0 = st * TILE_GROUP;
     const int h = (s.ntm - r0 < TILE_GROUP) ? (s.ntm - r0) : TILE_GROUP;
@@ -121,14 +141,25 @@ GPMI_HD void tile_decode(int64_t t, const TileShape& s, int* ti, int* tj) {
         return;
     }
     if (s.mode == 2) {
-        for (int i = 0;; ++i) {
-            const int n = stair_cmax(s, r0 + i) + 1;
-            if (t < n) {
-                *ti = r0 + i;
-                *tj = (int)t;
+        // column-major inside the strip, like the lower modes (GROUP consecutive tiles share one B panel): the columns
+        // every row of the strip keeps first, then the staircase columns (cmax is non-decreasing down a strip)
+        const int nfull = (r0 >= s.rc ? s.ntn - 1 : stair_cmax(s, r0)) + 1;
+        if (t < (int64_t)h * nfull) {
+            *tj = (int)(t / h);
+            *ti = r0 + (int)(t % h);
+            return;
+        }
+        int64_t q = t - (int64_t)h * nfull;
+        int first = 1;  // first row of the strip that keeps column c
+        for (int c = nfull;; ++c) {
+            while (first < h && r0 + first < s.rc && stair_cmax(s, r0 + first) < c) ++first;
+            const int n = h - first;
+            if (q < n) {
+                *tj = c;
+                *ti = r0 + first + (int)q;
                 return;
             }
-            t -= n;
+            q -= n;
         }
     }
     const int off = s.g0;

@@ -121,7 +121,7 @@ def load():
     lib.gpmi_dev_side_begin.argtypes = [vp]
     lib.gpmi_dev_side_end.argtypes = [vp]
     lib.gpmi_dev_side_join.argtypes = [vp]
-    lib.gpmi_ctx_set_stream.argtypes = [vp, vp]
+    lib.gpmi_ctx_set_stream.argtypes = [vp, vp, C.c_int]
     _lib = lib
     return lib
 

@@ -2,21 +2,27 @@
 
 The factorisation behind `update_mll!` (src/GPE.jl:202-212 → make_posdef!, src/GP.jl:101-112) is the only
 coupled part of the path; `cov!` shards trivially (every rank generates its own block-rows of K from a
-replicated x).  Layout (DESIGN.md "Row-block sharding"):
+replicated x).  Layout (DESIGN.md "Row-block sharding"), round 2 — the two-level factorisation of the
+single-GPU path (csrc/chol.h) with the super-panel as the distributed block:
 
-  * the row-major lower factor is split into block-rows of NBD = 256 rows, dealt round-robin:
+  * the row-major lower factor is split into block-rows of WD = 256·2^s rows (1024 by default), dealt round-robin:
     global block b lives on rank b % G at local block b // G (block-cyclic, so the shrinking trailing
     matrix stays balanced).  In the reference's column-major upper factor these are block-COLUMNS;
-  * step k: the owner factors the diagonal block and broadcasts it (512 KB fp64); every rank solves its
-    own rows of block-column k against it; the solved panel rows are ALL-GATHERED (the one real exchange
-    step of the path: (N - k·NBD) × 256 elements per step, N²/2 elements in total per rank); every rank
-    then applies the MFMA trailing update to the rows it owns ("staircase" tile shape: a local block
-    only needs columns up to its own global diagonal);
+  * step k: the owner has factored the WD×WD diagonal block and formed its explicit inverse LW_k (gpmi_dev_super_factor);
+    LW_k is broadcast (8 MB fp64 at WD = 1024); every rank solves its own rows of block-column k with ONE product
+    X ← X·LW_kᵀ; the solved panel rows are ALL-GATHERED (the one real exchange step of the path: (N − k·WD) × WD
+    elements per step, N²/2 in total per rank, in N/WD collectives); every rank then applies ONE K = WD trailing update
+    to the rows it owns ("staircase" tile shape: a local block only needs columns up to its own global diagonal);
+  * look-ahead: the owner of block k+1 updates that diagonal block FIRST, then factors and inverts it on the context's
+    side stream UNDER its share of update k (gpmi_dev_side_begin / _end / _join), so the latency-bound chain is off the
+    critical path of every rank; libgpmi enqueues on torch's current stream, so collectives and kernels are ordered on
+    the device — no host synchronisation inside the step loop;
   * the right-hand side y − μ rides along as one extra row on every rank (forward solve for free);
-    logdet is a local sum + all-reduce; the backward solve walks the block-rows in reverse, the owner of
-    each block doing its 256 rows and broadcasting the running vector;
-  * predict: every rank whitens its share of the test points while the panels are re-gathered from the
-    stored factor; μ and σ² are gathered at the end.
+    logdet is a local sum + all-reduce; the backward solve walks the block-rows in reverse: every rank keeps the partial
+    sums of the blocks it owns, the owner of a block receives their total (an all-reduce of WD numbers), solves its block
+    and folds it into its own partial sums; α is assembled by one all-reduce at the end;
+  * predict: every rank whitens its share of the test points through the replicated LW_k while the panels are
+    re-gathered from the stored factor; μ and σ² are gathered at the end.
 
 All device arithmetic is libgpmi's HIP kernels (`gpmi_dev_*`, include/gpmi.h) on buffers this module
 allocates as torch tensors so that torch.distributed (backend "nccl" = RCCL) can move them; torch itself
@@ -27,13 +33,21 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import numpy as np
 
 from . import _lib
 
-NBD = 256  # rows per distributed block (= K of the MFMA trailing update)
 LOG2PI = math.log(2.0 * math.pi)
+
+
+def default_block(n):
+    """Rows per distributed block: the super-panel width of the two-level factorisation (GPMI_DIST_WD overrides)."""
+    e = os.environ.get("GPMI_DIST_WD")
+    if e:
+        return int(e)
+    return 1024 if n >= 16384 else (512 if n >= 4096 else 256)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -80,6 +94,11 @@ class TorchDistComm:
         self.dist.all_gather_into_tensor(out.view(-1), buf.view(-1), group=self.group)
         return [out[q, : rows_per_rank[q]] for q in range(self.world)]
 
+    def all_reduce_tensor(self, t):
+        """in-place sum over the ranks"""
+        if self._active():
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
     def all_reduce(self, value, op="sum"):
         import torch
 
@@ -100,6 +119,9 @@ class SingleComm:
     def all_gather_rows(self, send, rows_per_rank):
         return [send]
 
+    def all_reduce_tensor(self, t):
+        pass
+
     def all_reduce(self, value, op="sum"):
         return value
 
@@ -117,6 +139,7 @@ class DeviceOps:
         self.lib = _lib.load()
         self.tdtype = torch.float64 if bits == 64 else torch.float32
         self.device = torch.device("cuda", ctx.device)
+        self._on_torch_stream = False
 
     # -- memory --
     def zeros(self, shape):
@@ -125,12 +148,49 @@ class DeviceOps:
     def from_host(self, a):
         return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
 
-    # -- stream hand-over between libgpmi's stream and torch's --
+    # -- streams: inside `with ops.stream_scope():` libgpmi enqueues on torch's current stream, so torch copies, RCCL
+    #    collectives and gpmi kernels are ordered on the device and sync() / torch_sync() have nothing to do --
+    def stream_scope(self):
+        """libgpmi enqueues on torch's current stream (GPMI_DIST_STREAM=default), on a dedicated torch stream made current
+        for the scope (own), or keeps its own stream with host synchronisation around every hand-over (host, round 1's
+        scheme).  Measured at world 1, N = 50 000: 832 / 836 / 840 ms per step (profiles/r02_sharded_world1.log)."""
+        ops = self
+        torch = self.torch
+        mode = os.environ.get("GPMI_DIST_STREAM", "default")  # own | default | host (host: libgpmi's stream + host syncs, round 1)
+
+        class _Scope:
+            def __enter__(self_inner):
+                if mode == "host":
+                    return
+                if mode == "own":
+                    if getattr(ops, "_tstream", None) is None:
+                        ops._tstream = torch.cuda.Stream(device=ops.device)
+                    ops._tstream.wait_stream(torch.cuda.current_stream(ops.device))
+                    self_inner.guard = torch.cuda.stream(ops._tstream)
+                    self_inner.guard.__enter__()
+                st = torch.cuda.current_stream(ops.device)
+                ops.ctx.check(ops.lib.gpmi_ctx_set_stream(ops.ctx.h, C.c_void_p(st.cuda_stream), 1))
+                ops._on_torch_stream = True
+
+            def __exit__(self_inner, *exc):
+                if mode == "host":
+                    return False
+                ops._on_torch_stream = False
+                ops.ctx.check(ops.lib.gpmi_ctx_set_stream(ops.ctx.h, None, 0))  # waits for the stream that is left
+                if mode == "own":
+                    self_inner.guard.__exit__(*exc)
+                    torch.cuda.current_stream(ops.device).wait_stream(ops._tstream)
+                return False
+
+        return _Scope()
+
     def sync(self):  # libgpmi work finished -> torch may touch the buffers
-        self.ctx.check(self.lib.gpmi_dev_sync(self.ctx.h))
+        if not self._on_torch_stream:
+            self.ctx.check(self.lib.gpmi_dev_sync(self.ctx.h))
 
     def torch_sync(self):  # torch / RCCL work finished -> libgpmi may touch the buffers
-        self.torch.cuda.current_stream(self.device).synchronize()
+        if not self._on_torch_stream:
+            self.torch.cuda.current_stream(self.device).synchronize()
 
     @staticmethod
     def _p(t):
@@ -159,18 +219,29 @@ class DeviceOps:
         self.ctx.check(self.lib.gpmi_dev_cov_rows(self.ctx.h, self.bits, d, xa_dev.shape[0], self._p(xa_dev), xb_dev.shape[0],
                                                   self._p(xb_dev), self._p(Cview), self._ld(Cview), ncols_total))
 
-    def potrf_block(self, blk, linv, invd, pivot_base):
-        self.ctx.check(self.lib.gpmi_dev_potrf_block(self.ctx.h, self.bits, self._p(blk), self._ld(blk), blk.shape[0],
-                                                     self._p(linv), self._p(invd), pivot_base))
+    def super_factor(self, blk, linv, invd, lw, pivot_base):
+        """in-place Cholesky of the w×w diagonal block + its 64×64 inverses + 1/diag + its explicit inverse lw (w×w)"""
+        assert lw.is_contiguous() and linv.is_contiguous()
+        self.ctx.check(self.lib.gpmi_dev_super_factor(self.ctx.h, self.bits, self._p(blk), self._ld(blk), blk.shape[0],
+                                                      self._p(linv), self._p(invd), self._p(lw), pivot_base))
 
-    def rows_solve(self, X, L, linv):
-        self.ctx.check(self.lib.gpmi_dev_rows_solve(self.ctx.h, self.bits, self._p(X), self._ld(X), X.shape[0], self._p(L),
-                                                    self._ld(L), self._p(linv), L.shape[0]))
+    def super_rows(self, X, lw):
+        """X ← X·LWᵀ"""
+        self.ctx.check(self.lib.gpmi_dev_super_rows(self.ctx.h, self.bits, self._p(X), self._ld(X), X.shape[0], X.shape[1], self._p(lw)))
 
-    def update(self, Cv, Av, Bv, mode, g0=0, G=1, nstair_tiles=0):
-        self.ctx.check(self.lib.gpmi_dev_update(self.ctx.h, self.bits, self._p(Cv), self._ld(Cv), self._p(Av), self._ld(Av),
-                                                self._p(Bv), self._ld(Bv), Cv.shape[0], Cv.shape[1], Av.shape[1], mode, g0, G,
-                                                nstair_tiles))
+    def update(self, Cv, Av, Bv, mode, g0=0, G=1, nstair_tiles=0, tpb=2):
+        self.ctx.check(self.lib.gpmi_dev_update_blocks(self.ctx.h, self.bits, self._p(Cv), self._ld(Cv), self._p(Av), self._ld(Av),
+                                                       self._p(Bv), self._ld(Bv), Cv.shape[0], Cv.shape[1], Av.shape[1], mode, g0, G,
+                                                       nstair_tiles, tpb, 0))
+
+    def side_begin(self):
+        self.ctx.check(self.lib.gpmi_dev_side_begin(self.ctx.h))
+
+    def side_end(self):
+        self.ctx.check(self.lib.gpmi_dev_side_end(self.ctx.h))
+
+    def side_join(self):
+        self.ctx.check(self.lib.gpmi_dev_side_join(self.ctx.h))
 
     def bsolve_block(self, Lrows, c0, linv, z, alpha):
         self.ctx.check(self.lib.gpmi_dev_bsolve_block(self.ctx.h, self.bits, self._p(Lrows), self._ld(Lrows), c0,
@@ -196,6 +267,14 @@ class DeviceOps:
         return out.value
 
 
+class _NoScope:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
 # ------------------------------------------------------------------------------------------------
 # the sharded model object
 # ------------------------------------------------------------------------------------------------
@@ -206,7 +285,7 @@ def owned_blocks(rank, world, nblk):
 class ShardedGPE:
     """GPE whose factor is row-block sharded over the ranks of `comm` (same verbs as gpe.GPE)."""
 
-    def __init__(self, x, y, mean, kernel, logNoise=-2.0, dtype=np.float64, comm=None, ops=None, ctx=None):
+    def __init__(self, x, y, mean, kernel, logNoise=-2.0, dtype=np.float64, comm=None, ops=None, ctx=None, block=None):
         from .means import MeanZero
 
         x = np.asarray(x)
@@ -231,17 +310,26 @@ class ShardedGPE:
         self.y = y
         self.dim, self.nobs = self.x.shape
         r, G = self.comm.rank, self.comm.world
-        self.npad = (self.nobs + NBD - 1) // NBD * NBD
-        self.nblk = self.npad // NBD
+        WD = int(block) if block else default_block(self.nobs)
+        if WD < 256 or WD % 256 or (WD // 256) & (WD // 256 - 1):
+            raise _lib.ArgumentError("the distributed block must be 256 * 2^s rows")
+        self.WD = WD
+        self.tpb = WD // 128                                   # 128-row tiles per distributed block
+        self.npad = (self.nobs + WD - 1) // WD * WD
+        self.nblk = self.npad // WD
         self.own = owned_blocks(r, G, self.nblk)
         self.nown = len(self.own)
         o = self.ops
         self.x_dev = o.from_host(self.x.T)                     # n × d row-major, replicated (N·d·s bytes)
-        self.A = o.zeros((self.nown * NBD + 8, self.npad))     # owned block-rows; row nown·NBD carries y − μ
-        self.P = o.zeros((self.npad, NBD))                     # the gathered panel, global row order
-        # broadcast buffer: rows [0,256) L_kk, rows [256,320) the four 64x64 inverses (contiguous), row 320 1/diag
-        self.D = o.zeros((NBD + NBD // 4 + 1, NBD))
-        self.Dall = o.zeros((self.nblk, NBD + NBD // 4 + 1, NBD))   # every factored diagonal block, replicated
+        # never a row stride that is a multiple of 4 KiB (a power-of-two stride parks every row of a tile on the same HBM
+        # channels: 58 instead of 65 TFLOP/s on the K = 1024 update, as on the single-GPU path's ld): 64 spare columns
+        self._ldA = self._padded(self.npad)
+        self.A = o.zeros((self.nown * WD + 8, self._ldA))[:, :self.npad]   # owned block-rows; row nown·WD carries y − μ
+        self._Pfull = o.zeros((self.npad, self._padded(WD))) if G > 1 else None   # the gathered panel, global row order
+        self.P = self._Pfull[:, :WD] if G > 1 else None
+        self.LW = o.zeros((self.nblk, WD, WD))                 # explicit inverse of every diagonal block, replicated
+        self.linv = o.zeros((max(self.nown, 1), WD, 64))       # 64×64 inverses of the OWN diagonal blocks (back-substitution)
+        self.invd = o.zeros((max(self.nown, 1), WD))
         self.alpha_dev = o.zeros((self.npad,))
         self.alpha = None
         self.mll = float("nan")
@@ -250,6 +338,13 @@ class ShardedGPE:
         self.target = self.mll
 
     # ---- helpers ---------------------------------------------------------------------------------
+    def _padded(self, ncols):
+        es = 8 if self.bits == 64 else 4
+        return ncols + 64 if (ncols * es) % 4096 == 0 else ncols
+
+    def _scope(self):
+        return self.ops.stream_scope() if hasattr(self.ops, "stream_scope") else _NoScope()
+
     def _n_le(self, q, k):
         """number of blocks owned by rank q with global index <= k"""
         return (k - q) // self.comm.world + 1 if k >= q else 0
@@ -257,59 +352,84 @@ class ShardedGPE:
     def _blocks_below(self, q, k):
         return [b for b in range(q, self.nblk, self.comm.world) if b > k]
 
-    def _gather_panel(self, k):
-        """All-gather the solved rows of block-column k into self.P (global row order)."""
-        o, G = self.ops, self.comm.world
-        k0 = k * NBD
-        lstart = self._n_le(self.comm.rank, k) * NBD
-        mloc = self.nown * NBD - lstart
-        rows = [len(self._blocks_below(q, k)) * NBD for q in range(G)]
-        send = self.A[lstart:lstart + mloc, k0:k0 + NBD].contiguous()
+    def _panel_rows(self, k):
+        """The solved rows of block-column k below its diagonal block, in GLOBAL row order from row (k+1)·WD on: the B
+        operand of update k.  One rank: the local rows are already that.  Otherwise all-gather into self.P."""
+        o, G, WD = self.ops, self.comm.world, self.WD
+        k0 = k * WD
+        lstart = self._n_le(self.comm.rank, k) * WD
+        if G == 1:
+            return self.A[lstart:self.nown * WD, k0:k0 + WD]
+        mloc = self.nown * WD - lstart
+        rows = [len(self._blocks_below(q, k)) * WD for q in range(G)]
+        send = self.A[lstart:lstart + mloc, k0:k0 + WD].contiguous()
+        o.sync()
         pieces = self.comm.all_gather_rows(send, rows)
-        Pv = self.P.view(self.nblk, NBD, NBD)
+        Pv = self._Pfull.view(self.nblk, WD, self._Pfull.shape[1])[:, :, :WD]
         for q in range(G):
             bq = self._blocks_below(q, k)
             if bq:
-                Pv[bq] = pieces[q].reshape(len(bq), NBD, NBD)
+                Pv[bq] = pieces[q].reshape(len(bq), WD, WD)
         o.torch_sync()
+        return self.P[k0 + WD:]
 
     # ---- update_mll! ------------------------------------------------------------------------------
     def update_mll(self):
+        with self._scope():
+            return self._update_mll()
+
+    def _update_mll(self):
         o, comm = self.ops, self.comm
-        r, G = comm.rank, comm.world
+        r, G, WD, tpb = comm.rank, comm.world, self.WD, self.tpb
         n, npad, nblk, nown = self.nobs, self.npad, self.nblk, self.nown
         ymu = np.zeros(npad, dtype=self.npdt)
         ymu[:n] = self.y - self.mean.mean(self.x)
         self.kdiag = o.set_kernel(self.kernel, self.dim)
         o.info(reset=True)
         for i, b in enumerate(self.own):                       # cov! + nugget, own block-rows only
-            o.assemble(self.x_dev, n, self.dim, b * NBD, self.logNoise, self.A[i * NBD:(i + 1) * NBD], npad)
+            o.assemble(self.x_dev, n, self.dim, b * WD, self.logNoise, self.A[i * WD:(i + 1) * WD], npad)
         ymu_dev = o.from_host(ymu)
-        self.A[nown * NBD].copy_(ymu_dev)
+        o.sync()
+        self.A[nown * WD].copy_(ymu_dev)
         o.torch_sync()
+        if r == 0:                                             # the first diagonal block has nothing to hide behind
+            o.super_factor(self.A[0:WD, 0:WD], self.linv[0], self.invd[0], self.LW[0], 0)
         for k in range(nblk):
-            k0, owner = k * NBD, k % G
-            if r == owner:
-                lk = (k // G) * NBD
-                blk = self.A[lk:lk + NBD, k0:k0 + NBD]
-                o.potrf_block(blk, self.D[NBD:NBD + NBD // 4], self.D[NBD + NBD // 4], k0)
-                o.sync()
-                self.D[:NBD].copy_(blk)
-                o.torch_sync()
-            comm.broadcast(self.D, owner)
-            self.Dall[k].copy_(self.D)
+            k0, owner = k * WD, k % G
+            o.sync()
+            comm.broadcast(self.LW[k], owner)
             o.torch_sync()
             nle = self._n_le(r, k)
-            lstart = nle * NBD
-            mtot = nown * NBD - lstart + 1                      # owned rows below + the carried y row
-            X = self.A[lstart:lstart + mtot, k0:k0 + NBD]
-            o.rows_solve(X, self.Dall[k, :NBD], self.Dall[k, NBD:NBD + NBD // 4])
-            o.sync()
-            ncols = npad - (k0 + NBD)
-            if ncols > 0:
-                self._gather_panel(k)
+            lstart = nle * WD
+            mtot = nown * WD - lstart + 1                       # owned rows below + the carried y row
+            X = self.A[lstart:lstart + mtot, k0:k0 + WD]
+            o.super_rows(X, self.LW[k])                         # X ← X·LW_kᵀ
+            k1 = k0 + WD
+            if npad - k1 <= 0:
+                continue
+            B = self._panel_rows(k)
+            if nle < nown and self.own[nle] == k + 1:
+                # this rank owns the NEXT diagonal block: its own tiles first, then its factorisation and inverse — on the
+                # side stream under the rest of the update (look-ahead) while that update is longer than the chain beside
+                # it (~0.4 ms per 256 columns on contended CUs, as csrc/chol.h decides it), in line otherwise
+                blk = self.A[lstart:lstart + WD, k1:k1 + WD]
+                o.update(blk, X[:WD], B[:WD], 1)
+                rest_rows = mtot - WD
+                tiles = (rest_rows / 128.0) * ((npad - k1) / 256.0) * (WD / 256.0)   # in 128 x 128 x 256 tile products
+                # beside the update the chain takes ~3x its in-line time: look ahead once the update outlasts ~2/3 of that
+                look = tiles >= 1200.0 * (WD // 256)
+                if look:
+                    o.side_begin()
+                o.super_factor(blk, self.linv[nle], self.invd[nle], self.LW[k + 1], k1)
+                if look:
+                    o.side_end()
+                g0 = (self.own[nle + 1] - (k + 1)) if nle + 1 < nown else 0
+                o.update(self.A[lstart + WD:lstart + mtot, k1:], X[WD:], B, 2, g0, G, tpb * (nown - nle - 1), tpb)
+                if look:
+                    o.side_join()
+            else:
                 g0 = (self.own[nle] - (k + 1)) if nle < nown else 0
-                o.update(self.A[lstart:lstart + mtot, k0 + NBD:], X, self.P[k0 + NBD:], 2, g0, G, 2 * (nown - nle))
+                o.update(self.A[lstart:lstart + mtot, k1:], X, B, 2, g0, G, tpb * (nown - nle), tpb)
         o.sync()
         # the FIRST failing pivot wins (ranks past it have been factoring garbage), as dpotrf reports it
         mine = o.info()
@@ -317,23 +437,30 @@ class ShardedGPE:
         if info < 1e17:
             raise _lib.PosDefException(int(info))
         # logdet = 2 Σ log L_ii: local share + all-reduce
-        half = sum(o.logdiag_sum(self.A[i * NBD:(i + 1) * NBD], b * NBD) for i, b in enumerate(self.own))
+        half = sum(o.logdiag_sum(self.A[i * WD:(i + 1) * WD], b * WD) for i, b in enumerate(self.own))
         self.logdet = 2.0 * comm.all_reduce(half, "sum")
-        # backward solve L' α = z, block-rows in reverse; the owner of a block does its 256 rows
-        z = self.A[nown * NBD].clone()
+        # backward solve L' α = z, block-rows in reverse.  v = this rank's share of z − Σ_{solved blocks} L_b' α_b: rank 0
+        # starts from z (replicated: every rank carried y − μ), the others from 0; the owner of block c needs the TOTAL of
+        # its WD entries (an all-reduce of WD numbers), solves, and folds L_c' α_c into its own v
+        v = self.A[nown * WD].clone()
+        if r != 0:
+            v.zero_()
         self.alpha_dev.zero_()
         o.torch_sync()
         for c in reversed(range(nblk)):
-            c0, owner = c * NBD, c % G
-            if r == owner:
-                lc = (c // G) * NBD
-                o.bsolve_block(self.A[lc:lc + NBD], c0, self.Dall[c, NBD:NBD + NBD // 4], z, self.alpha_dev)
-                o.sync()
+            c0, owner = c * WD, c % G
             if G > 1:
-                comm.broadcast(self.alpha_dev[c0:c0 + NBD], owner)
-                if c0 > 0:
-                    comm.broadcast(z[:c0], owner)
+                seg = v[c0:c0 + WD].clone()
+                o.sync()
+                comm.all_reduce_tensor(seg)
+                if r == owner:
+                    v[c0:c0 + WD].copy_(seg)
                 o.torch_sync()
+            if r == owner:
+                lc = (c // G) * WD
+                o.bsolve_block(self.A[lc:lc + WD], c0, self.linv[c // G], v, self.alpha_dev)
+        o.sync()
+        comm.all_reduce_tensor(self.alpha_dev)                  # every block of α was written by exactly one rank
         self.alpha = self.alpha_dev[:n].cpu().numpy().astype(self.npdt)
         dot = float((ymu_dev[:n].double() * self.alpha_dev[:n].double()).sum().item())
         self.mll = -(dot + self.logdet + LOG2PI * n) / 2.0     # GPE.jl:210
@@ -346,9 +473,13 @@ class ShardedGPE:
 
     # ---- predict_f ---------------------------------------------------------------------------------
     def predict_f(self, xpred):
+        with self._scope():
+            return self._predict_f(xpred)
+
+    def _predict_f(self, xpred):
         """Posterior mean / variance (full_cov=False branch of src/GP.jl:64-79), test points split over ranks."""
         o, comm = self.ops, self.comm
-        r, G = comm.rank, comm.world
+        r, G, WD = comm.rank, comm.world, self.WD
         xp = np.asarray(xpred)
         if xp.ndim == 1:
             xp = xp[None, :]
@@ -361,7 +492,7 @@ class ShardedGPE:
         pr = hi - lo
         n, npad, nblk = self.nobs, self.npad, self.nblk
         o.set_kernel(self.kernel, self.dim)
-        R = o.zeros((max(pr, 1), npad))
+        R = o.zeros((max(pr, 1), self._ldA))[:, :npad]
         mu = o.zeros((max(pr, 1),))
         var = o.zeros((max(pr, 1),))
         if pr > 0:
@@ -371,14 +502,13 @@ class ShardedGPE:
             o.cov_rows(xs, self.x_dev, self.dim, R[:pr], npad)
             o.row_gemv(R[:pr], n, self.alpha_dev, mx, mu)
         for k in range(nblk):
-            k0 = k * NBD
+            k0 = k * WD
             if pr > 0:
-                o.rows_solve(R[:pr, k0:k0 + NBD], self.Dall[k, :NBD], self.Dall[k, NBD:NBD + NBD // 4])
-            if npad - (k0 + NBD) > 0:
-                o.sync()
-                self._gather_panel(k)                           # every rank takes part, with or without test rows
+                o.super_rows(R[:pr, k0:k0 + WD], self.LW[k])   # V_k = R_k·LW_kᵀ
+            if npad - (k0 + WD) > 0:
+                B = self._panel_rows(k)                         # every rank takes part, with or without test rows
                 if pr > 0:
-                    o.update(R[:pr, k0 + NBD:], R[:pr, k0:k0 + NBD], self.P[k0 + NBD:], 0)
+                    o.update(R[:pr, k0 + WD:], R[:pr, k0:k0 + WD], B, 0)
         if pr > 0:
             o.row_var(R[:pr], npad, self.kdiag, var)
         o.sync()

@@ -248,9 +248,10 @@ int gpmi_dev_super_rows(gpmi_ctx*, int dtype, void* X_dev, int64_t ldx, int64_t 
 int gpmi_dev_side_begin(gpmi_ctx*);
 int gpmi_dev_side_end(gpmi_ctx*);
 int gpmi_dev_side_join(gpmi_ctx*);
-/* Run the context's launches on the caller's stream (a hipStream_t, e.g. torch's current stream, so that RCCL
- * collectives and gpmi kernels are ordered without host synchronisation); NULL restores the context's own stream.   */
-int gpmi_ctx_set_stream(gpmi_ctx*, void* hip_stream);
+/* use_caller_stream != 0: run the context's launches on the caller's stream (a hipStream_t — NULL being the default
+ * stream — e.g. torch's current stream, so that RCCL collectives and gpmi kernels are ordered without host
+ * synchronisation); 0: back to the context's own stream.  Waits for the stream that is left.                       */
+int gpmi_ctx_set_stream(gpmi_ctx*, void* hip_stream, int use_caller_stream);
 /* backward substitution through ONE block-row [c0, c0+nb) of the factor held at Lrows_dev:
  * alpha[c0..) = L_cc^-T z[c0..)  (through the block's linv);  z[0..c0) -= L[c-rows, 0..c0)' alpha_c  */
 int gpmi_dev_bsolve_block(gpmi_ctx*, int dtype, const void* Lrows_dev, int64_t ld, int64_t c0, int64_t nb,

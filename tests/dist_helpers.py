@@ -83,10 +83,42 @@ class FakeOps:
             sol = np.full(X.shape, np.nan)
         X.copy_(torch.from_numpy(sol).to(self.tdtype))
 
-    def update(self, Cv, Av, Bv, mode, g0=0, G=1, nstair_tiles=0):
+    def update(self, Cv, Av, Bv, mode, g0=0, G=1, nstair_tiles=0, tpb=2):
         if self._info or Cv.shape[0] == 0 or Cv.shape[1] == 0:
             return
         Cv -= Av @ Bv[: Cv.shape[1]].T  # full rectangle: a superset of the staircase, the extra part is never read
+
+    def super_factor(self, blk, linv, invd, lw, pivot_base):
+        """gpmi_dev_super_factor: Cholesky of the diagonal block + its explicit inverse (the 64x64 inverses are not
+        needed by this stand-in: bsolve_block substitutes against the block itself)"""
+        if self._info:
+            return
+        a = blk.numpy().astype(np.float64)
+        a = np.tril(a) + np.tril(a, -1).T
+        if not np.all(np.isfinite(a)):
+            self._info = pivot_base + 1
+            return
+        L, info = sla.lapack.dpotrf(a, lower=1, clean=1)
+        if info != 0:
+            self._info = pivot_base + int(info)
+            return
+        blk.copy_(torch.from_numpy(L).to(self.tdtype))
+        invd.copy_(torch.from_numpy(1.0 / np.diag(L)).to(self.tdtype))
+        lw.copy_(torch.from_numpy(sla.solve_triangular(L, np.eye(L.shape[0]), lower=True)).to(self.tdtype))
+
+    def super_rows(self, X, lw):
+        if self._info or X.shape[0] == 0:
+            return
+        X.copy_(X @ lw.T)
+
+    def side_begin(self):
+        pass
+
+    def side_end(self):
+        pass
+
+    def side_join(self):
+        pass
 
     def bsolve_block(self, Lrows, c0, linv, z, alpha):
         nb = Lrows.shape[0]
@@ -144,6 +176,13 @@ class LocalThreadComm:
     def all_gather_rows(self, send, rows_per_rank):
         got = self._exchange(send.clone())
         return [got[q][: rows_per_rank[q]] for q in range(self.world)]
+
+    def all_reduce_tensor(self, t):
+        got = self._exchange(t.clone())
+        tot = got[0].clone()
+        for g in got[1:]:
+            tot += g
+        t.copy_(tot)
 
     def all_reduce(self, value, op="sum"):
         got = self._exchange(float(value))

@@ -1,7 +1,8 @@
 """N > 1 path on CPU: the sharded orchestration (gpmi355x.dist) under world_size-2 gloo, with the device ops
 replaced by a NumPy stand-in (tests/dist_helpers.FakeOps), checked against the oracle.  What this pins:
-block-cyclic ownership, the diagonal broadcast, the panel all-gather + scatter into global row order, the
-carried right-hand-side row, the distributed backward solve, logdet all-reduce, the split of test points in
+block-cyclic ownership, the broadcast of the diagonal block's inverse, the panel all-gather + scatter into global row
+order, the look-ahead split of the update on the owner of the next block, the carried right-hand-side row, the
+distributed backward solve (partial sums + per-block all-reduce), logdet all-reduce, the split of test points in
 predict_f and the PosDefException contract across ranks."""
 import math
 import os
@@ -58,7 +59,9 @@ def _worker(rank, world, port, n, case):
                 G.update_mll(nspec, x, y, -400.0)
             assert ei.value.info == eo.value.info == 301
             return
-        gp = gd.ShardedGPE(x, y, g.MeanConst(0.2), g.from_spec(spec), ln, comm=comm, ops=FakeOps(spec))
+        block = 512 if case == "fit512" else None  # the super-panel as the distributed block: 512 rows = 4 tiles per block
+        gp = gd.ShardedGPE(x, y, g.MeanConst(0.2), g.from_spec(spec), ln, comm=comm, ops=FakeOps(spec), block=block)
+        assert gp.WD == (block or 256)
         ref = G.update_mll(spec, x, y, ln, ("const", 0.2))
         assert abs(gp.mll - ref["mll"]) <= 1e-9 * abs(ref["mll"]), (gp.mll, ref["mll"])
         np.testing.assert_allclose(gp.alpha, ref["alpha"], rtol=1e-7, atol=1e-9)
@@ -68,7 +71,7 @@ def _worker(rank, world, port, n, case):
         np.testing.assert_allclose(mu, mu_o, rtol=1e-7, atol=1e-9)
         np.testing.assert_allclose(s2, s2_o, rtol=1e-6, atol=1e-10)
         # ownership really is split: this rank holds only its share of the factor
-        assert gp.nown == len(range(rank, gp.nblk, world)) and gp.A.shape[0] == gp.nown * 256 + 8
+        assert gp.nown == len(range(rank, gp.nblk, world)) and gp.A.shape[0] == gp.nown * gp.WD + 8
         # refit with new hyper-parameters reuses the buffers
         hyp = gp.get_params()
         gp.set_params([h + 0.05 for h in hyp])
@@ -85,6 +88,10 @@ def _worker(rank, world, port, n, case):
 @pytest.mark.parametrize("world,n", [(2, 700), (2, 1100), (3, 1300)])
 def test_sharded_fit_predict_gloo(world, n):
     mp.spawn(_worker, args=(world, _free_port(), n, "fit"), nprocs=world, join=True)
+
+
+def test_sharded_fit_predict_gloo_512_row_blocks():
+    mp.spawn(_worker, args=(2, _free_port(), 1900, "fit512"), nprocs=2, join=True)
 
 
 def test_sharded_not_posdef_gloo():

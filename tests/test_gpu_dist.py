@@ -38,16 +38,19 @@ def _check(gp, x, y, xs, ln, mspec, rtol_mll=1e-10):
     np.testing.assert_allclose(s2, s2_o, rtol=1e-6, atol=1e-10)
 
 
-@pytest.mark.parametrize("n", [300, 1000, 1793])
-def test_single_rank_device_ops(n):
+@pytest.mark.parametrize("n,block", [(300, None), (1000, None), (1793, None), (5000, None), (3000, 1024), (4500, 2048)])
+def test_single_rank_device_ops(n, block):
+    """block None: 256-row blocks below 4096 points, 512 from there (dist.default_block); the look-ahead — next diagonal
+    block updated first, factored and inverted on the side stream under the rest of the update — runs at every step."""
     x, y, xs = _problem(n)
     ln = math.log(0.1)
-    gp = gd.ShardedGPE(x, y, g.MeanConst(0.1), g.from_spec(SPEC), ln)
+    gp = gd.ShardedGPE(x, y, g.MeanConst(0.1), g.from_spec(SPEC), ln, block=block)
+    assert gp.WD == (block or (512 if n >= 4096 else 256))
     _check(gp, x, y, xs, ln, ("const", 0.1))
 
 
-@pytest.mark.parametrize("world,n", [(2, 1000), (3, 1793), (4, 2600)])
-def test_virtual_ranks_on_one_gpu(world, n):
+@pytest.mark.parametrize("world,n,block", [(2, 1000, None), (3, 1793, None), (4, 2600, None), (2, 2600, 512), (3, 4200, 1024)])
+def test_virtual_ranks_on_one_gpu(world, n, block):
     x, y, xs = _problem(n)
     ln = math.log(0.1)
     shared = LocalThreadComm.Shared(world)
@@ -56,7 +59,7 @@ def test_virtual_ranks_on_one_gpu(world, n):
     def run(rank):
         try:
             ctx = g.Context(0)  # own stream per virtual rank
-            gp = gd.ShardedGPE(x, y, g.MeanConst(0.1), g.from_spec(SPEC), ln, comm=LocalThreadComm(shared, rank), ctx=ctx)
+            gp = gd.ShardedGPE(x, y, g.MeanConst(0.1), g.from_spec(SPEC), ln, comm=LocalThreadComm(shared, rank), ctx=ctx, block=block)
             assert gp.nown == len(range(rank, gp.nblk, world))
             _check(gp, x, y, xs, ln, ("const", 0.1))
         except BaseException as e:  # noqa: BLE001

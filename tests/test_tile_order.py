@@ -12,14 +12,15 @@ SRC = r"""
 #include <utility>
 #include "tile_order.h"
 using gpmi::TileShape;
-static int check(const TileShape& s) {
+static int check(TileShape s) {
+    gpmi::stair_finalize(s);
     std::set<std::pair<int,int>> want, got;
     for (int i = 0; i < s.ntm; ++i)
         for (int j = 0; j < s.ntn; ++j) {
             bool ok = true;
             if (s.mode == 1) ok = j <= i + s.g0;
             if (s.mode == 3) ok = j <= 2 * (i + s.g0) + 1;
-            if (s.mode == 2 && i < s.nstair) ok = j <= 2 * (s.g0 + (i >> 1) * s.G) + (i & 1);
+            if (s.mode == 2 && i < s.nstair) ok = j <= s.tpb * (s.g0 + (i / s.tpb) * s.G) + (i % s.tpb);
             if (ok) want.insert({i, j});
         }
     int64_t n = gpmi::tile_count(s);
@@ -49,8 +50,27 @@ int main() {
                     int ntn = 2 * (g0 + (nblk ? (nblk - 1) * G : 0)) + 2 + 3;   // wider than the last stair
                     for (int cut = 0; cut <= 4; cut += 2) { ++cases; bad += check(TileShape{ntm, ntn - cut > 0 ? ntn - cut : 1, 2, g0, G, 2 * nblk}); }
                 }
+    // the same with 4 / 8 tiles per distributed block (the super-panel blocks of the two-level sharded factorisation)
+    for (int tpb = 4; tpb <= 8; tpb += 4)
+        for (int G = 1; G <= 3; ++G)
+            for (int g0 = 0; g0 < G + 1; ++g0)
+                for (int nblk = 0; nblk <= 5; ++nblk)
+                    for (int extra = 0; extra <= 1; ++extra) {
+                        int ntm = tpb * nblk + extra; if (ntm == 0) continue;
+                        int ntn = tpb * (g0 + (nblk ? (nblk - 1) * G : 0)) + tpb + 3;
+                        for (int cut = 0; cut <= 6; cut += 3) { ++cases; bad += check(TileShape{ntm, ntn - cut > 0 ? ntn - cut : 1, 2, g0, G, tpb * nblk, tpb}); }
+                    }
+    // staircase locality: 8 consecutive tiles at the start of an interior strip share one column
+    {
+        int a0, b0, a7, b7;
+        TileShape st2{64, 200, 2, 1, 2, 64, 8};
+        gpmi::stair_finalize(st2);
+        int64_t b2 = 0; for (int st = 0; st < 2; ++st) b2 += gpmi::strip_count(st, st2);
+        gpmi::tile_decode(b2, st2, &a0, &b0); gpmi::tile_decode(b2 + 7, st2, &a7, &b7);
+        if (!(b0 == 0 && b7 == 0 && a0 == 16 && a7 == 23)) ++bad;
+    }
     // mode 1 == mode 2 with (g0, G, nstair) = (0, 1, ntm): same tile SET
-    for (int ntm = 1; ntm <= 20; ++ntm) { ++cases; bad += gpmi::tile_count(TileShape{ntm, ntm, 1, 0, 1, 0}) != gpmi::tile_count(TileShape{ntm, ntm, 2, 0, 1, ntm}); }
+    for (int ntm = 1; ntm <= 20; ++ntm) { ++cases; TileShape m2{ntm, ntm, 2, 0, 1, ntm}; gpmi::stair_finalize(m2); bad += gpmi::tile_count(TileShape{ntm, ntm, 1, 0, 1, 0}) != gpmi::tile_count(m2); }
     // locality: 8 consecutive tiles of a full interior strip share one column (mode 1)
     int ti0, tj0, ti7, tj7;
     TileShape s{64, 64, 1, 0, 1, 0};
