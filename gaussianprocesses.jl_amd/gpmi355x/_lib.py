@@ -70,6 +70,15 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    # torch's wheel bundles its own libamdhip64: whichever HIP runtime is loaded SECOND in a process finds no GPU
+    # ("No HIP GPUs are available" from torch when libgpmi came first).  Importing torch first makes libgpmi.so resolve
+    # libamdhip64 to the one already loaded, so the sharded / packed paths (torch tensors, torch.distributed) can be used
+    # at any later point.  GPMI_NO_TORCH_PRELOAD=1 skips it for processes that never touch torch.
+    if not os.environ.get("GPMI_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(LIB_PATH)
     vp, i64, dbl = C.c_void_p, C.c_int64, C.c_double
     lib.gpmi_version.restype = C.c_char_p

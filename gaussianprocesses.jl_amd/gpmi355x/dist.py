@@ -282,10 +282,57 @@ def owned_blocks(rank, world, nblk):
     return list(range(rank, nblk, world))
 
 
+class _Stripes:
+    """The block-rows a rank owns, in stripes of `per` consecutive local blocks.  One stripe (per = None) is the plain
+    (rows × npad) matrix.  PACKED storage: stripe s only holds the columns up to the diagonal of its last
+    block — the upper triangle is never allocated, N² (1 + 1/S) / 2 elements instead of N² — and every launch over a row
+    range becomes one launch per stripe it crosses.  The carried row (y − μ) lives in the last stripe, whose width is npad."""
+
+    def __init__(self, ops, own, WD, npad, per, padded):
+        self.WD, self.npad, self.nown = WD, npad, len(own)
+        nown = self.nown
+        per = nown if (not per or per >= nown) else int(per)
+        self.items = []  # (first local block, one past the last, tensor view rows × width)
+        starts = list(range(0, nown, per)) if nown else [0]
+        for i0 in starts:
+            i1 = min(i0 + per, nown)
+            last = i1 == nown
+            width = npad if (last or per >= nown) else (own[i1 - 1] + 1) * WD
+            rows = (i1 - i0) * WD + (8 if last else 0)
+            self.items.append((i0, i1, ops.zeros((rows, padded(width)))[:, :width]))
+        self.nbytes_rows = sum(t.shape[0] * t.stride(0) for _, _, t in self.items)
+
+    def block(self, i):
+        """local block i: WD rows × (its stripe's width)"""
+        for i0, i1, t in self.items:
+            if i0 <= i < i1:
+                return t[(i - i0) * self.WD:(i - i0 + 1) * self.WD]
+        raise IndexError(i)
+
+    def carried(self):
+        i0, i1, t = self.items[-1]
+        return t[(i1 - i0) * self.WD]
+
+    def pieces(self, first_block, carried=True):
+        """(rows view, first local block, number of blocks, has the carried row) for the local blocks >= first_block"""
+        out = []
+        for i0, i1, t in self.items:
+            last = i1 == self.nown
+            b0 = max(i0, first_block)
+            nb = max(0, i1 - b0)
+            extra = 1 if (carried and last) else 0
+            if nb == 0 and not extra:
+                continue
+            r0 = (b0 - i0) * self.WD if nb else (i1 - i0) * self.WD
+            out.append((t[r0:r0 + nb * self.WD + extra], b0, nb, bool(extra)))
+        return out
+
+
 class ShardedGPE:
     """GPE whose factor is row-block sharded over the ranks of `comm` (same verbs as gpe.GPE)."""
 
-    def __init__(self, x, y, mean, kernel, logNoise=-2.0, dtype=np.float64, comm=None, ops=None, ctx=None, block=None):
+    def __init__(self, x, y, mean, kernel, logNoise=-2.0, dtype=np.float64, comm=None, ops=None, ctx=None, block=None,
+                 stripe_blocks=None):
         from .means import MeanZero
 
         x = np.asarray(x)
@@ -324,9 +371,12 @@ class ShardedGPE:
         # never a row stride that is a multiple of 4 KiB (a power-of-two stride parks every row of a tile on the same HBM
         # channels: 58 instead of 65 TFLOP/s on the K = 1024 update, as on the single-GPU path's ld): 64 spare columns
         self._ldA = self._padded(self.npad)
-        self.A = o.zeros((self.nown * WD + 8, self._ldA))[:, :self.npad]   # owned block-rows; row nown·WD carries y − μ
-        self._Pfull = o.zeros((self.npad, self._padded(WD))) if G > 1 else None   # the gathered panel, global row order
-        self.P = self._Pfull[:, :WD] if G > 1 else None
+        # owned block-rows + the carried row y − μ; stripe_blocks = k: packed storage in stripes of k blocks (_Stripes)
+        self.S = _Stripes(o, self.own, WD, self.npad, stripe_blocks, self._padded)
+        self.A = self.S.items[0][2] if len(self.S.items) == 1 else None
+        need_P = G > 1 or len(self.S.items) > 1
+        self._Pfull = o.zeros((self.npad, self._padded(WD))) if need_P else None   # the gathered panel, global row order
+        self.P = self._Pfull[:, :WD] if need_P else None
         self.LW = o.zeros((self.nblk, WD, WD))                 # explicit inverse of every diagonal block, replicated
         self.linv = o.zeros((max(self.nown, 1), WD, 64))       # 64×64 inverses of the OWN diagonal blocks (back-substitution)
         self.invd = o.zeros((max(self.nown, 1), WD))
@@ -354,15 +404,22 @@ class ShardedGPE:
 
     def _panel_rows(self, k):
         """The solved rows of block-column k below its diagonal block, in GLOBAL row order from row (k+1)·WD on: the B
-        operand of update k.  One rank: the local rows are already that.  Otherwise all-gather into self.P."""
+        operand of update k.  One rank, one stripe: the local rows are already that.  One rank, packed stripes: copied
+        into self.P.  Otherwise all-gathered into self.P."""
         o, G, WD = self.ops, self.comm.world, self.WD
         k0 = k * WD
-        lstart = self._n_le(self.comm.rank, k) * WD
+        nle = self._n_le(self.comm.rank, k)
+        pcs = self.S.pieces(nle, carried=False)
         if G == 1:
-            return self.A[lstart:self.nown * WD, k0:k0 + WD]
-        mloc = self.nown * WD - lstart
+            if len(self.S.items) == 1:
+                return self.A[nle * WD:self.nown * WD, k0:k0 + WD]
+            for view, b0, nb, _ in pcs:                          # local block = global block
+                self.P[b0 * WD:(b0 + nb) * WD].copy_(view[:, k0:k0 + WD])
+            return self.P[k0 + WD:]
         rows = [len(self._blocks_below(q, k)) * WD for q in range(G)]
-        send = self.A[lstart:lstart + mloc, k0:k0 + WD].contiguous()
+        import torch
+
+        send = torch.cat([view[:, k0:k0 + WD] for view, _, _, _ in pcs], dim=0).contiguous() if pcs else self.ops.zeros((0, WD))
         o.sync()
         pieces = self.comm.all_gather_rows(send, rows)
         Pv = self._Pfull.view(self.nblk, WD, self._Pfull.shape[1])[:, :, :WD]
@@ -386,35 +443,39 @@ class ShardedGPE:
         ymu[:n] = self.y - self.mean.mean(self.x)
         self.kdiag = o.set_kernel(self.kernel, self.dim)
         o.info(reset=True)
-        for i, b in enumerate(self.own):                       # cov! + nugget, own block-rows only
-            o.assemble(self.x_dev, n, self.dim, b * WD, self.logNoise, self.A[i * WD:(i + 1) * WD], npad)
+        S = self.S
+        for i, b in enumerate(self.own):                       # cov! + nugget, own block-rows only (lower tiles)
+            blk_rows = S.block(i)
+            o.assemble(self.x_dev, n, self.dim, b * WD, self.logNoise, blk_rows, blk_rows.shape[1])
         ymu_dev = o.from_host(ymu)
         o.sync()
-        self.A[nown * WD].copy_(ymu_dev)
+        S.carried().copy_(ymu_dev)
         o.torch_sync()
         if r == 0:                                             # the first diagonal block has nothing to hide behind
-            o.super_factor(self.A[0:WD, 0:WD], self.linv[0], self.invd[0], self.LW[0], 0)
+            o.super_factor(S.block(0)[:, 0:WD], self.linv[0], self.invd[0], self.LW[0], 0)
         for k in range(nblk):
             k0, owner = k * WD, k % G
             o.sync()
             comm.broadcast(self.LW[k], owner)
             o.torch_sync()
             nle = self._n_le(r, k)
-            lstart = nle * WD
-            mtot = nown * WD - lstart + 1                       # owned rows below + the carried y row
-            X = self.A[lstart:lstart + mtot, k0:k0 + WD]
-            o.super_rows(X, self.LW[k])                         # X ← X·LW_kᵀ
+            pcs = S.pieces(nle)                                 # owned rows below block k + the carried y row, by stripe
+            for view, _, _, _ in pcs:
+                o.super_rows(view[:, k0:k0 + WD], self.LW[k])   # X ← X·LW_kᵀ
             k1 = k0 + WD
             if npad - k1 <= 0:
                 continue
             B = self._panel_rows(k)
-            if nle < nown and self.own[nle] == k + 1:
+            mine_next = nle < nown and self.own[nle] == k + 1
+            look = False
+            if mine_next:
                 # this rank owns the NEXT diagonal block: its own tiles first, then its factorisation and inverse — on the
                 # side stream under the rest of the update (look-ahead) while that update is longer than the chain beside
                 # it (~0.4 ms per 256 columns on contended CUs, as csrc/chol.h decides it), in line otherwise
-                blk = self.A[lstart:lstart + WD, k1:k1 + WD]
-                o.update(blk, X[:WD], B[:WD], 1)
-                rest_rows = mtot - WD
+                blk_rows = S.block(nle)
+                blk = blk_rows[:, k1:k1 + WD]
+                o.update(blk, blk_rows[:, k0:k0 + WD], B[:WD], 1)
+                rest_rows = (nown - nle - 1) * WD + 1
                 tiles = (rest_rows / 128.0) * ((npad - k1) / 256.0) * (WD / 256.0)   # in 128 x 128 x 256 tile products
                 # beside the update the chain takes ~3x its in-line time: look ahead once the update outlasts ~2/3 of that
                 look = tiles >= 1200.0 * (WD // 256)
@@ -423,13 +484,16 @@ class ShardedGPE:
                 o.super_factor(blk, self.linv[nle], self.invd[nle], self.LW[k + 1], k1)
                 if look:
                     o.side_end()
-                g0 = (self.own[nle + 1] - (k + 1)) if nle + 1 < nown else 0
-                o.update(self.A[lstart + WD:lstart + mtot, k1:], X[WD:], B, 2, g0, G, tpb * (nown - nle - 1), tpb)
-                if look:
-                    o.side_join()
-            else:
-                g0 = (self.own[nle] - (k + 1)) if nle < nown else 0
-                o.update(self.A[lstart:lstart + mtot, k1:], X, B, 2, g0, G, tpb * (nown - nle), tpb)
+            for view, b0, nb, extra in pcs:
+                skip = 1 if (mine_next and b0 == nle and nb > 0) else 0   # the next diagonal block had its update already
+                rows = view[skip * WD:]
+                nbl = nb - skip
+                if rows.shape[0] == 0:
+                    continue
+                g0 = (self.own[b0 + skip] - (k + 1)) if nbl > 0 else 0
+                o.update(rows[:, k1:], rows[:, k0:k0 + WD], B, 2, g0, G, tpb * nbl, tpb)
+            if look:
+                o.side_join()
         o.sync()
         # the FIRST failing pivot wins (ranks past it have been factoring garbage), as dpotrf reports it
         mine = o.info()
@@ -437,12 +501,12 @@ class ShardedGPE:
         if info < 1e17:
             raise _lib.PosDefException(int(info))
         # logdet = 2 Σ log L_ii: local share + all-reduce
-        half = sum(o.logdiag_sum(self.A[i * WD:(i + 1) * WD], b * WD) for i, b in enumerate(self.own))
+        half = sum(o.logdiag_sum(S.block(i), b * WD) for i, b in enumerate(self.own))
         self.logdet = 2.0 * comm.all_reduce(half, "sum")
         # backward solve L' α = z, block-rows in reverse.  v = this rank's share of z − Σ_{solved blocks} L_b' α_b: rank 0
         # starts from z (replicated: every rank carried y − μ), the others from 0; the owner of block c needs the TOTAL of
         # its WD entries (an all-reduce of WD numbers), solves, and folds L_c' α_c into its own v
-        v = self.A[nown * WD].clone()
+        v = S.carried().clone()
         if r != 0:
             v.zero_()
         self.alpha_dev.zero_()
@@ -457,8 +521,7 @@ class ShardedGPE:
                     v[c0:c0 + WD].copy_(seg)
                 o.torch_sync()
             if r == owner:
-                lc = (c // G) * WD
-                o.bsolve_block(self.A[lc:lc + WD], c0, self.linv[c // G], v, self.alpha_dev)
+                o.bsolve_block(S.block(c // G), c0, self.linv[c // G], v, self.alpha_dev)
         o.sync()
         comm.all_reduce_tensor(self.alpha_dev)                  # every block of α was written by exactly one rank
         self.alpha = self.alpha_dev[:n].cpu().numpy().astype(self.npdt)
@@ -521,6 +584,11 @@ class ShardedGPE:
 
         allp = torch.cat([p for p in pieces if p.shape[0] > 0], dim=0).cpu().numpy()
         return allp[:, 0].astype(self.npdt), allp[:, 1].astype(self.npdt)
+
+    def predict_y(self, xpred):
+        """predict_f + the observation noise (src/GPE.jl:408-416; scalar logNoise)"""
+        mu, s2 = self.predict_f(xpred)
+        return mu, s2 + np.exp(2.0 * float(np.atleast_1d(self.logNoise)[0]))
 
     # ---- parameters (same ordering as GPE: [logNoise; mean; kernel], src/GPE.jl:447-512) -------------
     def get_params(self):

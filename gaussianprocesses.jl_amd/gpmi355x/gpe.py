@@ -320,8 +320,18 @@ class GPE:
             i += nk
 
 
-def GP(x, y, mean=None, kernel=None, logNoise=-2.0, **kw):
-    """GP(x, y, mean, kernel, logNoise) — src/GPE.jl:119-120."""
+def GP(x, y, mean=None, kernel=None, logNoise=-2.0, packed=False, **kw):
+    """GP(x, y, mean, kernel, logNoise) — src/GPE.jl:119-120.
+
+    packed=True: the factor is kept in PACKED storage (stripes of block-rows that stop at their own diagonal — no upper
+    triangle, N²/2·(1 + 1/S) elements), which lifts the single-device ceiling from N ≈ 180 000 to
+    N ≈ 250 000 in fp64.  The object is the row-block path of gpmi355x.dist on one rank (update_mll / predict_f /
+    predict_y / set_params; no gradient at that size: it needs two more N × N matrices)."""
+    if packed:
+        from .dist import ShardedGPE
+
+        return ShardedGPE(x, y, mean, kernel, logNoise, dtype=kw.pop("dtype", np.float64), ctx=kw.pop("ctx", None),
+                          block=kw.pop("block", 1024), stripe_blocks=kw.pop("stripe_blocks", 8), **kw)
     return GPE(x, y, mean, kernel, logNoise, **kw)
 
 

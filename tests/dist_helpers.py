@@ -42,8 +42,9 @@ class FakeOps:
         nrows = A_rows.shape[0]
         out = np.zeros((nrows, ncols))
         na = max(0, min(nrows, n - row_off))
-        if na > 0:
-            out[:na, :n] = G.cov(self.spec, x[:, row_off:row_off + na], x)
+        if na > 0:  # packed stripes ask for fewer than n columns (up to the stripe's last diagonal)
+            nc = min(n, ncols)
+            out[:na, :nc] = G.cov(self.spec, x[:, row_off:row_off + na], x)[:, :nc]
         nv = np.exp(2.0 * np.atleast_1d(np.asarray(log_noise, dtype=np.float64)))
         for i in range(nrows):
             g = row_off + i

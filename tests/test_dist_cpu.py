@@ -60,8 +60,12 @@ def _worker(rank, world, port, n, case):
             assert ei.value.info == eo.value.info == 301
             return
         block = 512 if case == "fit512" else None  # the super-panel as the distributed block: 512 rows = 4 tiles per block
-        gp = gd.ShardedGPE(x, y, g.MeanConst(0.2), g.from_spec(spec), ln, comm=comm, ops=FakeOps(spec), block=block)
+        stripes = 2 if case == "packed" else None   # packed storage: stripes of 2 local blocks, no upper triangle
+        gp = gd.ShardedGPE(x, y, g.MeanConst(0.2), g.from_spec(spec), ln, comm=comm, ops=FakeOps(spec), block=block,
+                           stripe_blocks=stripes)
         assert gp.WD == (block or 256)
+        if stripes:
+            assert len(gp.S.items) > 1 and gp.S.items[0][2].shape[1] < gp.npad
         ref = G.update_mll(spec, x, y, ln, ("const", 0.2))
         assert abs(gp.mll - ref["mll"]) <= 1e-9 * abs(ref["mll"]), (gp.mll, ref["mll"])
         np.testing.assert_allclose(gp.alpha, ref["alpha"], rtol=1e-7, atol=1e-9)
@@ -71,7 +75,7 @@ def _worker(rank, world, port, n, case):
         np.testing.assert_allclose(mu, mu_o, rtol=1e-7, atol=1e-9)
         np.testing.assert_allclose(s2, s2_o, rtol=1e-6, atol=1e-10)
         # ownership really is split: this rank holds only its share of the factor
-        assert gp.nown == len(range(rank, gp.nblk, world)) and gp.A.shape[0] == gp.nown * gp.WD + 8
+        assert gp.nown == len(range(rank, gp.nblk, world)) and (stripes or gp.A.shape[0] == gp.nown * gp.WD + 8)
         # refit with new hyper-parameters reuses the buffers
         hyp = gp.get_params()
         gp.set_params([h + 0.05 for h in hyp])
@@ -92,6 +96,12 @@ def test_sharded_fit_predict_gloo(world, n):
 
 def test_sharded_fit_predict_gloo_512_row_blocks():
     mp.spawn(_worker, args=(2, _free_port(), 1900, "fit512"), nprocs=2, join=True)
+
+
+@pytest.mark.parametrize("world,n", [(2, 2100), (3, 2500)])
+def test_sharded_packed_stripes_gloo(world, n):
+    """the owned block-rows in stripes that stop at their own diagonal (no upper triangle allocated)."""
+    mp.spawn(_worker, args=(world, _free_port(), n, "packed"), nprocs=world, join=True)
 
 
 def test_sharded_not_posdef_gloo():

@@ -49,6 +49,16 @@ def test_single_rank_device_ops(n, block):
     _check(gp, x, y, xs, ln, ("const", 0.1))
 
 
+@pytest.mark.parametrize("n,block,per", [(2300, 256, 2), (5000, 512, 3), (9000, 1024, 2)])
+def test_single_rank_packed_stripes(n, block, per):
+    """SURVEY §8f-3 on the device: stripes that stop at their own diagonal; every update is one launch per stripe."""
+    x, y, xs = _problem(n)
+    ln = math.log(0.1)
+    gp = gd.ShardedGPE(x, y, g.MeanConst(0.1), g.from_spec(SPEC), ln, block=block, stripe_blocks=per)
+    assert len(gp.S.items) > 1 and gp.S.items[0][2].shape[1] < gp.npad
+    _check(gp, x, y, xs, ln, ("const", 0.1))
+
+
 @pytest.mark.parametrize("world,n,block", [(2, 1000, None), (3, 1793, None), (4, 2600, None), (2, 2600, 512), (3, 4200, 1024)])
 def test_virtual_ranks_on_one_gpu(world, n, block):
     x, y, xs = _problem(n)

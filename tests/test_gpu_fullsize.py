@@ -151,3 +151,44 @@ def test_c4_fp32_n100000_d16_properties_and_fp64_device():
     np.testing.assert_allclose(mu, mu64, rtol=1e-2, atol=1e-2 * np.abs(mu64).max())
     np.testing.assert_allclose(s2, s264, rtol=1e-2, atol=1e-2 * np.abs(s264).max())
     np.testing.assert_allclose(alpha32, gp64.alpha, rtol=0, atol=1e-2 * np.abs(gp64.alpha).max())
+
+
+def test_f3_packed_n220000_fp64_on_one_device_block_diagonal():
+    """N = 220 000 in fp64 on ONE device — past the ~180 000 ceiling of a full N x N buffer — in packed
+    storage (stripes of block-rows that stop at their own diagonal, gpmi355x.dist._Stripes).  Size-independent exactness:
+    220 clusters of 1000 points, 100 length-scale units apart, make K + s2 I EXACTLY block diagonal (exp(-r^2 / 2 l^2)
+    underflows to 0.0 across clusters), so mll, alpha and the predictions of the full factorisation — which does all
+    N^3 / 3 flops, knows nothing of the zeros, and whose 1024-row blocks and 8192-row stripes straddle the 1000-point
+    clusters — must equal those of 220 independent 1000-point GPs, which the oracle computes in seconds."""
+    nc, m, d = 220, 1000, 2
+    n = nc * m
+    rng = np.random.default_rng(42)
+    x = rng.uniform(0.0, 1.0, size=(d, n))
+    x[0] += 100.0 * np.repeat(np.arange(nc), m)
+    y = np.sin(6.0 * (x[0] % 100.0)) + x[1] + 0.1 * rng.standard_normal(n)
+    spec = ("se_iso", math.log(0.3), 0.0)
+    ln = math.log(0.1)
+    gp = g.GP(x, y, g.MeanZero(), g.from_spec(spec), ln, packed=True)
+    assert gp.nobs == n and len(gp.S.items) > 20
+    packed_bytes = gp.S.nbytes_rows * 8
+    assert packed_bytes < 0.56 * 8.0 * n * n, packed_bytes          # the full square would be 387 GB: it does not fit
+    # reference: the clusters one by one
+    mll_ref, alpha_ref = 0.0, np.empty(n)
+    refs = {}
+    for c in range(nc):
+        sl = slice(c * m, (c + 1) * m)
+        ref = G.update_mll(spec, x[:, sl], y[sl], ln)
+        mll_ref += ref["mll"]
+        alpha_ref[sl] = ref["alpha"]
+        if c in (0, 57, 219):
+            refs[c] = ref
+    assert gp.mll == pytest.approx(mll_ref, rel=1e-9)
+    np.testing.assert_allclose(gp.alpha, alpha_ref, rtol=1e-6, atol=1e-8 * np.abs(alpha_ref).max())
+    # predictions next to three clusters (first stripe, a middle one, the last block)
+    xs = np.concatenate([rng.uniform(0.0, 1.0, size=(d, 16)) + np.array([[100.0 * c], [0.0]]) for c in refs], axis=1)
+    mu, s2 = gp.predict_f(xs)
+    for j, c in enumerate(refs):
+        sl = slice(c * m, (c + 1) * m)
+        mu_o, s2_o = G.predict_f(spec, x[:, sl], refs[c], xs[:, 16 * j:16 * (j + 1)])
+        np.testing.assert_allclose(mu[16 * j:16 * (j + 1)], mu_o, rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(s2[16 * j:16 * (j + 1)], s2_o, rtol=1e-5, atol=1e-9)
