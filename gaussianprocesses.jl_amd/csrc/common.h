@@ -293,6 +293,11 @@ void launch_set_identity(gpmi_ctx* ctx, T* A, int64_t ld, int64_t n);
 template <typename T>
 int64_t launch_dmll(gpmi_ctx* ctx, const T* x, int64_t n, int d, const T* alpha, const T* Kinv, int64_t ld, double* partial,
                     int n_hyp);
+// the same reduction over the rectangle of pairs (xa_i, xb_j) with an explicit weight matrix Wt (na x nb, ld): FITC gradient;
+// partial[b][0..n_hyp) (slot n_hyp is zero); returns the number of blocks
+template <typename T>
+int64_t launch_dmll_rect(gpmi_ctx* ctx, const T* xa, int64_t na, const T* xb, int64_t nb, int d, const T* Wt, int64_t ld,
+                         double* partial, int n_hyp);
 // out[s] = sum_b partial[b][s]  (deterministic order)
 void launch_reduce_partials(gpmi_ctx* ctx, const double* partial, int64_t nblocks, int nslots, double* out);
 

@@ -44,6 +44,10 @@ struct gpmi_fitc {
     void *F = nullptr, *U = nullptr, *Cpart = nullptr, *G1 = nullptr, *G = nullptr;
     void *lam = nullptr, *rs = nullptr, *r = nullptr, *alpha = nullptr, *au = nullptr, *cvec = nullptr, *tmp = nullptr;
     double* part = nullptr;  // reduction partials
+    // gradient scratch (gpmi_fitc_grad), allocated on first use: two n x m buffers, five m x m matrices, vectors, partials
+    void *gA = nullptr, *gB = nullptr, *gM[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}, *gq = nullptr, *gv = nullptr, *gbt = nullptr;
+    double* gpart = nullptr;
+    int64_t gpart_cap = 0;
     void *rows = nullptr, *xp = nullptr, *small = nullptr;  // predict scratch
     int64_t rows_cap = 0, xp_cap = 0, small_cap = 0;
     bool fitted = false;
@@ -247,6 +251,85 @@ __global__ __launch_bounds__(256) void fitc_negate_kernel(T* __restrict__ A, int
     if (i < count) A[i] = -A[i];
 }
 
+// ---- gradient (gpmi_fitc_grad) -------------------------------------------------------------------------------------
+// out[i][a] = in[i][a] * s[i]
+template <typename T>
+__global__ __launch_bounds__(256) void fitc_scale_rows_kernel(const T* __restrict__ in, int64_t ld, int64_t n, int64_t m,
+                                                              const T* __restrict__ s, T* __restrict__ out) {
+    const int64_t i = blockIdx.y;
+    const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (a < m) out[i * ld + a] = in[i * ld + a] * s[i];
+}
+// q[i] = alpha_i^2 - (Sigma^-1)_ii,  (Sigma^-1)_ii = (1 - |g_i|^2) / Lambda_i,  g_i = L_B^-1 u'_i  (row i of G);  v[i] = Lambda_i alpha_i
+template <typename T>
+__global__ __launch_bounds__(256) void fitc_q_kernel(const T* __restrict__ G, int64_t ld, int64_t m, const T* __restrict__ alpha,
+                                                     const T* __restrict__ lam, T* __restrict__ q, T* __restrict__ v) {
+    __shared__ double sh[256];
+    const int64_t i = blockIdx.x;
+    const T* row = G + i * ld;
+    double s = 0.0;
+    for (int64_t j = threadIdx.x; j < m; j += 256) {
+        const double g = (double)row[j];
+        s += g * g;
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double a = (double)alpha[i], l = (double)lam[i];
+        q[i] = (T)(a * a - (1.0 - sh[0]) / l);
+        v[i] = (T)(l * a);
+    }
+}
+// Ft[i][a] = alpha_i bt[a] - R2[i][a] rs_i - q_i W[i][a]      (in place on R2)
+template <typename T>
+__global__ __launch_bounds__(256) void fitc_ftilde_kernel(T* __restrict__ R2, const T* __restrict__ W, int64_t ld, int64_t m,
+                                                          const T* __restrict__ alpha, const T* __restrict__ bt,
+                                                          const T* __restrict__ rs, const T* __restrict__ q) {
+    const int64_t i = blockIdx.y;
+    const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (a < m) R2[i * ld + a] = alpha[i] * bt[a] - R2[i * ld + a] * rs[i] - q[i] * W[i * ld + a];
+}
+// out[a][i] = U'[a][i] q_i Lambda_i   (so that out U'' = W' diag(q) W)
+template <typename T>
+__global__ __launch_bounds__(256) void fitc_scale_cols_kernel(const T* __restrict__ U, int64_t ld, int64_t n, int64_t npad,
+                                                              const T* __restrict__ q, const T* __restrict__ lam, T* __restrict__ out) {
+    const int64_t a = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < npad) out[a * ld + i] = i < n ? U[a * ld + i] * q[i] * lam[i] : T(0);
+}
+// Ht = -bt bt' + I - Binv + sum_s part[s]   (full symmetric m x m from the lower triangles)
+template <typename T>
+__global__ __launch_bounds__(256) void fitc_htilde_kernel(T* __restrict__ H, int64_t ld, const T* __restrict__ bt,
+                                                          const T* __restrict__ Binv, const T* __restrict__ part, int nsplit,
+                                                          int64_t stride) {
+    const int64_t i = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j > i) return;
+    T acc = T(0);
+    for (int s = 0; s < nsplit; ++s) acc += part[(int64_t)s * stride + i * ld + j];
+    const T h = -bt[i] * bt[j] + (i == j ? T(1) : T(0)) - Binv[i * ld + j] + acc;
+    H[i * ld + j] = h;
+    H[j * ld + i] = h;
+}
+// out[0] = sum_i q_i  (fixed tree)
+template <typename T>
+__global__ __launch_bounds__(1024) void fitc_sumq_kernel(const T* __restrict__ q, int64_t n, double* __restrict__ out) {
+    __shared__ double sh[1024];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) s += (double)q[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 512; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+
 // factor an mpad x mpad covariance held in A (lower, identity padding) + its 256-block inverses
 template <typename T>
 void factor_dense(gpmi_ctx* c, T* A, int64_t ld, int64_t mpad, int64_t extra, T* linv, T* linv256, T* invdiag) {
@@ -405,6 +488,113 @@ int fitc_predict_t(gpmi_fitc* f, const gpmi_kernel* k, int64_t P, const void* xp
 }
 
 }  // namespace
+// ---- update_dmll! on a FITC model: dmll_kern! (fully_indep_train_conditional.jl:200-234 over the SoR part,
+// subsetofregressors.jl:219-256) and dmll_noise (:243-257), in the whitened coordinates of the fit.  With
+//   b~ = W' alpha,  G = Lambda^-1/2 W L_B^-T,  (Sigma^-1)_ii = (1 - |g_i|^2) / Lambda_i,  q_i = alpha_i^2 - (Sigma^-1)_ii
+//   F~ = alpha b~' - Lambda^-1/2 (G L_B^-1) - diag(q) W                (n x m),      F = F~ Luu^-1
+//   H~ = -b~ b~' + (I - B^-1) + W' diag(q) W                            (m x m),      H = Luu^-T H~ Luu^-1
+// the reference's V - T sums collapse to
+//   dmll/dθ = <dKfu/dθ, F> + 1/2 <dKuu/dθ, H> + 1/2 (sum_i q_i) dk(x,x)/dθ ,      dmll/dlogNoise = sigma^2 sum_i q_i
+// (checked against the literal restatement oracle.gp_oracle.fitc_update_dmll, itself checked by central differences).
+// Five n m^2 products on gemm_nt_kernel — the m x m triangular inverses are formed explicitly (L_B^-1 by whitening an
+// identity; Luu^-1 is the fit's G), so every step is a plain NT product — and three passes of the fused dK/dθ trace kernel
+// (grad.hip, rectangular form): over (x, xu) with weights F, over (xu, xu) with weights H, and one pair at r = 0.
+template <typename T>
+int fitc_grad_t(gpmi_fitc* f, const gpmi_kernel* k, double log_noise, double* dkern_out, int32_t n_kern, double* dnoise_out) {
+    gpmi_ctx* c = f->ctx;
+    const int64_t n = f->n, npad = f->npad, m = f->m, mpad = f->mpad, ldm = f->ldm, ldn = f->ldn;
+    la_reset(c);
+    int rc = upload_program(c, k, f->d);
+    if (rc != GPMI_OK) return rc;
+    const int n_hyp = c->h_prog->n_hyp;
+    if (n_kern != n_hyp) {
+        c->err = "gpmi_fitc_grad: n_kern does not match the kernel's number of hyper-parameters";
+        return GPMI_EARG;
+    }
+    if (n_hyp > GRAD_MAX_HYP || f->d > GRAD_MAX_D || c->h_prog->n_ops > GRAD_MAX_NODES) {
+        c->err = "gpmi_fitc_grad: the device gradient covers kernels with <= 48 hyper-parameters, <= 32 nodes, d <= 16";
+        return GPMI_EARG;
+    }
+    const size_t es = sizeof(T);
+    const int64_t big = std::max<int64_t>(n * ldm, mpad * ldn);
+    if (!f->gA) GPMI_HIP(c, hipMalloc(&f->gA, (size_t)big * es));
+    if (!f->gB) GPMI_HIP(c, hipMalloc(&f->gB, (size_t)big * es));
+    for (auto& p : f->gM)
+        if (!p) GPMI_HIP(c, hipMalloc(&p, (size_t)(mpad * ldm) * es));
+    if (!f->gq) GPMI_HIP(c, hipMalloc(&f->gq, (size_t)n * es));
+    if (!f->gv) GPMI_HIP(c, hipMalloc(&f->gv, (size_t)n * es));
+    if (!f->gbt) GPMI_HIP(c, hipMalloc(&f->gbt, (size_t)mpad * es));
+    const int64_t nb1 = ((n + 63) / 64) * ((m + 63) / 64), nb2 = ((m + 63) / 64) * ((m + 63) / 64);
+    const int64_t need = (std::max(nb1, nb2) + 1) * (int64_t)(n_hyp + 1) * (int64_t)sizeof(double);
+    if (f->gpart_cap < need) {
+        if (f->gpart) hipFree(f->gpart);
+        f->gpart = nullptr;
+        f->gpart_cap = 0;
+        GPMI_HIP(c, hipMalloc(&f->gpart, (size_t)need));
+        f->gpart_cap = need;
+    }
+    T *bufA = (T*)f->gA, *bufB = (T*)f->gB, *W = (T*)f->F, *U = (T*)f->U;
+    T *GBT = (T*)f->gM[0], *GB = (T*)f->gM[1], *GTuu = (T*)f->gM[2], *M3 = (T*)f->gM[3], *M4 = (T*)f->gM[4];
+    T *q = (T*)f->gq, *v = (T*)f->gv, *bt = (T*)f->gbt;
+    const TileShape rect{0, 0, 0, 0, 1, 0}, lower{0, 0, 1, 0, 1, 0};
+    const dim3 gm((unsigned)((mpad + 255) / 256), (unsigned)n), gmm((unsigned)(mpad / 32), (unsigned)(mpad / 32));
+    std::vector<double> t1((size_t)n_hyp + 1), t2((size_t)n_hyp + 1), t3((size_t)n_hyp + 1);
+    double sumq = 0.0;
+    {
+        ProfScope ps(c, GPMI_PROF_SOLVE, 8.0 * (double)n * (double)mpad * (double)mpad);
+        // L_B^-T (rows of the whitened identity), L_B^-1, Luu^-T
+        launch_set_identity<T>(c, GBT, ldm, mpad);
+        whiten_rows<T>(c, (const T*)f->AS, ldm, (const T*)f->linv_S, mpad, GBT, ldm, mpad);
+        hipLaunchKernelGGL(fitc_transpose_kernel<T>, gmm, dim3(256), 0, c->stream, (const T*)GBT, ldm, mpad, mpad, (const T*)nullptr, GB, ldm);
+        hipLaunchKernelGGL(fitc_transpose_kernel<T>, gmm, dim3(256), 0, c->stream, (const T*)f->G, ldm, mpad, mpad, (const T*)nullptr, GTuu, ldm);
+        // G = (Lambda^-1/2 W) L_B^-T ;  q, v = Lambda alpha ;  b~ = W' alpha = U' (rs . v)
+        hipLaunchKernelGGL(fitc_scale_rows_kernel<T>, gm, dim3(256), 0, c->stream, (const T*)W, ldm, n, mpad, (const T*)f->rs, bufA);
+        launch_gemm_shape<T>(c, bufB, ldm, bufA, ldm, GB, ldm, n, mpad, mpad, rect, nullptr, GEMM_OVERWRITE);
+        hipLaunchKernelGGL(fitc_q_kernel<T>, dim3((unsigned)n), dim3(256), 0, c->stream, (const T*)bufB, ldm, mpad, (const T*)f->alpha,
+                           (const T*)f->lam, q, v);
+        hipLaunchKernelGGL(fitc_gemv_rows_kernel<T>, dim3((unsigned)mpad), dim3(256), 0, c->stream, (const T*)U, ldn, n, (const T*)f->rs,
+                           (const T*)v, bt);
+        hipLaunchKernelGGL(fitc_sumq_kernel<T>, dim3(1), dim3(1024), 0, c->stream, (const T*)q, n, c->d_scal + 6);
+        // R2 = G L_B^-1 ;  F~ (in place) ;  F = F~ Luu^-1
+        launch_gemm_shape<T>(c, bufA, ldm, bufB, ldm, GBT, ldm, n, mpad, mpad, rect, nullptr, GEMM_OVERWRITE);
+        hipLaunchKernelGGL(fitc_ftilde_kernel<T>, gm, dim3(256), 0, c->stream, bufA, (const T*)W, ldm, mpad, (const T*)f->alpha, (const T*)bt,
+                           (const T*)f->rs, (const T*)q);
+        launch_gemm_shape<T>(c, bufB, ldm, bufA, ldm, GTuu, ldm, n, mpad, mpad, rect, nullptr, GEMM_OVERWRITE);
+        // <dKfu, F>
+        const int64_t b1 = launch_dmll_rect<T>(c, (const T*)f->x, n, (const T*)f->xu, m, f->d, (const T*)bufB, ldm, f->gpart, n_hyp);
+        launch_reduce_partials(c, f->gpart, b1, n_hyp + 1, (double*)M3);
+        GPMI_HIP(c, hipMemcpyAsync(t1.data(), M3, t1.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        // W' diag(q) W = (U' diag(q Lambda)) U''  (split-K, lower tiles), B^-1 = L_B^-T L_B^-1 (lower), H~, H
+        hipLaunchKernelGGL(fitc_scale_cols_kernel<T>, dim3((unsigned)((npad + 255) / 256), (unsigned)mpad), dim3(256), 0, c->stream,
+                           (const T*)U, ldn, n, npad, (const T*)q, (const T*)f->lam, bufA);
+        {
+            const int64_t kc = npad / f->nsplit;
+            GemmBatch gb{f->nsplit, kc, kc, mpad * ldm};
+            launch_gemm_shape<T>(c, (T*)f->Cpart, ldm, bufA, ldn, U, ldn, mpad, mpad, kc, lower, nullptr, GEMM_OVERWRITE, &gb);
+        }
+        launch_gemm_shape<T>(c, M3, ldm, GBT, ldm, GBT, ldm, mpad, mpad, mpad, lower, nullptr, GEMM_OVERWRITE);
+        hipLaunchKernelGGL(fitc_htilde_kernel<T>, dim3((unsigned)((mpad + 255) / 256), (unsigned)mpad), dim3(256), 0, c->stream, M4, ldm,
+                           (const T*)bt, (const T*)M3, (const T*)f->Cpart, f->nsplit, mpad * ldm);
+        launch_gemm_shape<T>(c, M3, ldm, M4, ldm, GTuu, ldm, mpad, mpad, mpad, rect, nullptr, GEMM_OVERWRITE);      // Y = H~ Luu^-1
+        hipLaunchKernelGGL(fitc_transpose_kernel<T>, gmm, dim3(256), 0, c->stream, (const T*)M3, ldm, mpad, mpad, (const T*)nullptr, M4, ldm);
+        launch_gemm_shape<T>(c, M3, ldm, M4, ldm, GTuu, ldm, mpad, mpad, mpad, rect, nullptr, GEMM_OVERWRITE);      // H = Y' Luu^-1
+        // <dKuu, H>  and  dk(x, x)/dθ (one pair at distance 0, weight 1)
+        const int64_t b2 = launch_dmll_rect<T>(c, (const T*)f->xu, m, (const T*)f->xu, m, f->d, (const T*)M3, ldm, f->gpart, n_hyp);
+        launch_reduce_partials(c, f->gpart, b2, n_hyp + 1, (double*)M4);
+        GPMI_HIP(c, hipMemcpyAsync(t2.data(), M4, t2.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        launch_set_identity<T>(c, GB, ldm, 1);  // GB is free again: a 1 x 1 weight matrix [1]
+        const int64_t b3 = launch_dmll_rect<T>(c, (const T*)f->xu, 1, (const T*)f->xu, 1, f->d, (const T*)GB, ldm, f->gpart, n_hyp);
+        launch_reduce_partials(c, f->gpart, b3, n_hyp + 1, (double*)GBT);
+        GPMI_HIP(c, hipMemcpyAsync(t3.data(), GBT, t3.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        GPMI_HIP(c, hipMemcpyAsync(&sumq, c->d_scal + 6, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    GPMI_HIP(c, hipStreamSynchronize(c->stream));
+    GPMI_HIP(c, hipGetLastError());
+    for (int p = 0; p < n_hyp; ++p) dkern_out[p] = t1[(size_t)p] + 0.5 * t2[(size_t)p] + 0.5 * sumq * t3[(size_t)p];
+    if (dnoise_out) *dnoise_out = exp(2.0 * log_noise) * sumq;
+    return GPMI_OK;
+}
+
 }  // namespace gpmi
 
 extern "C" {
@@ -417,7 +607,7 @@ void gpmi_fitc_destroy(gpmi_fitc* f) {
     }
     void* ptrs[] = {f->x, f->xu, f->Auu, f->linv_uu, f->linv256_uu, f->invdiag_uu, f->AS, f->linv_S, f->linv256_S, f->invdiag_S,
                     f->F, f->U, f->Cpart, f->G1, f->G, f->lam, f->rs, f->r, f->alpha, f->au, f->cvec, f->tmp, f->part, f->rows, f->xp,
-                    f->small};
+                    f->small, f->gA, f->gB, f->gM[0], f->gM[1], f->gM[2], f->gM[3], f->gM[4], f->gq, f->gv, f->gbt, f->gpart};
     for (void* p : ptrs)
         if (p) hipFree(p);
     delete f;
@@ -517,6 +707,21 @@ int gpmi_fitc_predict(gpmi_fitc* f, const gpmi_kernel* k, int64_t p, const void*
     hipSetDevice(f->ctx->device);
     return f->dtype == 64 ? gpmi::fitc_predict_t<double>(f, k, p, xpred, mean_pred, full_cov, mu_out, var_out)
                           : gpmi::fitc_predict_t<float>(f, k, p, xpred, mean_pred, full_cov, mu_out, var_out);
+}
+
+int gpmi_fitc_grad(gpmi_fitc* f, const gpmi_kernel* k, double log_noise, double* dkern_out, int32_t n_kern, double* dnoise_out) {
+    if (!f) return GPMI_EARG;
+    if (!k || !dkern_out) {
+        f->ctx->err = "gpmi_fitc_grad: null argument";
+        return GPMI_EARG;
+    }
+    if (!f->fitted) {
+        f->ctx->err = "gpmi_fitc_grad: no factorisation (call gpmi_fitc_fit first)";
+        return GPMI_EARG;
+    }
+    hipSetDevice(f->ctx->device);
+    return f->dtype == 64 ? gpmi::fitc_grad_t<double>(f, k, log_noise, dkern_out, n_kern, dnoise_out)
+                          : gpmi::fitc_grad_t<float>(f, k, log_noise, dkern_out, n_kern, dnoise_out);
 }
 
 int gpmi_fitc_alpha_u(gpmi_fitc* f, void* out) {

@@ -48,11 +48,13 @@ __device__ __forceinline__ bool is_ard_op(int op) {
     return op == GPMI_K_SE_ARD || op == GPMI_K_MAT12_ARD || op == GPMI_K_MAT32_ARD || op == GPMI_K_MAT52_ARD || op == GPMI_K_RQ_ARD;
 }
 
-template <typename T, int DMAX>
+// RECT (FITC gradient, fitc.hip): the same reduction over a RECTANGLE of pairs (x_i, xb_j), i < n, j < nb, with an explicit
+// weight matrix:  partial[p] = sum_ij Wt[i][j] dk(x_i, xb_j)/dθ_p  — `Kinv` is Wt, alpha is unused, no triangle, no trace slot.
+template <typename T, int DMAX, bool RECT>
 __global__ __launch_bounds__(256) void dmll_kernel(const T* __restrict__ x, int64_t n, int d, const T* __restrict__ alpha,
                                                    const T* __restrict__ Kinv, int64_t ld,
                                                    const DevProgram* __restrict__ prog, double* __restrict__ partial,
-                                                   int n_hyp) {
+                                                   int n_hyp, const T* __restrict__ xb_pts, int64_t nb) {
     constexpr int GSTK = 6;  // evaluation-stack depth (validated on the host, as for cov)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* gl = reinterpret_cast<double*>(smem);                 // [n_hyp + 1][256] accumulators
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(256) void dmll_kernel(const T* __restrict__ x, int6
     const int64_t row0 = (int64_t)blockIdx.y * 64, col0 = (int64_t)blockIdx.x * 64;
     const int64_t bid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
     const int nslots = n_hyp + 1;
-    if (col0 > row0 + 63 || row0 >= n) {  // nothing on or below the diagonal in this tile
+    if ((!RECT && col0 > row0 + 63) || row0 >= n || (RECT && col0 >= nb)) {  // nothing on or below the diagonal in this tile
         if (tid < nslots) partial[bid * nslots + tid] = 0.0;
         return;
     }
@@ -77,14 +79,16 @@ __global__ __launch_bounds__(256) void dmll_kernel(const T* __restrict__ x, int6
     }
     if (tid < 64) {
         int64_t gr = row0 + tid;
-        sal[tid] = gr < n ? alpha[gr] : T(0);
+        sal[tid] = (!RECT && gr < n) ? alpha[gr] : T(0);
     }
     const int64_t gcol = col0 + lane;
-    const int64_t gc = gcol < n ? gcol : n - 1;
+    const int64_t ncols = RECT ? nb : n;
+    const T* __restrict__ xcols = RECT ? xb_pts : x;
+    const int64_t gc = gcol < ncols ? gcol : ncols - 1;
     T xb[DMAX];
 #pragma unroll
-    for (int k = 0; k < DMAX; ++k) xb[k] = (k < d) ? x[gc * d + k] : T(0);
-    const T acol = gcol < n ? alpha[gcol] : T(0);
+    for (int k = 0; k < DMAX; ++k) xb[k] = (k < d) ? xcols[gc * d + k] : T(0);
+    const T acol = (!RECT && gcol < n) ? alpha[gcol] : T(0);
     __syncthreads();
 
     const int nops = prog->n_ops;
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(256) void dmll_kernel(const T* __restrict__ x, int6
         const int row = wv * 16 + rr;
         const int64_t grow = row0 + row;
         if (grow >= n) break;  // wave-uniform
-        const bool valid = (gcol <= grow);  // lower triangle including the diagonal (gcol < n follows)
+        const bool valid = RECT ? (gcol < nb) : (gcol <= grow);  // lower triangle including the diagonal (gcol < n follows)
         const T* sar = sa + row * d;
         T dsq[DMAX];
 #pragma unroll
@@ -102,9 +106,9 @@ __global__ __launch_bounds__(256) void dmll_kernel(const T* __restrict__ x, int6
         }
         // W_ij and its weight: diagonal entries count half (GPE.jl:228-231), strict lower entries once (:233-238)
         const T kin = valid ? Kinv[grow * ld + gcol] : T(0);
-        const T wij = sal[row] * acol - kin;
-        const T ww = valid ? ((grow == gcol) ? T(0.5) * wij : wij) : T(0);
-        if (valid && grow == gcol) gl[n_hyp * 256 + tid] += (double)wij;  // tr(alpha alpha' - K^-1)
+        const T wij = RECT ? kin : sal[row] * acol - kin;
+        const T ww = valid ? ((!RECT && grow == gcol) ? T(0.5) * wij : wij) : T(0);
+        if (!RECT && valid && grow == gcol) gl[n_hyp * 256 + tid] += (double)wij;  // tr(alpha alpha' - K^-1)
 
         // For every leaf L: one forward-mode sweep of the postfix program with the seed on L gives
         //   kv = value of L,  m = d(root)/d(value of L)   (sum rule: sum_kernel.jl:18-51, product rule: prod_kernel.jl:17-68)
@@ -280,22 +284,32 @@ void launch_set_identity(gpmi_ctx* ctx, T* A, int64_t ld, int64_t n) {
     hipLaunchKernelGGL(set_identity_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, A, ld, n);
 }
 
-template <typename T>
-int64_t launch_dmll(gpmi_ctx* ctx, const T* x, int64_t n, int d, const T* alpha, const T* Kinv, int64_t ld, double* partial,
-                    int n_hyp) {
-    const unsigned nt = (unsigned)((n + 63) / 64);
+template <typename T, bool RECT>
+static int64_t launch_dmll_any(gpmi_ctx* ctx, const T* x, int64_t n, int d, const T* alpha, const T* Kinv, int64_t ld, double* partial,
+                               int n_hyp, const T* xb, int64_t nb) {
+    const unsigned ntr = (unsigned)((n + 63) / 64), ntc = RECT ? (unsigned)((nb + 63) / 64) : ntr;
     const size_t lds = (size_t)(n_hyp + 1) * 256 * 8 + (size_t)(64 * d + 64) * sizeof(T) + (size_t)4 * (n_hyp + 1) * 8;
     auto go = [&](auto kern) {
         if (lds > 48 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(nt, nt), dim3(256), lds, ctx->stream, x, n, d, alpha, Kinv, ld, ctx->d_prog, partial, n_hyp);
+        hipLaunchKernelGGL(kern, dim3(ntc, ntr), dim3(256), lds, ctx->stream, x, n, d, alpha, Kinv, ld, ctx->d_prog, partial, n_hyp, xb, nb);
     };
     if (d <= 4)
-        go(dmll_kernel<T, 4>);
+        go(dmll_kernel<T, 4, RECT>);
     else if (d <= 8)
-        go(dmll_kernel<T, 8>);
+        go(dmll_kernel<T, 8, RECT>);
     else
-        go(dmll_kernel<T, 16>);
-    return (int64_t)nt * nt;
+        go(dmll_kernel<T, 16, RECT>);
+    return (int64_t)ntr * ntc;
+}
+template <typename T>
+int64_t launch_dmll(gpmi_ctx* ctx, const T* x, int64_t n, int d, const T* alpha, const T* Kinv, int64_t ld, double* partial,
+                    int n_hyp) {
+    return launch_dmll_any<T, false>(ctx, x, n, d, alpha, Kinv, ld, partial, n_hyp, x, n);
+}
+template <typename T>
+int64_t launch_dmll_rect(gpmi_ctx* ctx, const T* xa, int64_t na, const T* xb, int64_t nb, int d, const T* Wt, int64_t ld,
+                         double* partial, int n_hyp) {
+    return launch_dmll_any<T, true>(ctx, xa, na, d, xa /* unused */, Wt, ld, partial, n_hyp, xb, nb);
 }
 
 void launch_reduce_partials(gpmi_ctx* ctx, const double* partial, int64_t nblocks, int nslots, double* out) {
@@ -306,5 +320,7 @@ template void launch_set_identity<double>(gpmi_ctx*, double*, int64_t, int64_t);
 template void launch_set_identity<float>(gpmi_ctx*, float*, int64_t, int64_t);
 template int64_t launch_dmll<double>(gpmi_ctx*, const double*, int64_t, int, const double*, const double*, int64_t, double*, int);
 template int64_t launch_dmll<float>(gpmi_ctx*, const float*, int64_t, int, const float*, const float*, int64_t, double*, int);
+template int64_t launch_dmll_rect<double>(gpmi_ctx*, const double*, int64_t, const double*, int64_t, int, const double*, int64_t, double*, int);
+template int64_t launch_dmll_rect<float>(gpmi_ctx*, const float*, int64_t, const float*, int64_t, int, const float*, int64_t, double*, int);
 
 }  // namespace gpmi

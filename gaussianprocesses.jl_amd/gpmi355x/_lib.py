@@ -21,7 +21,7 @@ PROF_SYRK, PROF_COV, PROF_PANEL, PROF_SOLVE, PROF_PREDICT = range(5)
 SYMBOLS = [
     "gpmi_ctx_create", "gpmi_ctx_destroy", "gpmi_last_error", "gpmi_version",
     "gpmi_gp_create", "gpmi_gp_destroy", "gpmi_fit", "gpmi_predict", "gpmi_grad", "gpmi_cov",
-    "gpmi_inv_diag", "gpmi_fitc_create", "gpmi_fitc_destroy", "gpmi_fitc_fit", "gpmi_fitc_predict", "gpmi_fitc_alpha_u",
+    "gpmi_inv_diag", "gpmi_fitc_create", "gpmi_fitc_destroy", "gpmi_fitc_fit", "gpmi_fitc_predict", "gpmi_fitc_alpha_u", "gpmi_fitc_grad",
     "gpmi_solve", "gpmi_whiten", "gpmi_logdet", "gpmi_factor_to_host", "gpmi_factor_diag",
     "gpmi_profile_enable", "gpmi_profile_get", "gpmi_profile_get_bytes", "gpmi_mfma_peak", "gpmi_bench_gemm",
     "gpmi_dev_set_kernel", "gpmi_dev_assemble", "gpmi_dev_cov_rows", "gpmi_dev_potrf_block", "gpmi_dev_rows_solve",
@@ -99,6 +99,7 @@ def load():
     lib.gpmi_fitc_fit.argtypes = [vp, C.POINTER(GpmiKernel), C.c_double, vp, C.POINTER(dbl), vp, C.POINTER(i64)]
     lib.gpmi_fitc_predict.argtypes = [vp, C.POINTER(GpmiKernel), i64, vp, vp, C.c_int, vp, vp]
     lib.gpmi_fitc_alpha_u.argtypes = [vp, vp]
+    lib.gpmi_fitc_grad.argtypes = [vp, C.POINTER(GpmiKernel), C.c_double, C.POINTER(dbl), C.c_int32, C.POINTER(dbl)]
     lib.gpmi_grad.argtypes = [vp, C.POINTER(GpmiKernel), C.POINTER(dbl), i64, C.POINTER(dbl), C.c_int32, C.POINTER(dbl)]
     lib.gpmi_solve.argtypes = [vp, i64, vp]
     lib.gpmi_whiten.argtypes = [vp, i64, vp]

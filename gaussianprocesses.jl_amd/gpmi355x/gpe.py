@@ -160,8 +160,6 @@ class GPE:
     def update_dmll(self, noise=True, domean=True, kern=True):
         """Gradient of the mll in the order [logNoise; mean…; kernel…] (the exposed parameters only).
         Kernel and noise parts come from the device (gpmi_grad); the mean part is dot(grad_mean, alpha)."""
-        if self.covstrat is not None:
-            raise _lib.ArgumentError("the device gradient covers the exact path only (FITC gradients: SURVEY 8f, not built)")
         if self.alpha is None:
             raise _lib.ArgumentError("update_dmll needs a fitted model (call update_mll first)")
         parts = []
@@ -173,8 +171,12 @@ class GPE:
             kd, keep = self.kernel.descriptor(self.dim)
             dk = np.empty(max(nfull, 1), dtype=np.float64)
             dn = C.c_double()
-            rc = _lib.load().gpmi_grad(self.cK.h, C.byref(kd), ln.ctypes.data_as(C.POINTER(C.c_double)), ln.shape[0],
-                                       dk.ctypes.data_as(C.POINTER(C.c_double)), nfull, C.byref(dn) if noise else None)
+            if self.covstrat is not None:  # FITC: dmll_kern! / dmll_noise of fully_indep_train_conditional.jl:200-257
+                rc = _lib.load().gpmi_fitc_grad(self.cK.h, C.byref(kd), float(ln[0]), dk.ctypes.data_as(C.POINTER(C.c_double)), nfull,
+                                                C.byref(dn))
+            else:
+                rc = _lib.load().gpmi_grad(self.cK.h, C.byref(kd), ln.ctypes.data_as(C.POINTER(C.c_double)), ln.shape[0],
+                                           dk.ctypes.data_as(C.POINTER(C.c_double)), nfull, C.byref(dn) if noise else None)
             del keep
             self.ctx.check(rc)
         if noise:

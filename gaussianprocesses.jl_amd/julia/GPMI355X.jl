@@ -298,6 +298,25 @@ function predict_f(gp::GPE{X,Y,M,K,<:HIPFITC}, x::AbstractMatrix; full_cov::Bool
     end
     check(context(), rc); μ, Σ
 end
+# update_dmll! (src/GPE.jl:298-324) with dmll_kern! / dmll_noise of the FITC strategy (fully_indep…:200-257) from the device
+function update_dmll!(gp::GPE{X,Y,M,K,<:HIPFITC}; noise::Bool=true, domean::Bool=true, kern::Bool=true) where {X,Y,M,K}
+    nfull = full_nparams(gp.kernel)
+    dk = Vector{Float64}(undef, max(nfull, 1)); dn = Ref{Float64}(0.0)
+    rc = withkernel(descriptor(gp.kernel)) do ck
+        ccall((:gpmi_fitc_grad, libgpmi), Cint, (Ptr{Cvoid}, Ref{CKernel}, Float64, Ptr{Float64}, Int32, Ref{Float64}),
+              gp.cK.handle, ck, Float64(get_value(gp.logNoise)), dk, nfull, dn)
+    end
+    check(context(), rc)
+    n_mean = num_params(gp.mean)
+    gp.dmll = Vector{Float64}(undef, noise + domean * n_mean + kern * num_params(gp.kernel))
+    i = 1
+    noise && (gp.dmll[i] = dn[]; i += 1)
+    if domean && n_mean > 0
+        gp.dmll[i:i+n_mean-1] = grad_stack(gp.mean, gp.x)' * gp.alpha; i += n_mean
+    end
+    kern && (gp.dmll[i:end] = dk[full_slots(gp.kernel)])
+    gp
+end
 function get_alpha_u(a::HIPFITCPDMat, args...)                           # fully_indep…:279-286
     au = Vector{Float64}(undef, size(a.inducing, 2))
     check(context(), ccall((:gpmi_fitc_alpha_u, libgpmi), Cint, (Ptr{Cvoid}, Ptr{Float64}), a.handle, au)); au

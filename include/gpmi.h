@@ -152,6 +152,10 @@ int gpmi_fitc_predict(gpmi_fitc*, const gpmi_kernel*, int64_t p, const void* xpr
                       void* mu_out, void* var_out);
 /* alpha_u = SigmaQR \ (Kuf (Lambda \ (y - mu))), m elements (get_alpha_u) */
 int gpmi_fitc_alpha_u(gpmi_fitc*, void* out);
+/* update_dmll! on the FITC model of the last gpmi_fitc_fit (same kernel, same log_noise): dmll_kern!
+ * (src/sparse/fully_indep_train_conditional.jl:200-234 over subsetofregressors.jl:219-256) -> dkern_out[n_kern] in
+ * get_params order, dmll_noise (:243-257) -> *dnoise_out.  The mean part (GPE.jl:282-288) is grad_stack' * alpha on the host. */
+int gpmi_fitc_grad(gpmi_fitc*, const gpmi_kernel*, double log_noise, double* dkern_out, int32_t n_kern, double* dnoise_out);
 
 /* ---- cov: replaces cov / cov! (src/kernels/kernels.jl:31-71) -------------
  * out is n1 x n2 col-major; x2 == NULL selects the symmetric X1 === X2 form. */

@@ -584,6 +584,56 @@ def fitc_predict_f(spec, xu, fit, xpred, mspec=("zero",), full_cov=False):
     return mu, np.maximum(np.diag(S), 0.0)
 
 
+def grad_cov_rect(spec, Xa, Xb):
+    """(cov(k, Xa, Xb), [d cov / dθ_p]) for two point sets, and the diagonal derivative d k(x, x) / dθ_p of Xb's points:
+    grad_slice! (kernels.jl:140-160) over a rectangular block and dKij_dθp(kernel, X, X, EmptyData(), i, i, p, dim).
+    Evaluated as blocks of grad_cov on the joined set (small cases only)."""
+    Xa = np.asarray(Xa, dtype=np.float64)
+    Xb = np.asarray(Xb, dtype=np.float64)
+    ma = Xa.shape[1]
+    K, dK = grad_cov(spec, np.concatenate([Xa, Xb], axis=1))
+    return K[:ma, ma:], [d[:ma, ma:] for d in dK], [np.diag(d)[ma:].copy() for d in dK]
+
+
+def fitc_update_dmll(spec, x, xu, y, log_noise, mspec=("zero",), fit=None):
+    """update_dmll! (GPE.jl:298-324) on a FITC model: [dmll_noise; dmll_mean; dmll_kern] as the reference forms them.
+      precompute!          subsetofregressors.jl:141-151   Kuu⁻¹Kuf, Kuu⁻¹KufΣ⁻¹y, Σ⁻¹Kfu
+      dmll_kern! (SoR)     subsetofregressors.jl:219-256   V = 2 α'∂Kfu b − b'∂Kuu b ;  T = 2 tr(Kuu⁻¹KufΣ⁻¹∂Kfu) − tr(Σ⁻¹Kfu Kuu⁻¹∂Kuu Kuu⁻¹Kuf)
+      dmll_kern! (FITC)    fully_indep_train_conditional.jl:200-234   ∂Λ_i = ∂K_ii + a_i'∂Kuu a_i − 2 ∂K_ui'a_i ;  += (α'∂Λα − tr(Σ⁻¹∂Λ)) / 2
+      trinvAB              fully_indep_train_conditional.jl:63-67
+      dmll_noise           fully_indep_train_conditional.jl:243-257   σ² (α'α − tr Λ⁻¹ + |Lk|²),  Lk = ΣQR^-½ Kuf Λ⁻¹
+      dmll_mean!           GPE.jl:282-288"""
+    x = np.asarray(x, dtype=np.float64)
+    xu = np.asarray(xu, dtype=np.float64)
+    if fit is None:
+        fit = fitc_update_mll(spec, x, xu, y, log_noise, mspec)
+    alpha, lam, Kuf = fit["alpha"], fit["lam"], fit["Kuf"]
+    n, m = x.shape[1], xu.shape[1]
+    # precompute!
+    A = sla.cho_solve((fit["Uuu"], False), Kuf)                       # Kuu⁻¹Kuf                  (m × n)
+    b = sla.cho_solve((fit["Uuu"], False), Kuf @ alpha)               # Kuu⁻¹KufΣ⁻¹y              (m)
+    SiKfu = fitc_solve(fit, Kuf.T.copy())                             # Σ⁻¹Kfu = cK \ Kfu         (n × m)
+    # trinvAB's L
+    L = sla.solve_triangular(fit["Usqr"], Kuf / lam, trans="T", lower=False)   # whiten(ΣQR, Kuf Λ⁻¹)
+    _, dKuf, dKdiag = grad_cov_rect(spec, xu, x)
+    _, dKuu = grad_cov(spec, xu)
+    dk = np.zeros(len(dKuf))
+    for p in range(len(dKuf)):
+        dKuf_p, dKuu_p = dKuf[p], dKuu[p]
+        V = 2.0 * float(alpha @ (dKuf_p.T @ b)) - float(b @ (dKuu_p @ b))
+        T = 2.0 * float(np.sum(fitc_solve(fit, dKuf_p.T.copy()) * A.T))
+        T -= float(np.sum(SiKfu.T * (sla.cho_solve((fit["Uuu"], False), dKuu_p) @ A)))
+        dk[p] = (V - T) / 2.0
+        dlam = dKdiag[p] + np.einsum("ui,uv,vi->i", A, dKuu_p, A) - 2.0 * np.sum(dKuf_p * A, axis=0)
+        V2 = float(alpha @ (dlam * alpha))
+        T2 = float(np.sum(dlam / lam)) - float(np.sum(L * (L * dlam)))
+        dk[p] += (V2 - T2) / 2.0
+    Lk = sla.solve_triangular(fit["Usqr"], Kuf, trans="T", lower=False) / lam
+    dnoise = math.exp(2.0 * float(log_noise)) * (float(alpha @ alpha) - float(np.sum(1.0 / lam)) + float(np.sum(Lk * Lk)))
+    dmean = grad_mean(mspec, x).T @ alpha                              # dmll_mean!: grad_stack' * alpha
+    return {"dmll": np.concatenate([[dnoise], dmean, dk]), "dnoise": dnoise, "dmean": dmean, "dkern": dk}
+
+
 def _chol_lower_ld(A):
     """Unblocked lower Cholesky in np.longdouble (80-bit on x86): the arithmetic-independent value of a factorisation."""
     LD = np.longdouble

@@ -333,3 +333,32 @@ def test_predict_loo_is_refitting_without_the_point():
         f_i = G.update_mll(spec, x[:, keep], y[keep], ln)
         m_i, v_i = G.predict_y(spec, x[:, keep], f_i, x[:, i:i + 1], ln)
         assert abs(mu[i] - m_i[0]) < 1e-8 and abs(s2[i] - v_i[0]) < 1e-8
+
+
+def test_fitc_gradient_restatement_against_central_differences():
+    """fitc_update_dmll (dmll_noise / dmll_mean! / dmll_kern! of the FITC strategy, fully_indep_train_conditional.jl:200-257
+    over subsetofregressors.jl:219-256) differentiates fitc_update_mll: the reference pins the same relation for its
+    strategies in test/test_sparse.jl:161-175 (dmll vs finite differences)."""
+    rng = np.random.default_rng(0)
+    n, m, d = 300, 25, 3
+    x = rng.uniform(size=(d, n))
+    xu = x[:, ::12][:, :m].copy()
+    y = np.sin(3 * x.sum(axis=0)) + 0.1 * rng.standard_normal(n)
+
+    def spec_of(th):
+        return ("sum", ("se_ard", list(th[0:3]), th[3]), ("mat52_iso", th[4], th[5]))
+
+    th0 = np.array([-0.5, -0.3, -0.6, 0.2, -0.4, -0.5])
+    ln0, c0 = math.log(0.3), 0.2
+    g = G.fitc_update_dmll(spec_of(th0), x, xu, y, ln0, ("const", c0))["dmll"]
+
+    def f(ln, c, th):
+        return G.fitc_update_mll(spec_of(th), x, xu, y, ln, ("const", c))["mll"]
+
+    h = 1e-5
+    fd = [(f(ln0 + h, c0, th0) - f(ln0 - h, c0, th0)) / (2 * h), (f(ln0, c0 + h, th0) - f(ln0, c0 - h, th0)) / (2 * h)]
+    for p in range(6):
+        e = np.zeros(6)
+        e[p] = h
+        fd.append((f(ln0, c0, th0 + e) - f(ln0, c0, th0 - e)) / (2 * h))
+    np.testing.assert_allclose(g, np.array(fd), rtol=1e-4, atol=1e-4)
