@@ -82,6 +82,9 @@ struct gpmi_ctx {
     double* h_scal = nullptr;            // pinned
     unsigned long long* d_queue = nullptr;  // 8 per-XCD tile-queue words, 64 B apart (never reset)
     unsigned long long queue_base[8] = {0}; // value of each word when the next launch starts
+    unsigned long long done_base[8] = {0};      // 'tiles finished' words (queue word + 1), GEMM_PHASE_LOCK launches only
+    unsigned long long done_base_side[8] = {0};
+    int64_t phase_lock_min_k = 0;               // trailing updates with K >= this are phase-locked (0 = never; GPMI_PHASE_LOCK)
     unsigned long long* d_queue_side = nullptr;   // a second set for persistent launches beside the update (side stream):
     unsigned long long queue_base_side[8] = {0};  // the two run concurrently and must not share queue words
     bool refine_default = false;         // GPMI_REFINE=1: refine everywhere (bring-up / accuracy studies)
@@ -227,6 +230,7 @@ void launch_gemm_shape(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda
                        int64_t N, int64_t K, TileShape shape, const int* info, int flags = 0, const GemmBatch* batch = nullptr);
 enum GemmFlags { GEMM_OVERWRITE = 1 /* C = A B' instead of C -= A B' */, GEMM_KSTART_ROW = 2 /* A[i][k] = 0 for k < i: start K at the tile's first row */,
                  GEMM_KEND_COL = 8 /* B[j][k] = 0 for k > j: end K at the tile's last column */,
+                 GEMM_PHASE_LOCK = 64 /* tiles of an XCD start round by round (gemm.hip QueueArgs::done_base) */,
                  GEMM_AUX = 4 /* no effect on the kernel: account the launch to the panel class, not to the trailing update */,
                  GEMM_NO_PAIR16 = 32 /* tools: 8-byte instead of 16-byte C accesses in fp64 (A/B of the access width) */ };
 

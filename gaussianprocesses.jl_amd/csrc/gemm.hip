@@ -55,6 +55,10 @@ struct QueueArgs {
     unsigned long long base[8];  // per-XCD value of the queue word at launch
     int64_t start[9];            // chunk x = tiles [start[x], start[x+1])
     int use_queue;
+    // GEMM_PHASE_LOCK: value of the XCD's "tiles finished" word (queue word + 1) at launch; a tile of round r = (t - start) /
+    // nloc starts once every tile of the earlier rounds has finished its K loop, so the ~64 tiles in flight on an XCD step
+    // through K together and share their 16 operand panels in L2 slab by slab
+    unsigned long long done_base[8];
     // batched launch (split-K with separate outputs): work item t is tile t % tiles_per of batch t / tiles_per,
     // whose operands and output start strideA / strideB / strideC elements further on
     int64_t tiles_per;
@@ -88,7 +92,10 @@ __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __rest
     const int nloc = (gridDim.x - xcd + 7) >> 3;           // workgroups on this XCD
     const int64_t cbeg = qa.start[xcd], cend = qa.start[xcd + 1];
     if (info && *info != 0) {  // an earlier pivot failed: abandon, but keep the queue arithmetic exact
-        if (qa.use_queue && tid == 0 && li == 0) atomicAdd(queue + 8 * xcd, (unsigned long long)(cend - cbeg));
+        if (qa.use_queue && tid == 0 && li == 0) {
+            atomicAdd(queue + 8 * xcd, (unsigned long long)(cend - cbeg));
+            if (flags & GEMM_PHASE_LOCK) atomicAdd(queue + 8 * xcd + 1, (unsigned long long)(cend - cbeg));
+        }
         return;
     }
 
@@ -126,6 +133,21 @@ __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __rest
         if constexpr (VARIANT & 128) tk0 = wall_clock64();
         if (t >= cend) break;
         if constexpr (VARIANT & 128) tk_n += 1;
+        if ((flags & GEMM_PHASE_LOCK) && qa.use_queue) {
+            // wait (bounded: ~17 ms, then go anyway) until the earlier rounds' tiles have left their K loops
+            if (tid == 0) {
+                const long long r = (t - cbeg) / nloc;
+                if (r > 0) {
+                    const unsigned long long target = qa.done_base[xcd] + (unsigned long long)(r * nloc);
+                    int spins = 0;
+                    while (__hip_atomic_load(queue + 8 * xcd + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && spins < 20000) {
+                        __builtin_amdgcn_s_sleep(32);
+                        ++spins;
+                    }
+                }
+            }
+            __syncthreads();
+        }
         int ti, tj;
         const int64_t bi = t / qa.tiles_per;  // 0 unless batched
         tile_decode(t - bi * qa.tiles_per, shape, &ti, &tj);
@@ -314,7 +336,10 @@ __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __rest
                 }
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs above the barrier (they are what hides the DMA)
-            if (last && tid == 0) s_tile = (long long)(pulled - qa.base[xcd]) + cbeg + nloc;
+            if (last && tid == 0) {
+                s_tile = (long long)(pulled - qa.base[xcd]) + cbeg + nloc;
+                if ((flags & GEMM_PHASE_LOCK) && qa.use_queue) atomicAdd(queue + 8 * xcd + 1, 1ull);  // this tile's K loop is over
+            }
             __syncthreads();  // (a) next slab has landed for everyone  (b) everyone is done reading `cur`  (c) s_tile
         }
         if (kbeg >= nk && qa.use_queue) {  // (no slab at all: cannot happen for the shapes launched, kept for safety)
@@ -451,6 +476,7 @@ static void launch_persistent_ni(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, i
     // small launches: one workgroup per tile (rounded up to a multiple of 8 so XCD chunks stay contiguous)
     const int grid = (int)std::min<int64_t>(slots, (ntiles + 7) / 8 * 8);
     unsigned long long* const qbase = side ? ctx->queue_base_side : ctx->queue_base;
+    unsigned long long* const dbase = side ? ctx->done_base_side : ctx->done_base;
     QueueArgs qa;
     qa.use_queue = ntiles > grid;
     qa.tiles_per = tiles_per;
@@ -463,6 +489,8 @@ static void launch_persistent_ni(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, i
         // (chunk - nloc) successful pulls + one failing pull per workgroup (or `chunk` failing pulls when
         // the chunk is smaller than the XCD's workgroup count): the word advances by `chunk` either way
         if (qa.use_queue) qbase[x] += (unsigned long long)(qa.start[x + 1] - qa.start[x]);
+        qa.done_base[x] = dbase[x];
+        if (qa.use_queue && (flags & GEMM_PHASE_LOCK)) dbase[x] += (unsigned long long)(qa.start[x + 1] - qa.start[x]);
     }
     static const bool no_pair16 = getenv("GPMI_GEMM_NO_PAIR16") != nullptr;  // tools: A/B of the C access width
     if (no_pair16) flags |= GEMM_NO_PAIR16;
@@ -514,6 +542,8 @@ void launch_gemm_shape(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda
     // launches run as narrow tiles and are accounted with the panel), <T, 64, *> every other product.
     const bool narrow = use_narrow_tiles(ctx, M, N, shape, batch);
     const bool trailing = shape.mode && !flags && !narrow;
+    // the trailing update with a long K: phase-lock the tiles of an XCD (operand panels of 128 x K exceed the 4 MB L2 16 at a time)
+    if (trailing && K >= ctx->phase_lock_min_k && ctx->phase_lock_min_k > 0) flags |= GEMM_PHASE_LOCK;
     // algorithmic bytes: every output entry read and written once, the operand panels once (B inside A for the SYRK shape)
     const double entries = shape_entries(M, N, shape) * (batch ? batch->count : 1);
     const bool b_in_a = B >= A && B < A + M * lda;
