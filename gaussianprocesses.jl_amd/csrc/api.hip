@@ -583,6 +583,7 @@ int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
         sscanf(e, "%lld,%lld,%lld", &a, &b, &d);
         c->super_min[0] = a; c->super_min[1] = b; c->super_min[2] = d;
     }
+    if (const char* e = getenv("GPMI_POTRF256")) c->fused_potrf = atoi(e) != 0;
     if (const char* e = getenv("GPMI_PHASE_LOCK")) c->phase_lock_min_k = atoll(e);
     if (const char* e = getenv("GPMI_SUPER_INV")) c->super_inverse = atoi(e) != 0;
     if (const char* e = getenv("GPMI_WHITEN_INV")) c->whiten_by_super_inverse = atoi(e) != 0;

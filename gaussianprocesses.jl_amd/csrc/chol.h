@@ -129,6 +129,10 @@ inline void factor_panel(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, int
 template <typename T>
 inline void factor_panel_diag(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, int64_t k0, int64_t nbk, int* d_info) {
     const int64_t kend = k0 + nbk;
+    if (c->fused_potrf) {  // one launch for the whole block (panel.hip potrf256_kernel)
+        launch_potrf256<T>(c, A + k0 * ld + k0, ld, (int)nbk, linv + (k0 / IB) * IB * IB, invdiag + k0, d_info, k0);
+        return;
+    }
     for (int64_t j0 = k0; j0 < kend; j0 += IB) {
         T* linv_j = linv + (j0 / IB) * IB * IB;
         launch_diag64<T>(c, A + j0 * ld + j0, ld, linv_j, invdiag + j0, d_info, j0);

@@ -112,6 +112,8 @@ struct gpmi_ctx {
     void* sup_ut = nullptr;  int64_t sup_ut_cap = 0;
     void* sup_s = nullptr;   int64_t sup_s_cap = 0;
     int64_t sup_wld = 0;
+    int fused_potrf = 0;                 // GPMI_POTRF256=1: one launch per 256 x 256 diagonal block instead of 4 diag64 + 3 rows64
+                                         // (built and tested; measured neutral to -1 %, so off: profiles/r02_super_sweep.log)
     int super_inverse = 1;               // rows below a super-panel through its explicit inverse (GPMI_SUPER_INV=0: NB-block substitution)
     int whiten_by_super_inverse = 1;     // predict / gradient whitening through the stored super-block inverses (GPMI_WHITEN_INV=0: NB blocks)
     int64_t whiten_super = 1024;         // super-block width of whiten_rows_inv (GPMI_WHITEN_SUPER; 256 = one level)
@@ -239,6 +241,9 @@ enum GemmFlags { GEMM_OVERWRITE = 1 /* C = A B' instead of C -= A B' */, GEMM_KS
 // *info = pivot_base + j + 1.
 template <typename T>
 void launch_diag64(gpmi_ctx* ctx, T* A, int64_t ld, T* linv, T* invdiag, int* info, int64_t pivot_base);
+// the whole nb x nb diagonal block (nb <= 256, multiple of 64) in one launch: L in place, its nb/64 64 x 64 inverses, 1 / L_jj
+template <typename T>
+void launch_potrf256(gpmi_ctx* ctx, T* A, int64_t ld, int nb, T* linv, T* invdiag, int* info, int64_t pivot_base);
 
 // Panel step for the rows below column block j of a panel (Xp, Lp point at the panel's first column k0):
 //   X_j <- (X_j - X[:, 0:K1] Lp[0:64, 0:K1]') Linv'   and, for the first diag_rows rows (Cholesky only),

@@ -71,26 +71,29 @@ __device__ __forceinline__ void store16(const typename Mfma<T>::Acc& acc, T* C, 
 //   3. the off-diagonal blocks of L^-1 follow from  X_ib = -Dinv_i * sum_{t=b}^{i-1} L_it X_tb  on the matrix
 //      cores (16 tiny products, LDS-resident operands);
 // so that every later solve against this block (panel TRSM, whiten!, back-substitution) is a GEMM.
+// LDS pool of the panel kernels, in elements: diag64 needs S + XT + DI + WT + sinv, rows64 two 64 x 65 buffers (a subset)
+constexpr int PANEL_POOL = 2 * 64 * 65 + 64 * 16 + 16 * 17 + 64;
+
+// barrier of a phase that ONE wavefront executes (diag64): LDS operations of a wave complete in issue order, so a fence that
+// keeps the compiler from moving them (and waits for them) is all a single wave needs — and, unlike __syncthreads(), it does
+// not involve the workgroup's other waves, which wait at the phase boundary of the fused kernel (potrf256)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <typename T>
-__global__ __launch_bounds__(256, 2) void diag64_kernel(T* __restrict__ A, int64_t ld, T* __restrict__ Linv,
-                                                    T* __restrict__ invdiag, int* __restrict__ info, int64_t pivot_base) {
-    // Launched with 256 threads of which only wave 0 works: __launch_bounds__(256, 2) is what caps the kernel at 256
-    // registers (with a 64-thread bound the 77 KiB of LDS already limits occupancy and the compiler takes 282), and
-    // under look-ahead the wave must fit beside a 248-register GEMM wave on its SIMD.
-    if (threadIdx.x >= 64) return;
-    if (*info != 0) return;
-    // Under look-ahead this wave shares a SIMD with two GEMM waves that always have an MFMA ready; instruction
-    // arbitration is oldest-first, so without a raised priority the chain crawls (measured: 2 ms instead of 25 us).
-    __builtin_amdgcn_s_setprio(3);
+__device__ __forceinline__ void diag64_body(T* __restrict__ A, int64_t ld, T* __restrict__ Linv, T* __restrict__ invdiag,
+                                            int* __restrict__ info, int64_t pivot_base, T* __restrict__ pool) {
     constexpr int SLD = 65;
-    __shared__ T S[64 * SLD];    // L, row-major
-    __shared__ T XT[64 * SLD];   // XT[n][k] = Linv[k][n]
-    __shared__ T DI[64 * 16];    // DI[16 b + i][c] = (L_bb^-1)[i][c]
-    __shared__ T WT[16 * 17];
-    __shared__ T sinv[64];
-    const int i = threadIdx.x;
+    T* const S = pool;                  // [64 * SLD]  L, row-major
+    T* const XT = S + 64 * SLD;         // [64 * SLD]  XT[n][k] = Linv[k][n]
+    T* const DI = XT + 64 * SLD;        // [64 * 16]   DI[16 b + i][c] = (L_bb^-1)[i][c]
+    T* const WT = DI + 64 * 16;         // [16 * 17]
+    T* const sinv = WT + 16 * 17;       // [64]
+    const int i = threadIdx.x & 63;
     for (int r = 0; r < 64; ++r) S[r * SLD + i] = A[(int64_t)r * ld + i];  // coalesced rows
-    __syncthreads();
+    wave_sync();
     T a[64];
 #pragma unroll
     for (int c = 0; c < 64; ++c) a[c] = S[i * SLD + c];
@@ -123,10 +126,10 @@ __global__ __launch_bounds__(256, 2) void diag64_kernel(T* __restrict__ A, int64
             for (int c = j + 1; c < 16 * b + 16; ++c) a[c] -= lij * bcast_lane<T>(lij, c);
         }
         if (b < 3) {
-            __syncthreads();
+            wave_sync();
 #pragma unroll
             for (int q = 0; q < 16; ++q) PL[i * 17 + q] = a[16 * b + q];
-            __syncthreads();
+            wave_sync();
             for (int ri = b + 1; ri < 4; ++ri)
                 for (int ci = b + 1; ci <= ri; ++ci) {
                     AccP u;
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void diag64_kernel(T* __restrict__ A, int64
                     mma16_nt<T>(u, PL + 16 * ri * 17, 17, PL + 16 * ci * 17, 17, 16, i);
                     store16<T>(u, S + (16 * ri) * SLD + 16 * ci, SLD, T(1), false, i);
                 }
-            __syncthreads();
+            wave_sync();
 #pragma unroll
             for (int ci = b + 1; ci < 4; ++ci) {
                 if (ci <= (i >> 4)) {
@@ -150,13 +153,13 @@ __global__ __launch_bounds__(256, 2) void diag64_kernel(T* __restrict__ A, int64
     }
     invdiag[i] = myinv;
     sinv[i] = myinv;
-    __syncthreads();
+    wave_sync();
 #pragma unroll
     for (int c = 0; c < 64; ++c) {
         S[i * SLD + c] = (c <= i) ? a[c] : T(0);
         XT[i * SLD + c] = T(0);
     }
-    __syncthreads();
+    wave_sync();
     for (int r = 0; r < 64; ++r) A[(int64_t)r * ld + i] = S[r * SLD + i];  // lower triangle = L, strict upper = 0
 
     // ---- 16 x 16 diagonal inverses: lane (b, c) computes column c of (L_bb)^-1 ----------------------------
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void diag64_kernel(T* __restrict__ A, int64
             XT[(16 * b + c) * SLD + 16 * b + q] = x[q];
         }
     }
-    __syncthreads();
+    wave_sync();
     // ---- off-diagonal blocks, by distance from the diagonal ---------------------------------------------
     using Acc = typename Mfma<T>::Acc;
     for (int dist = 1; dist < 4; ++dist) {
@@ -187,15 +190,30 @@ __global__ __launch_bounds__(256, 2) void diag64_kernel(T* __restrict__ A, int64
             for (int t = b; t < ib; ++t)  // W = sum_t L_it X_tb ;  B operand rows n: XT[16 b + n][16 t + k]
                 mma16_nt<T>(w, S + (16 * ib) * SLD + 16 * t, SLD, XT + (16 * b) * SLD + 16 * t, SLD, 16, i);
             store16<T>(w, WT, 17, T(1), true, i);  // WT[n][k] = W[k][n]
-            __syncthreads();
+            wave_sync();
             Acc xacc;
             acc_zero<T>(xacc);
             mma16_nt<T>(xacc, DI + (16 * ib) * 16, 16, WT, 17, 16, i);  // Dinv_i * W
             store16<T>(xacc, XT + (16 * b) * SLD + 16 * ib, SLD, T(-1), true, i);  // XT[16b + n][16 ib + row] = -X[row][n]
-            __syncthreads();
+            wave_sync();
         }
     }
     for (int k = 0; k < 64; ++k) Linv[k * 64 + i] = XT[i * SLD + k];  // Linv[k][n] = XT[n][k]
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void diag64_kernel(T* __restrict__ A, int64_t ld, T* __restrict__ Linv,
+                                                    T* __restrict__ invdiag, int* __restrict__ info, int64_t pivot_base) {
+    // Launched with 256 threads of which only wave 0 works: __launch_bounds__(256, 2) is what caps the kernel at 256
+    // registers (with a 64-thread bound the 77 KiB of LDS already limits occupancy and the compiler takes 282), and
+    // under look-ahead the wave must fit beside a 248-register GEMM wave on its SIMD.
+    if (threadIdx.x >= 64) return;
+    if (*info != 0) return;
+    // Under look-ahead this wave shares a SIMD with two GEMM waves that always have an MFMA ready; instruction
+    // arbitration is oldest-first, so without a raised priority the chain crawls (measured: 2 ms instead of 25 us).
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ T pool[PANEL_POOL];
+    diag64_body<T>(A, ld, Linv, invdiag, info, pivot_base, pool);
 }
 
 // rows64: the panel step for every row below a 64-wide column block j of a 256-wide panel, 64 rows per workgroup.
@@ -205,24 +223,15 @@ __global__ __launch_bounds__(256, 2) void diag64_kernel(T* __restrict__ A, int64
 //                           A_mm -= X_j X_j'                        keeps the next diagonal blocks current
 // All products run on the matrix cores from LDS-resident 64 x 64 operands.  Xp / Lp point at COLUMN k0.
 template <typename T>
-__global__ __launch_bounds__(256, 2) void rows64_kernel(T* __restrict__ Xp, int64_t ldx, int64_t M, int K1,
-                                                     const T* __restrict__ Lp, int64_t ldl, const T* __restrict__ Linv,
-                                                     int64_t diag_rows, const int* __restrict__ info, int refine) {
-    if (info && *info != 0) return;
-    __builtin_amdgcn_s_setprio(3);  // see diag64_kernel
+__device__ __forceinline__ void rows64_block(T* __restrict__ Xp, int64_t ldx, int64_t M, int K1, const T* __restrict__ Lp, int64_t ldl,
+                                             const T* __restrict__ Linv, int64_t diag_rows, int refine, int64_t row0,
+                                             T* __restrict__ buf1, T* __restrict__ buf2) {
     using MF = Mfma<T>;
     using Acc = typename MF::Acc;
     constexpr int LD = 65;
     constexpr int KS = 32, KLD = 33;
-    __shared__ T buf1[64 * LD];
-    __shared__ T buf2[64 * LD];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv >> 1, wn = wv & 1;
-    // one 64-row block per workgroup, or — when the launch is capped to the slots the persistent update leaves free
-    // (chol.h: beside_update) — a grid-stride walk over the row blocks
-    const int64_t nblk = (M + 63) / 64;
-    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    const int64_t row0 = blk * 64;
 
     Acc acc[2][2];
 #pragma unroll
@@ -376,6 +385,61 @@ __global__ __launch_bounds__(256, 2) void rows64_kernel(T* __restrict__ Xp, int6
             }
     }
     __syncthreads();  // the next row block reuses buf1 / buf2
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void rows64_kernel(T* __restrict__ Xp, int64_t ldx, int64_t M, int K1,
+                                                     const T* __restrict__ Lp, int64_t ldl, const T* __restrict__ Linv,
+                                                     int64_t diag_rows, const int* __restrict__ info, int refine) {
+    if (info && *info != 0) return;
+    __builtin_amdgcn_s_setprio(3);  // see diag64_kernel
+    __shared__ T pool[2 * 64 * 65];
+    // one 64-row block per workgroup, or — when the launch is capped to the slots the persistent update leaves free
+    // (chol.h: beside_update) — a grid-stride walk over the row blocks
+    const int64_t nblk = (M + 63) / 64;
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x)
+        rows64_block<T>(Xp, ldx, M, K1, Lp, ldl, Linv, diag_rows, refine, blk * 64, pool, pool + 64 * 65);
+}
+
+// out-of-line copies for the fused kernel: each phase keeps its own register allocation (inlined into one loop body the two
+// phases spilled 132 VGPRs)
+template <typename T>
+__device__ __noinline__ void diag64_call(T* A, int64_t ld, T* Linv, T* invdiag, int* info, int64_t pivot_base, T* pool) {
+    diag64_body<T>(A, ld, Linv, invdiag, info, pivot_base, pool);
+}
+template <typename T>
+__device__ __noinline__ void rows64_call(T* Xp, int64_t ldx, int64_t M, int K1, const T* Lp, int64_t ldl, const T* Linv, int64_t diag_rows,
+                                         int refine, int64_t row0, T* buf1, T* buf2) {
+    rows64_block<T>(Xp, ldx, M, K1, Lp, ldl, Linv, diag_rows, refine, row0, buf1, buf2);
+}
+
+// potrf256: the WHOLE factorisation of one nb x nb diagonal block (nb <= 256, a multiple of 64) in ONE launch — what was a
+// chain of 4 diag64 + 3 rows64 launches (~0.2 ms alone, ~1 ms beside the trailing update: every launch pays the contended
+// dispatch and its own load phases).  One workgroup: per 64 columns wave 0 factors and inverts the diagonal block
+// (diag64_body) while the other waves wait at the phase barrier, then all four waves run the rows64 step for the row
+// blocks below inside the block.  Results travel between the phases through global memory (the 512 KiB block is L2
+// resident): __threadfence() + barrier between phases.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void potrf256_kernel(T* __restrict__ A, int64_t ld, int nb, T* __restrict__ Linv,
+                                                      T* __restrict__ invdiag, int* __restrict__ info, int64_t pivot_base, int refine) {
+    if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ T pool[PANEL_POOL];
+    const int nsub = nb / 64;
+    for (int j = 0; j < nsub; ++j) {
+        if (threadIdx.x < 64)
+            diag64_call<T>(A + (int64_t)(64 * j) * ld + 64 * j, ld, Linv + (int64_t)j * 64 * 64, invdiag + 64 * j, info, pivot_base + 64 * j, pool);
+        __threadfence();
+        __syncthreads();
+        if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;  // uniform: read after the barrier
+        const int M = nb - 64 * (j + 1);
+        if (M > 0) {
+            T* Xp = A + (int64_t)(64 * (j + 1)) * ld;   // rows below, at the panel's first column
+            for (int r0 = 0; r0 < M; r0 += 64)
+                rows64_call<T>(Xp, ld, M, 64 * j, A + (int64_t)(64 * j) * ld, ld, Linv + (int64_t)j * 64 * 64, M, refine, r0, pool, pool + 64 * 65);
+            __threadfence();
+            __syncthreads();
+        }
     }
 }
 
@@ -851,6 +915,13 @@ void launch_place_inv_blocks(gpmi_ctx* ctx, const T* l256, T* LW, T* LWT, int64_
 }
 
 template <typename T>
+void launch_potrf256(gpmi_ctx* ctx, T* A, int64_t ld, int nb, T* linv, T* invdiag, int* info, int64_t pivot_base) {
+    ProfScope ps(ctx, GPMI_PROF_PANEL, 2.0 * (double)nb * nb * nb / 3.0);
+    hipLaunchKernelGGL(potrf256_kernel<T>, dim3(1), dim3(256), 0, ctx->stream, A, ld, nb, linv, invdiag, info, pivot_base,
+                       ctx->refine_solves ? 1 : 0);
+}
+
+template <typename T>
 void launch_diag64(gpmi_ctx* ctx, T* A, int64_t ld, T* linv, T* invdiag, int* info, int64_t pivot_base) {
     ProfScope ps(ctx, GPMI_PROF_PANEL, 2.0 * 64.0 * 64.0 * 64.0 / 3.0);
     hipLaunchKernelGGL(diag64_kernel<T>, dim3(1), dim3(256), 0, ctx->stream, A, ld, linv, invdiag, info, pivot_base);
@@ -915,6 +986,7 @@ void launch_logdiag(gpmi_ctx* ctx, const T* A, int64_t ld, int64_t nrows, int64_
 
 #define INST(T)                                                                                                   \
     template void launch_diag64<T>(gpmi_ctx*, T*, int64_t, T*, T*, int*, int64_t);                                \
+    template void launch_potrf256<T>(gpmi_ctx*, T*, int64_t, int, T*, T*, int*, int64_t);                         \
     template void launch_rows64<T>(gpmi_ctx*, T*, int64_t, int64_t, int, const T*, int64_t, const T*, int64_t,    \
                                    const int*);                                                                   \
     template void launch_rows256<T>(gpmi_ctx*, T*, int64_t, int64_t, int, const T*, int64_t, const T*, const int*); \

@@ -23,6 +23,9 @@ for n, m in sizes:
     t2 = time.perf_counter(); gp.update_mll(); t3 = time.perf_counter()
     mu, var = gp.predict_f(xs); t4 = time.perf_counter()
     flops = 2.0 * n * m * m  # whitening n m^2 + SYRK n m^2
+    t5 = time.perf_counter(); gp.update_dmll(); t6 = time.perf_counter()   # first call allocates two more n x m buffers
+    t7 = time.perf_counter(); gp.update_dmll(); t8 = time.perf_counter()
+    print(f"N={n} M={m}: update_dmll {t8 - t7:.3f} s (first call incl. allocation {t6 - t5:.3f} s), |dmll|_inf {np.abs(gp.dmll).max():.4e}", flush=True)
     print(f"N={n} M={m}: first fit incl. alloc/upload {t1 - t0:.3f} s, update_mll {t3 - t2:.3f} s ({flops / (t3 - t2) / 1e12:.1f} TFLOP/s on 2 n m^2), "
           f"predict_f(1024) {1e3 * (t4 - t3):.1f} ms, mll {gp.mll:.6f}", flush=True)
     if n * m <= 2 ** 28:  # host check of alpha = (Kfu Kuu^-1 Kuf + Lambda)^-1 r through matrix-free products
