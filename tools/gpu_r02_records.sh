@@ -13,3 +13,4 @@ head -8 gpurun_out/kernel_stats.csv | cut -c1-200
 rm -rf gpurun_out/prof_end
 bash tools/gpu_pmc_bench.sh > gpurun_out/pmc_bench.log 2>&1; tail -2 gpurun_out/pmc_bench.log
 rm -rf gpurun_out/pmc_bench
+timeout 600 python tools/fitc_bench.py 1000000x4096 2>&1 | grep -v amdgpu > gpurun_out/fitc_c5.log; cat gpurun_out/fitc_c5.log
