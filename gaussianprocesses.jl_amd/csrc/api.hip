@@ -524,10 +524,11 @@ static int super_factor_t(gpmi_ctx* c, T* blk, int64_t ld, int64_t w, T* linv, T
 template <typename T>
 static int super_rows_t(gpmi_ctx* c, T* X, int64_t ldx, int64_t M, int64_t w, const T* lw) {
     int rc;
-    if ((rc = grow(c, &c->sup_s, &c->sup_s_cap, M * w * (int64_t)sizeof(T)))) return rc;
+    const int64_t lds = w + IB;  // never a 4 KiB-multiple row stride
+    if ((rc = grow(c, &c->sup_s, &c->sup_s_cap, M * lds * (int64_t)sizeof(T)))) return rc;
     T* S = (T*)c->sup_s;
-    launch_gemm_shape<T>(c, S, w, X, ldx, lw, w, M, w, w, TileShape{0, 0, 0, 0, 1, 0}, c->d_info, GEMM_OVERWRITE | GEMM_KEND_COL | GEMM_AUX);
-    GPMI_HIP(c, hipMemcpy2DAsync(X, (size_t)ldx * sizeof(T), S, (size_t)w * sizeof(T), (size_t)w * sizeof(T), (size_t)M, hipMemcpyDeviceToDevice,
+    launch_gemm_shape<T>(c, S, lds, X, ldx, lw, w, M, w, w, TileShape{0, 0, 0, 0, 1, 0}, c->d_info, GEMM_OVERWRITE | GEMM_KEND_COL | GEMM_AUX);
+    GPMI_HIP(c, hipMemcpy2DAsync(X, (size_t)ldx * sizeof(T), S, (size_t)lds * sizeof(T), (size_t)w * sizeof(T), (size_t)M, hipMemcpyDeviceToDevice,
                                  c->stream));
     return GPMI_OK;
 }

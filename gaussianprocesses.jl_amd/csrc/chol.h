@@ -243,9 +243,10 @@ inline void rows_below_super(gpmi_ctx* c, T* A, int64_t ld, const T* linv, int64
     const int64_t M = Mtot - ke, w = ke - ks;
     if (LW) {
         T* S = (T*)c->sup_s;
-        launch_gemm_shape<T>(c, S, w, A + ke * ld + ks, ld, LW, wld, M, w, w, TileShape{0, 0, 0, 0, 1, 0}, d_info,
+        const int64_t lds = w + IB;  // never a 4 KiB-multiple row stride (w * 8 B = 16 KiB would park the stores on a few channels)
+        launch_gemm_shape<T>(c, S, lds, A + ke * ld + ks, ld, LW, wld, M, w, w, TileShape{0, 0, 0, 0, 1, 0}, d_info,
                              GEMM_OVERWRITE | GEMM_KEND_COL | GEMM_AUX);
-        (void)hipMemcpy2DAsync(A + ke * ld + ks, (size_t)ld * sizeof(T), S, (size_t)w * sizeof(T), (size_t)w * sizeof(T), (size_t)M,
+        (void)hipMemcpy2DAsync(A + ke * ld + ks, (size_t)ld * sizeof(T), S, (size_t)lds * sizeof(T), (size_t)w * sizeof(T), (size_t)M,
                                hipMemcpyDeviceToDevice, c->stream);
         return;
     }
@@ -266,7 +267,7 @@ inline int super_scratch(gpmi_ctx* c, int64_t wmax, int64_t mrows) {
     if ((rc = grow(c, &c->sup_lwt, &c->sup_lwt_cap, wmax * (wmax + IB) * (int64_t)sizeof(T)))) return rc;
     if ((rc = grow(c, &c->sup_l256, &c->sup_l256_cap, wmax * NB * (int64_t)sizeof(T)))) return rc;
     if ((rc = grow(c, &c->sup_ut, &c->sup_ut_cap, (wmax / 2) * (wmax / 2) * (int64_t)sizeof(T)))) return rc;
-    if ((rc = grow(c, &c->sup_s, &c->sup_s_cap, mrows * wmax * (int64_t)sizeof(T)))) return rc;
+    if ((rc = grow(c, &c->sup_s, &c->sup_s_cap, mrows * (wmax + IB) * (int64_t)sizeof(T)))) return rc;
     c->sup_wld = wmax + IB;
     return GPMI_OK;
 }
