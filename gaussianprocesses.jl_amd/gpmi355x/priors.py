@@ -141,11 +141,16 @@ class NoiseParam:
     same four functions apply:  set_priors(gp.noise_param, [Normal(-1.0, 0.5)])."""
 
     def __init__(self, gp):
-        self._gp = gp
+        # a WEAK reference: the GP owns this view, and a strong reference back would put every GP into a reference cycle —
+        # its device buffers (tens of GB) would then live until the cyclic collector happens to run instead of being
+        # released when the last reference goes
+        import weakref
+
+        self._gp = weakref.ref(gp)
         self.priors = []
 
     def get_params(self):
-        return [float(v) for v in np.atleast_1d(self._gp.logNoise)]
+        return [float(v) for v in np.atleast_1d(self._gp().logNoise)]
 
     def num_params(self):
         return len(self.get_params())

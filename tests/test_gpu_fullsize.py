@@ -9,6 +9,7 @@ in the test budget, so it is checked through size-independent properties of the 
     predict       sigma2 in [0, k(x,x)], mu finite; at training inputs mu ~ y (test/gp.jl:47-50)
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -160,7 +161,13 @@ def test_f3_packed_n220000_fp64_on_one_device_block_diagonal():
     underflows to 0.0 across clusters), so mll, alpha and the predictions of the full factorisation — which does all
     N^3 / 3 flops, knows nothing of the zeros, and whose 1024-row blocks and 8192-row stripes straddle the 1000-point
     clusters — must equal those of 220 independent 1000-point GPs, which the oracle computes in seconds."""
-    nc, m, d = 220, 1000, 2
+    import gc
+
+    import torch
+
+    gc.collect()                  # 205 GB: everything earlier tests left behind has to be gone
+    torch.cuda.empty_cache()
+    nc, m, d = int(os.environ.get("GPMI_F3_CLUSTERS", "220")), 1000, 2
     n = nc * m
     rng = np.random.default_rng(42)
     x = rng.uniform(0.0, 1.0, size=(d, n))
@@ -170,6 +177,7 @@ def test_f3_packed_n220000_fp64_on_one_device_block_diagonal():
     ln = math.log(0.1)
     gp = g.GP(x, y, g.MeanZero(), g.from_spec(spec), ln, packed=True)
     assert gp.nobs == n and len(gp.S.items) > 20
+    print(f"[f3] N = {n}: packed factor {gp.S.nbytes_rows * 8 / 1e9:.1f} GB in {len(gp.S.items)} stripes, mll {gp.mll:.6f}")
     packed_bytes = gp.S.nbytes_rows * 8
     assert packed_bytes < 0.56 * 8.0 * n * n, packed_bytes          # the full square would be 387 GB: it does not fit
     # reference: the clusters one by one
@@ -180,7 +188,7 @@ def test_f3_packed_n220000_fp64_on_one_device_block_diagonal():
         ref = G.update_mll(spec, x[:, sl], y[sl], ln)
         mll_ref += ref["mll"]
         alpha_ref[sl] = ref["alpha"]
-        if c in (0, 57, 219):
+        if c in (0, 57, nc - 1):
             refs[c] = ref
     assert gp.mll == pytest.approx(mll_ref, rel=1e-9)
     np.testing.assert_allclose(gp.alpha, alpha_ref, rtol=1e-6, atol=1e-8 * np.abs(alpha_ref).max())

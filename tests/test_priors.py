@@ -89,3 +89,24 @@ def test_gpe_prior_terms_follow_the_parameter_switches():
     np.testing.assert_allclose(gp.prior_gradlogpdf(kern=False), full[:2], rtol=1e-13)
     gp.logNoise = -0.7  # the noise view reads the live value
     assert gp.prior_gradlogpdf()[0] == pytest.approx(-(-0.7 + 1.0) / 0.25)
+
+
+def test_a_gp_is_not_kept_alive_by_its_noise_parameter_view():
+    """gp.noise_param must not hold the GP strongly: a reference cycle would keep the device buffers of every model alive
+    until the cyclic collector runs (the full GPU suite ran out of HBM that way)."""
+    import gc
+    import weakref
+
+    class _GP:
+        logNoise = -1.0
+
+    gc.disable()
+    try:
+        gp = _GP()
+        gp._noise_param = g.priors.NoiseParam(gp) if hasattr(g, "priors") else __import__("gpmi355x.priors", fromlist=["NoiseParam"]).NoiseParam(gp)
+        assert gp._noise_param.get_params() == [-1.0]
+        r = weakref.ref(gp)
+        del gp
+        assert r() is None  # freed by reference counting alone
+    finally:
+        gc.enable()

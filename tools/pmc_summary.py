@@ -27,23 +27,25 @@ if out.get("FETCH_SIZE_KiB_avg") and out.get("WRITE_SIZE_KiB_avg"):
     out["read_bytes_corrected"] = rd
     out["write_bytes"] = wr
     out["traffic_bytes_per_launch"] = rd + wr
-# the kernel build (cov!): bytes per FIT of the two covariance kernels' big launches (the N x N assembly: launches that write
-# more than 64 MiB), for the HBM GB/s of the memory-bound stage
+# the kernel build (cov!): bytes of the covariance kernels per fit + predict (the N x N assembly by cov_fast_kernel + cov_kernel
+# and the K*' rows of predict), for the HBM GB/s of the memory-bound stage; fits = big cov_fast launches
 cov = {}
+fits = 0
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-    per = {}
+    tot = 0.0
     for f in glob.glob(os.path.join(root, counter, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             name = row.get("Kernel_Name", "")
             if ("cov_fast_kernel" in name or "cov_kernel<" in name) and row.get("Counter_Name") == counter:
-                per[row.get("Dispatch_Id")] = per.get(row.get("Dispatch_Id"), 0.0) + float(row["Counter_Value"])
-    cov[counter] = per
-big = [d for d, v in cov.get("WRITE_SIZE", {}).items() if v * 1024.0 > 64 * 2 ** 20]
-if big:
-    nfits = max(1, len(big) // 2)  # one cov_fast + one cov_kernel launch per fit
-    out["cov_fits"] = nfits
-    out["cov_write_bytes_per_fit"] = sum(cov["WRITE_SIZE"][d] for d in big) * 1024.0 / nfits
-    out["cov_read_bytes_per_fit_corrected"] = 2.0 * sum(cov["FETCH_SIZE"].get(d, 0.0) for d in big) * 1024.0 / nfits
+                v = float(row["Counter_Value"]) * 1024.0
+                tot += v
+                if counter == "WRITE_SIZE" and "cov_fast_kernel" in name and v > 2 ** 30:
+                    fits += 1
+    cov[counter] = tot
+if fits:
+    out["cov_fits"] = fits
+    out["cov_write_bytes_per_fit"] = cov["WRITE_SIZE"] / fits
+    out["cov_read_bytes_per_fit_corrected"] = 2.0 * cov["FETCH_SIZE"] / fits
 if out.get("SQ_VALU_MFMA_BUSY_CYCLES_avg") and out.get("GRBM_GUI_ACTIVE_avg"):
     # GRBM_GUI_ACTIVE is summed over the 8 XCDs; the chip has 256 CUs x 4 SIMDs whose MFMA pipes each count busy cycles
     cycles = out["GRBM_GUI_ACTIVE_avg"] / 8.0
