@@ -309,7 +309,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        import datetime
+
+        # a collective that never completes becomes an error after 10 minutes instead of a hang until the caller's limit
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=10))
 
     import gpmi355x as g
 

@@ -294,6 +294,23 @@ static int fit_t(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int
 }
 
 // gradient of the mll with respect to the kernel hyper-parameters and log-noise (update_dmll!, GPE.jl:298-324)
+// the gradient / predict_LOO scratch: two more npad x ld matrices (L^-T rows and K^-1), kept until gpmi_gp_destroy.  They
+// triple the model's footprint — N = 150 000 fp64 would need 540 GB — so failure here gets a message of its own.
+static int alloc_grad_scratch(gpmi_gp* gp, size_t bytes) {
+    gpmi_ctx* c = gp->ctx;
+    for (void** p : {&gp->g1, &gp->g2}) {
+        if (*p) continue;
+        if (hipMalloc(p, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            *p = nullptr;
+            c->err = "update_dmll / predict_LOO need two more N x N device matrices (" + std::to_string(2 * bytes >> 30) +
+                     " GiB at this size) next to the factor: out of device memory";
+            return GPMI_EDEVICE;
+        }
+    }
+    return GPMI_OK;
+}
+
 // the column ranges of the factor that still have their explicit super-block inverse from the last fit (chol.h)
 template <typename T>
 static std::vector<WhitenSeg<T>> whiten_segments(const gpmi_gp* gp) {
@@ -317,8 +334,7 @@ static int grad_t(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, do
         return GPMI_EARG;
     }
     const size_t bytes = (size_t)(npad * ld) * sizeof(T);
-    if (!gp->g1) GPMI_HIP(c, hipMalloc(&gp->g1, bytes));
-    if (!gp->g2) GPMI_HIP(c, hipMalloc(&gp->g2, bytes));
+    if (const int rc_g = alloc_grad_scratch(gp, bytes)) return rc_g;
     T* G1 = (T*)gp->g1;
     T* G2 = (T*)gp->g2;
     const int64_t nt = (n + 63) / 64;
@@ -359,8 +375,7 @@ static int inv_diag_t(gpmi_gp* gp, void* out) {
     const int64_t n = gp->n, npad = gp->npad, ld = gp->ld;
     la_reset(c);
     const size_t bytes = (size_t)(npad * ld) * sizeof(T);
-    if (!gp->g1) GPMI_HIP(c, hipMalloc(&gp->g1, bytes));
-    if (!gp->g2) GPMI_HIP(c, hipMalloc(&gp->g2, bytes));
+    if (const int rc_g = alloc_grad_scratch(gp, bytes)) return rc_g;
     T* G1 = (T*)gp->g1;
     T* G2 = (T*)gp->g2;
     launch_set_identity<T>(c, G2, ld, npad);
@@ -533,6 +548,12 @@ static int super_rows_t(gpmi_ctx* c, T* X, int64_t ldx, int64_t M, int64_t w, co
     return GPMI_OK;
 }
 
+// GPMI_EARG with a message of its own (gpmi_last_error must never return the text of an unrelated earlier failure)
+static int earg(gpmi_ctx* c, const char* msg) {
+    if (c) c->err = msg;
+    return GPMI_EARG;
+}
+
 extern "C" {
 
 const char* gpmi_version(void) { return "gpmi 0.1 (gfx950)"; }
@@ -609,7 +630,7 @@ void gpmi_ctx_destroy(gpmi_ctx* c) {
     for (auto e : c->ev_pool) hipEventDestroy(e);
     for (auto e : c->la_events) hipEventDestroy(e);
     if (c->side_stream) hipStreamDestroy(c->side_stream);
-    for (void* p : {c->sup_lw, c->sup_lwt, c->sup_l256, c->sup_ut, c->sup_s})
+    for (void* p : {c->sup_lw, c->sup_lwt, c->sup_l256, c->sup_ut, c->sup_s, c->dev_noise})
         if (p) hipFree(p);
     if (c->d_prog) hipFree(c->d_prog);
     if (c->h_prog) hipHostFree(c->h_prog);
@@ -625,7 +646,7 @@ void gpmi_ctx_destroy(gpmi_ctx* c) {
 const char* gpmi_last_error(gpmi_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
 int gpmi_gp_create(gpmi_ctx* c, int dtype, int d, int64_t n, const void* x, gpmi_gp** out) {
-    if (!c) return GPMI_EARG;
+    if (!c) return earg(c, "gpmi_gp_create: bad argument");
     if (!out || !x || (dtype != 64 && dtype != 32) || d <= 0 || d > MAX_D || n <= 0) {
         c->err = "gpmi_gp_create: bad argument (dtype must be 64|32, 1 <= d <= 64, n >= 1)";
         return GPMI_EARG;
@@ -675,7 +696,7 @@ void gpmi_gp_destroy(gpmi_gp* gp) {
 
 int gpmi_fit(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int64_t n_noise, const void* y_minus_mu,
              double* mll_out, void* alpha_out, int64_t* info_out) {
-    if (!gp) return GPMI_EARG;
+    if (!gp) return earg((gp ? gp->ctx : nullptr), "gpmi_fit: bad argument");
     gpmi_ctx* c = gp->ctx;
     if (info_out) *info_out = 0;
     if (!k || !log_noise || !y_minus_mu || (n_noise != 1 && n_noise != gp->n)) {
@@ -689,7 +710,7 @@ int gpmi_fit(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int64_t
 
 int gpmi_predict(gpmi_gp* gp, const gpmi_kernel* k, int64_t p, const void* xpred, const void* mean_pred, int full_cov,
                  void* mu_out, void* var_out) {
-    if (!gp) return GPMI_EARG;
+    if (!gp) return earg((gp ? gp->ctx : nullptr), "gpmi_predict: bad argument");
     gpmi_ctx* c = gp->ctx;
     if (!k || p <= 0 || !xpred || !mean_pred || !mu_out || !var_out) {
         c->err = "gpmi_predict: bad argument";
@@ -706,7 +727,7 @@ int gpmi_predict(gpmi_gp* gp, const gpmi_kernel* k, int64_t p, const void* xpred
 
 int gpmi_grad(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int64_t n_noise, double* dkern_out, int32_t n_kern,
               double* dnoise_out) {
-    if (!gp) return GPMI_EARG;
+    if (!gp) return earg((gp ? gp->ctx : nullptr), "gpmi_grad: bad argument");
     gpmi_ctx* c = gp->ctx;
     if (!k || !log_noise || !dkern_out) {
         c->err = "gpmi_grad: bad argument";
@@ -735,7 +756,7 @@ int gpmi_grad(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int64_
 
 int gpmi_cov(gpmi_ctx* c, const gpmi_kernel* k, int dtype, int d, int64_t n1, const void* x1, int64_t n2, const void* x2,
              void* out) {
-    if (!c) return GPMI_EARG;
+    if (!c) return earg(c, "gpmi_cov: bad argument");
     if (!k || !x1 || !out || n1 <= 0 || (x2 && n2 <= 0) || (dtype != 64 && dtype != 32)) {
         c->err = "gpmi_cov: bad argument";
         return GPMI_EARG;
@@ -756,7 +777,7 @@ static int need_fit(gpmi_gp* gp, const char* who) {
 int gpmi_solve(gpmi_gp* gp, int64_t nrhs, void* b) {
     int rc = need_fit(gp, "gpmi_solve");
     if (rc) return rc;
-    if (nrhs <= 0 || !b) return GPMI_EARG;
+    if (nrhs <= 0 || !b) return earg((gp ? gp->ctx : nullptr), "gpmi_solve: bad argument");
     GPMI_HIP(gp->ctx, hipSetDevice(gp->ctx->device));
     return gp->dtype == 64 ? solve_t<double>(gp, nrhs, b, true) : solve_t<float>(gp, nrhs, b, true);
 }
@@ -764,13 +785,13 @@ int gpmi_solve(gpmi_gp* gp, int64_t nrhs, void* b) {
 int gpmi_whiten(gpmi_gp* gp, int64_t nrhs, void* b) {
     int rc = need_fit(gp, "gpmi_whiten");
     if (rc) return rc;
-    if (nrhs <= 0 || !b) return GPMI_EARG;
+    if (nrhs <= 0 || !b) return earg((gp ? gp->ctx : nullptr), "gpmi_whiten: bad argument");
     GPMI_HIP(gp->ctx, hipSetDevice(gp->ctx->device));
     return gp->dtype == 64 ? solve_t<double>(gp, nrhs, b, false) : solve_t<float>(gp, nrhs, b, false);
 }
 
 int gpmi_inv_diag(gpmi_gp* gp, void* out) {
-    if (!gp || !out) return GPMI_EARG;
+    if (!gp || !out) return earg((gp ? gp->ctx : nullptr), "gpmi_inv_diag: bad argument");
     int rc = need_fit(gp, "gpmi_inv_diag");
     if (rc != GPMI_OK) return rc;
     hipSetDevice(gp->ctx->device);
@@ -780,7 +801,7 @@ int gpmi_inv_diag(gpmi_gp* gp, void* out) {
 int gpmi_logdet(gpmi_gp* gp, double* out) {
     int rc = need_fit(gp, "gpmi_logdet");
     if (rc) return rc;
-    if (!out) return GPMI_EARG;
+    if (!out) return earg((gp ? gp->ctx : nullptr), "gpmi_logdet: bad argument");
     *out = gp->logdet;
     return GPMI_OK;
 }
@@ -788,7 +809,7 @@ int gpmi_logdet(gpmi_gp* gp, double* out) {
 int gpmi_factor_to_host(gpmi_gp* gp, void* U_out) {
     int rc = need_fit(gp, "gpmi_factor_to_host");
     if (rc) return rc;
-    if (!U_out) return GPMI_EARG;
+    if (!U_out) return earg((gp ? gp->ctx : nullptr), "gpmi_factor_to_host: bad argument");
     gpmi_ctx* c = gp->ctx;
     GPMI_HIP(c, hipSetDevice(c->device));
     const size_t es = gp->dtype == 64 ? 8 : 4;
@@ -816,7 +837,7 @@ int gpmi_factor_diag(gpmi_gp* gp, void* diag_out) {
 }
 
 int gpmi_profile_enable(gpmi_ctx* c, int on) {
-    if (!c) return GPMI_EARG;
+    if (!c) return earg(c, "gpmi_profile_enable: bad argument");
     int rc = drain_profile(c);
     c->prof_on = on != 0;
     for (int i = 0; i < GPMI_PROF_NCLASS; ++i) {
@@ -829,7 +850,7 @@ int gpmi_profile_enable(gpmi_ctx* c, int on) {
 }
 
 int gpmi_profile_get(gpmi_ctx* c, int cls, int64_t* launches, double* total_ms, double* work) {
-    if (!c || cls < 0 || cls >= GPMI_PROF_NCLASS) return GPMI_EARG;
+    if (!c || cls < 0 || cls >= GPMI_PROF_NCLASS) return earg(c, "gpmi_profile_get: bad argument");
     int rc = drain_profile(c);
     if (rc) return rc;
     if (launches) *launches = c->prof_n[cls];
@@ -855,22 +876,22 @@ int gpmi_profile_get_bytes(gpmi_ctx* c, int cls, double* bytes) {
 
 int gpmi_bench_gemm(gpmi_ctx* c, int dtype, int64_t M, int64_t N, int64_t K, int lower, int variant, int iters,
                     double* ms_out) {
-    if (!c || !ms_out || (dtype != 64 && dtype != 32) || M <= 0 || N <= 0 || K <= 0 || iters <= 0 || N > M) return GPMI_EARG;
-    if (K % 64 != 0) return GPMI_EARG;
+    if (!c || !ms_out || (dtype != 64 && dtype != 32) || M <= 0 || N <= 0 || K <= 0 || iters <= 0 || N > M) return earg(c, "gpmi_bench_gemm: bad argument");
+    if (K % 64 != 0) return earg(c, "gpmi_bench_gemm: bad argument");
     GPMI_HIP(c, hipSetDevice(c->device));
     return dtype == 64 ? gemm_bench<double>(c, M, N, K, lower, variant, iters, ms_out)
                        : gemm_bench<float>(c, M, N, K, lower, variant, iters, ms_out);
 }
 
 int gpmi_mfma_peak(gpmi_ctx* c, int dtype, double* tflops_out) {
-    if (!c || !tflops_out || (dtype != 64 && dtype != 32)) return GPMI_EARG;
+    if (!c || !tflops_out || (dtype != 64 && dtype != 32)) return earg(c, "gpmi_mfma_peak: bad argument");
     GPMI_HIP(c, hipSetDevice(c->device));
     return dtype == 64 ? mfma_peak<double>(c, tflops_out) : mfma_peak<float>(c, tflops_out);
 }
 
 /* ---- device-pointer building blocks of the row-block sharded path --------------------------- */
 int gpmi_dev_set_kernel(gpmi_ctx* c, const gpmi_kernel* k, int d, double* kdiag_out) {
-    if (!c || !k) return GPMI_EARG;
+    if (!c || !k) return earg(c, "gpmi_dev_set_kernel: bad argument");
     GPMI_HIP(c, hipSetDevice(c->device));
     int rc = upload_program(c, k, d);
     if (rc == GPMI_OK && kdiag_out) *kdiag_out = c->h_prog->kdiag;
@@ -879,7 +900,7 @@ int gpmi_dev_set_kernel(gpmi_ctx* c, const gpmi_kernel* k, int d, double* kdiag_
 
 int gpmi_dev_assemble(gpmi_ctx* c, int dtype, int d, int64_t n, const void* x_dev, int64_t row_off, int64_t nrows,
                       const double* log_noise, int64_t n_noise, void* A_dev, int64_t ld, int64_t ncols) {
-    if (!c || !x_dev || !A_dev || !log_noise || (n_noise != 1 && n_noise != n) || nrows <= 0) return GPMI_EARG;
+    if (!c || !x_dev || !A_dev || !log_noise || (n_noise != 1 && n_noise != n) || nrows <= 0) return earg(c, "gpmi_dev_assemble: bad argument");
     GPMI_HIP(c, hipSetDevice(c->device));
     double nugget = 0.0;
     double* d_noise = nullptr;
@@ -888,8 +909,12 @@ int gpmi_dev_assemble(gpmi_ctx* c, int dtype, int d, int64_t n, const void* x_de
     } else {
         std::vector<double> nv((size_t)n);
         for (int64_t i = 0; i < n; ++i) nv[(size_t)i] = exp(2.0 * log_noise[i]);
-        GPMI_HIP(c, hipMalloc(&d_noise, (size_t)n * sizeof(double)));
-        GPMI_HIP(c, hipMemcpy(d_noise, nv.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+        // a context buffer, grown once: no allocation / synchronisation / free per call (a shard calls this once per block)
+        const int rc_n = grow(c, &c->dev_noise, &c->dev_noise_cap, n * (int64_t)sizeof(double));
+        if (rc_n) return rc_n;
+        d_noise = (double*)c->dev_noise;
+        GPMI_HIP(c, hipMemcpyAsync(d_noise, nv.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        GPMI_HIP(c, hipStreamSynchronize(c->stream));  // nv is a local: the copy must have left the host before it goes
     }
     const int64_t na = std::max<int64_t>(0, std::min<int64_t>(nrows, n - row_off));
     const int flags = COV_LOWER | COV_NUGGET | COV_PAD_IDENTITY;
@@ -900,16 +925,12 @@ int gpmi_dev_assemble(gpmi_ctx* c, int dtype, int d, int64_t n, const void* x_de
     else
         launch_cov<float>(c, (const float*)x_dev + xoff, na, (const float*)x_dev, n, d, (float*)A_dev, ld, nrows, ncols, flags,
                           nugget, d_noise, row_off);
-    if (d_noise) {
-        GPMI_HIP(c, hipStreamSynchronize(c->stream));
-        hipFree(d_noise);
-    }
     return GPMI_OK;
 }
 
 int gpmi_dev_cov_rows(gpmi_ctx* c, int dtype, int d, int64_t na, const void* xa_dev, int64_t nb, const void* xb_dev,
                       void* C_dev, int64_t ldc, int64_t ncols_total) {
-    if (!c || !xa_dev || !xb_dev || !C_dev || na <= 0 || nb <= 0) return GPMI_EARG;
+    if (!c || !xa_dev || !xb_dev || !C_dev || na <= 0 || nb <= 0) return earg(c, "gpmi_dev_cov_rows: bad argument");
     GPMI_HIP(c, hipSetDevice(c->device));
     if (dtype == 64)
         launch_cov<double>(c, (const double*)xa_dev, na, (const double*)xb_dev, nb, d, (double*)C_dev, ldc, na, ncols_total, 0,
@@ -922,7 +943,7 @@ int gpmi_dev_cov_rows(gpmi_ctx* c, int dtype, int d, int64_t na, const void* xa_
 
 int gpmi_dev_potrf_block(gpmi_ctx* c, int dtype, void* A_dev, int64_t ld, int64_t nb, void* linv_dev, void* invdiag_dev,
                          int64_t pivot_base) {
-    if (!c || !A_dev || !linv_dev || !invdiag_dev || nb <= 0 || nb % IB) return GPMI_EARG;
+    if (!c || !A_dev || !linv_dev || !invdiag_dev || nb <= 0 || nb % IB) return earg(c, "gpmi_dev_potrf_block: bad argument");
     GPMI_HIP(c, hipSetDevice(c->device));
     if (dtype == 64)
         potrf_block<double>(c, (double*)A_dev, ld, nb, (double*)linv_dev, (double*)invdiag_dev, pivot_base, c->d_info);
@@ -933,7 +954,7 @@ int gpmi_dev_potrf_block(gpmi_ctx* c, int dtype, void* A_dev, int64_t ld, int64_
 
 int gpmi_dev_rows_solve(gpmi_ctx* c, int dtype, void* X_dev, int64_t ldx, int64_t M, const void* L_dev, int64_t ldl,
                         const void* linv_dev, int64_t nb) {
-    if (!c || !X_dev || !L_dev || !linv_dev || nb <= 0 || nb % IB) return GPMI_EARG;
+    if (!c || !X_dev || !L_dev || !linv_dev || nb <= 0 || nb % IB) return earg(c, "gpmi_dev_rows_solve: bad argument");
     if (M <= 0) return GPMI_OK;
     GPMI_HIP(c, hipSetDevice(c->device));
     if (dtype == 64)
@@ -988,7 +1009,7 @@ int gpmi_dev_super_rows(gpmi_ctx* c, int dtype, void* X_dev, int64_t ldx, int64_
                        : super_rows_t<float>(c, (float*)X_dev, ldx, M, w, (const float*)lw_dev);
 }
 int gpmi_dev_side_begin(gpmi_ctx* c) {
-    if (!c) return GPMI_EARG;
+    if (!c) return earg(c, "gpmi_dev_side_begin: bad argument");
     if (!c->side_stream || c->lookahead_slots <= 0 || c->beside_update) return GPMI_OK;  // no look-ahead: the section runs in line
     GPMI_HIP(c, hipSetDevice(c->device));
     hipEvent_t e = la_event(c);
@@ -1000,7 +1021,7 @@ int gpmi_dev_side_begin(gpmi_ctx* c) {
     return GPMI_OK;
 }
 int gpmi_dev_side_end(gpmi_ctx* c) {
-    if (!c) return GPMI_EARG;
+    if (!c) return earg(c, "gpmi_dev_side_end: bad argument");
     if (!c->beside_update) return GPMI_OK;
     GPMI_HIP(c, hipSetDevice(c->device));
     c->side_event = la_event(c);
@@ -1011,7 +1032,7 @@ int gpmi_dev_side_end(gpmi_ctx* c) {
     return GPMI_OK;
 }
 int gpmi_dev_side_join(gpmi_ctx* c) {
-    if (!c) return GPMI_EARG;
+    if (!c) return earg(c, "gpmi_dev_side_join: bad argument");
     if (!c->side_pending) return GPMI_OK;
     GPMI_HIP(c, hipSetDevice(c->device));
     GPMI_HIP(c, hipStreamWaitEvent(c->stream, c->side_event, 0));
@@ -1019,7 +1040,7 @@ int gpmi_dev_side_join(gpmi_ctx* c) {
     return GPMI_OK;
 }
 int gpmi_ctx_set_stream(gpmi_ctx* c, void* hip_stream, int use_caller_stream) {
-    if (!c) return GPMI_EARG;
+    if (!c) return earg(c, "gpmi_ctx_set_stream: bad argument");
     if (c->beside_update || c->side_pending) {
         c->err = "gpmi_ctx_set_stream: a side section is open";
         return GPMI_EARG;
@@ -1031,7 +1052,7 @@ int gpmi_ctx_set_stream(gpmi_ctx* c, void* hip_stream, int use_caller_stream) {
 }
 int gpmi_dev_bsolve_block(gpmi_ctx* c, int dtype, const void* Lrows_dev, int64_t ld, int64_t c0, int64_t nb,
                           const void* linv_dev, void* z_dev, void* alpha_dev) {
-    if (!c || !Lrows_dev || !linv_dev || !z_dev || !alpha_dev || nb <= 0 || nb % IB) return GPMI_EARG;
+    if (!c || !Lrows_dev || !linv_dev || !z_dev || !alpha_dev || nb <= 0 || nb % IB) return earg(c, "gpmi_dev_bsolve_block: bad argument");
     GPMI_HIP(c, hipSetDevice(c->device));
     const size_t es = dtype == 64 ? 8 : 4;
     for (int64_t j = nb - IB; j >= 0; j -= IB) {
@@ -1047,7 +1068,7 @@ int gpmi_dev_bsolve_block(gpmi_ctx* c, int dtype, const void* Lrows_dev, int64_t
 
 int gpmi_dev_row_gemv(gpmi_ctx* c, int dtype, const void* R_dev, int64_t ldr, int64_t P, int64_t n, const void* v_dev,
                       const void* add_dev, void* out_dev) {
-    if (!c || !R_dev || !v_dev || !add_dev || !out_dev) return GPMI_EARG;
+    if (!c || !R_dev || !v_dev || !add_dev || !out_dev) return earg(c, "gpmi_dev_row_gemv: bad argument");
     GPMI_HIP(c, hipSetDevice(c->device));
     if (dtype == 64)
         launch_row_gemv<double>(c, (const double*)R_dev, ldr, P, n, (const double*)v_dev, (const double*)add_dev, (double*)out_dev);
@@ -1057,7 +1078,7 @@ int gpmi_dev_row_gemv(gpmi_ctx* c, int dtype, const void* R_dev, int64_t ldr, in
 }
 
 int gpmi_dev_row_var(gpmi_ctx* c, int dtype, const void* R_dev, int64_t ldr, int64_t P, int64_t n, double kdiag, void* out_dev) {
-    if (!c || !R_dev || !out_dev) return GPMI_EARG;
+    if (!c || !R_dev || !out_dev) return earg(c, "gpmi_dev_row_var: bad argument");
     GPMI_HIP(c, hipSetDevice(c->device));
     if (dtype == 64)
         launch_row_var<double>(c, (const double*)R_dev, ldr, P, n, kdiag, (double*)out_dev);
@@ -1067,7 +1088,7 @@ int gpmi_dev_row_var(gpmi_ctx* c, int dtype, const void* R_dev, int64_t ldr, int
 }
 
 int gpmi_dev_logdiag_sum(gpmi_ctx* c, int dtype, const void* A_dev, int64_t ld, int64_t nrows, int64_t col_off, double* out) {
-    if (!c || !A_dev || !out || nrows < 0) return GPMI_EARG;
+    if (!c || !A_dev || !out || nrows < 0) return earg(c, "gpmi_dev_logdiag_sum: bad argument");
     GPMI_HIP(c, hipSetDevice(c->device));
     if (dtype == 64)
         launch_logdiag<double>(c, (const double*)A_dev, ld, nrows, col_off, c->d_scal);
@@ -1080,7 +1101,7 @@ int gpmi_dev_logdiag_sum(gpmi_ctx* c, int dtype, const void* A_dev, int64_t ld, 
 }
 
 int gpmi_dev_info(gpmi_ctx* c, int reset, int64_t* info_out) {
-    if (!c) return GPMI_EARG;
+    if (!c) return earg(c, "gpmi_dev_info: bad argument");
     GPMI_HIP(c, hipSetDevice(c->device));
     if (reset) {
         GPMI_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
@@ -1096,7 +1117,7 @@ int gpmi_dev_info(gpmi_ctx* c, int reset, int64_t* info_out) {
 }
 
 int gpmi_dev_sync(gpmi_ctx* c) {
-    if (!c) return GPMI_EARG;
+    if (!c) return earg(c, "gpmi_dev_sync: bad argument");
     GPMI_HIP(c, hipSetDevice(c->device));
     GPMI_HIP(c, hipStreamSynchronize(c->stream));
     GPMI_HIP(c, hipGetLastError());

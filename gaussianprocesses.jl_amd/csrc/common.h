@@ -112,6 +112,8 @@ struct gpmi_ctx {
     void* sup_ut = nullptr;  int64_t sup_ut_cap = 0;
     void* sup_s = nullptr;   int64_t sup_s_cap = 0;
     int64_t sup_wld = 0;
+    void* dev_noise = nullptr;  // per-point nuggets of gpmi_dev_assemble (grown once)
+    int64_t dev_noise_cap = 0;
     int fused_potrf = 0;                 // GPMI_POTRF256=1: one launch per 256 x 256 diagonal block instead of 4 diag64 + 3 rows64
                                          // (built and tested; measured neutral to -1 %, so off: profiles/r02_super_sweep.log)
     int super_inverse = 1;               // rows below a super-panel through its explicit inverse (GPMI_SUPER_INV=0: NB-block substitution)
