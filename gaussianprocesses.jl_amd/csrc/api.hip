@@ -353,10 +353,26 @@ static int grad_t(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, do
         launch_set_identity<T>(c, G2, ld, npad);
         const auto segs = whiten_segments<T>(gp);
         whiten_rows_inv<T>(c, A, ld, (const T*)gp->linv256, npad, G2, ld, G1, ld, [](int64_t kend) { return kend; }, &segs);
-        // K^-1 = L^-T L^-1 = G1 G1'  (lower tiles; K loop starts at the tile's first row)
-        launch_gemm_shape<T>(c, G2, ld, G1, ld, G1, ld, npad, npad, npad, TileShape{0, 0, 1, 0, 1, 0}, nullptr,
-                             GEMM_OVERWRITE | GEMM_KSTART_ROW);
-        const int64_t nblocks = launch_dmll<T>(c, (const T*)gp->x, n, gp->d, (const T*)gp->alpha, G2, ld, gp->gpart, n_hyp);
+        // K^-1 = L^-T L^-1 = G1 G1'  (lower tiles).  Small n: one product whose K loop starts at the tile's first row (G1 is
+        // upper triangular by rows).  Large n: the K dimension in chunks of 2048 columns — a tile's K loop over the whole
+        // row length streams two 128 x n panels (25 MB each at n = 50 000) through a 4 MB L2, chunked it is the K = 2048
+        // update of the factorisation: chunk c first WRITES the rows that start inside it (rows [k0, k1), K from the tile's
+        // first row), then accumulates onto the k0 x k0 block above them.  The accumulation subtracts, so G2 holds -K^-1.
+        const int64_t WK = c->grad_chunk;
+        const bool chunked = WK > 0 && npad >= 4 * WK;
+        if (!chunked) {
+            launch_gemm_shape<T>(c, G2, ld, G1, ld, G1, ld, npad, npad, npad, TileShape{0, 0, 1, 0, 1, 0}, nullptr,
+                                 GEMM_OVERWRITE | GEMM_KSTART_ROW);
+        } else {
+            for (int64_t k0 = 0; k0 < npad; k0 += WK) {
+                const int64_t kw = std::min<int64_t>(WK, npad - k0), k1 = k0 + kw;
+                launch_gemm_shape<T>(c, G2 + k0 * ld, ld, G1 + k0 * ld + k0, ld, G1 + k0, ld, kw, k1, kw,
+                                     TileShape{0, 0, 1, (int)(k0 / GEMM_BM), 1, 0}, nullptr, GEMM_OVERWRITE | GEMM_NEGOUT | GEMM_KSTART_ROW);
+                if (k0 > 0)
+                    launch_gemm_shape<T>(c, G2, ld, G1 + k0, ld, G1 + k0, ld, k0, k0, kw, TileShape{0, 0, 1, 0, 1, 0}, nullptr, GEMM_AUX);
+            }
+        }
+        const int64_t nblocks = launch_dmll<T>(c, (const T*)gp->x, n, gp->d, (const T*)gp->alpha, G2, ld, gp->gpart, n_hyp, chunked);
         launch_reduce_partials(c, gp->gpart, nblocks, n_hyp + 1, (double*)gp->g1);  // g1 is free again: result vector
     }
     std::vector<double> h((size_t)n_hyp + 1);
@@ -605,6 +621,7 @@ int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
         sscanf(e, "%lld,%lld,%lld", &a, &b, &d);
         c->super_min[0] = a; c->super_min[1] = b; c->super_min[2] = d;
     }
+    if (const char* e = getenv("GPMI_GRAD_CHUNK")) c->grad_chunk = std::max<long long>(0, atoll(e) / NB * NB);
     if (const char* e = getenv("GPMI_POTRF256")) c->fused_potrf = atoi(e) != 0;
     if (const char* e = getenv("GPMI_PHASE_LOCK")) c->phase_lock_min_k = atoll(e);
     if (const char* e = getenv("GPMI_SUPER_INV")) c->super_inverse = atoi(e) != 0;

@@ -116,6 +116,7 @@ struct gpmi_ctx {
     int64_t dev_noise_cap = 0;
     int fused_potrf = 0;                 // GPMI_POTRF256=1: one launch per 256 x 256 diagonal block instead of 4 diag64 + 3 rows64
                                          // (built and tested; measured neutral to -1 %, so off: profiles/r02_super_sweep.log)
+    int64_t grad_chunk = 2048;           // K chunk of the gradient's K^-1 = L^-T L^-1 accumulation (GPMI_GRAD_CHUNK; 0 = one product)
     int super_inverse = 1;               // rows below a super-panel through its explicit inverse (GPMI_SUPER_INV=0: NB-block substitution)
     int whiten_by_super_inverse = 1;     // predict / gradient whitening through the stored super-block inverses (GPMI_WHITEN_INV=0: NB blocks)
     int64_t whiten_super = 1024;         // super-block width of whiten_rows_inv (GPMI_WHITEN_SUPER; 256 = one level)
@@ -235,6 +236,7 @@ void launch_gemm_shape(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda
 enum GemmFlags { GEMM_OVERWRITE = 1 /* C = A B' instead of C -= A B' */, GEMM_KSTART_ROW = 2 /* A[i][k] = 0 for k < i: start K at the tile's first row */,
                  GEMM_KEND_COL = 8 /* B[j][k] = 0 for k > j: end K at the tile's last column */,
                  GEMM_PHASE_LOCK = 64 /* tiles of an XCD start round by round (gemm.hip QueueArgs::done_base) */,
+                 GEMM_NEGOUT = 256 /* with GEMM_OVERWRITE: C = -A B' */,
                  GEMM_AUX = 4 /* no effect on the kernel: account the launch to the panel class, not to the trailing update */,
                  GEMM_NO_PAIR16 = 32 /* tools: 8-byte instead of 16-byte C accesses in fp64 (A/B of the access width) */ };
 
@@ -303,7 +305,7 @@ void launch_set_identity(gpmi_ctx* ctx, T* A, int64_t ld, int64_t n);
 // partial[b][n_hyp] = block b's share of tr(alpha alpha' - Kinv); returns the number of blocks
 template <typename T>
 int64_t launch_dmll(gpmi_ctx* ctx, const T* x, int64_t n, int d, const T* alpha, const T* Kinv, int64_t ld, double* partial,
-                    int n_hyp);
+                    int n_hyp, bool kinv_negated = false);  // kinv_negated: Kinv holds -K^-1
 // the same reduction over the rectangle of pairs (xa_i, xb_j) with an explicit weight matrix Wt (na x nb, ld): FITC gradient;
 // partial[b][0..n_hyp) (slot n_hyp is zero); returns the number of blocks
 template <typename T>

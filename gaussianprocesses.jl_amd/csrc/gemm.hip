@@ -364,7 +364,8 @@ __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __rest
                     for (int r = 0; r < 4; ++r) sacc += acc[mi][ni].v[r];
             if (sacc == T(-1.2345e300)) C[0] = sacc;
         } else {
-            const bool negate = overwrite ? MF::NEG : !MF::NEG;
+            // GEMM_NEGOUT (with OVERWRITE): C = -A B'
+            const bool negate = (overwrite ? MF::NEG : !MF::NEG) != (overwrite && (flags & GEMM_NEGOUT) != 0);
             // the addresses are recomputed from opaque copies: kept alive across the K loop they cost 32 VGPRs (spills)
             int64_t ld2 = ldc;
             int ln2 = lane;

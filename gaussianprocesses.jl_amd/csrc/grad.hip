@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void dmll_kernel(const T* __restrict__ x, int6
         }
         // W_ij and its weight: diagonal entries count half (GPE.jl:228-231), strict lower entries once (:233-238)
         const T kin = valid ? Kinv[grow * ld + gcol] : T(0);
-        const T wij = RECT ? kin : sal[row] * acol - kin;
+        const T wij = RECT ? kin : (nb < 0 ? sal[row] * acol + kin : sal[row] * acol - kin);  // nb < 0: Kinv holds -K^-1
         const T ww = valid ? ((!RECT && grow == gcol) ? T(0.5) * wij : wij) : T(0);
         if (!RECT && valid && grow == gcol) gl[n_hyp * 256 + tid] += (double)wij;  // tr(alpha alpha' - K^-1)
 
@@ -303,8 +303,8 @@ static int64_t launch_dmll_any(gpmi_ctx* ctx, const T* x, int64_t n, int d, cons
 }
 template <typename T>
 int64_t launch_dmll(gpmi_ctx* ctx, const T* x, int64_t n, int d, const T* alpha, const T* Kinv, int64_t ld, double* partial,
-                    int n_hyp) {
-    return launch_dmll_any<T, false>(ctx, x, n, d, alpha, Kinv, ld, partial, n_hyp, x, n);
+                    int n_hyp, bool kinv_negated) {
+    return launch_dmll_any<T, false>(ctx, x, n, d, alpha, Kinv, ld, partial, n_hyp, x, kinv_negated ? -1 : n);
 }
 template <typename T>
 int64_t launch_dmll_rect(gpmi_ctx* ctx, const T* xa, int64_t na, const T* xb, int64_t nb, int d, const T* Wt, int64_t ld,
@@ -318,8 +318,8 @@ void launch_reduce_partials(gpmi_ctx* ctx, const double* partial, int64_t nblock
 
 template void launch_set_identity<double>(gpmi_ctx*, double*, int64_t, int64_t);
 template void launch_set_identity<float>(gpmi_ctx*, float*, int64_t, int64_t);
-template int64_t launch_dmll<double>(gpmi_ctx*, const double*, int64_t, int, const double*, const double*, int64_t, double*, int);
-template int64_t launch_dmll<float>(gpmi_ctx*, const float*, int64_t, int, const float*, const float*, int64_t, double*, int);
+template int64_t launch_dmll<double>(gpmi_ctx*, const double*, int64_t, int, const double*, const double*, int64_t, double*, int, bool);
+template int64_t launch_dmll<float>(gpmi_ctx*, const float*, int64_t, int, const float*, const float*, int64_t, double*, int, bool);
 template int64_t launch_dmll_rect<double>(gpmi_ctx*, const double*, int64_t, const double*, int64_t, int, const double*, int64_t, double*, int);
 template int64_t launch_dmll_rect<float>(gpmi_ctx*, const float*, int64_t, const float*, int64_t, int, const float*, int64_t, double*, int);
 

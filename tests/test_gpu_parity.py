@@ -374,6 +374,28 @@ def test_gradient_synthetic_d8_n3000():
     _close(gp.dmll, ref["dmll"], 1e-6, 1e-8 * np.abs(ref["dmll"]).max(), "dmll")
 
 
+def test_gradient_n9000_chunked_inverse(monkeypatch):
+    """n >= 8192: K^-1 = L^-T L^-1 is accumulated in chunks of 2048 columns of L^-T (api.hip grad_t) — first-touch rows written
+    with the sign flipped, the block above them accumulated — and the trace kernel reads -K^-1.  fp64 against the oracle;
+    fp32 (whose gradient is a difference of O(1e3) terms at this size: ~5 % on its smallest component either way) against the
+    one-product form of the same arithmetic."""
+    x, y, _ = G.synthetic_inputs(9000, 4, p=4)
+    spec = ("sum", ("se_ard", [math.log(0.4), math.log(0.5), math.log(0.6), math.log(0.7)], 0.0), ("mat32_iso", math.log(0.8), -0.5))
+    ln = math.log(0.2)
+    gp = g.GP(x, y, g.MeanZero(), g.from_spec(spec), ln)
+    gp.update_dmll()
+    ref = G.update_dmll(spec, x, y, ln)
+    _close(gp.dmll, ref["dmll"], 1e-6, 1e-8 * np.abs(ref["dmll"]).max(), "dmll")
+    g32 = g.GP(x.astype(np.float32), y, g.MeanZero(), g.from_spec(spec), ln, dtype=np.float32)
+    g32.update_dmll()
+    monkeypatch.setenv("GPMI_GRAD_CHUNK", "0")
+    one = g.GP(x.astype(np.float32), y, g.MeanZero(), g.from_spec(spec), ln, dtype=np.float32, ctx=g.Context(0))
+    one.update_dmll()
+    scale = np.abs(ref["dmll"]).max()
+    _close(g32.dmll, one.dmll, 1e-2, 1e-3 * scale, "fp32 chunked vs one product")
+    _close(g32.dmll, ref["dmll"], 1e-1, 1e-2 * scale, "fp32 vs fp64 oracle")
+
+
 def test_optimize_with_device_gradient_matches_reference_contract():
     """test/optim.jl:20-25 (target improves), :54-82 (switched-off parameter groups stay bit-identical)."""
     x, y, _ = G.synthetic_inputs(400, 2, p=4)

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import gpmi355x as g
 from bench import synthetic_inputs
 
-for n in (5000, 20000):
+for n in (5000, 20000, 50000):
     x, y, xs = synthetic_inputs(n, 8, 16)
     ll = [math.log(0.5) + 0.05 * k for k in range(8)]
     gp = g.GP(x, y, g.MeanZero(), g.SEArd(ll, 0.0), math.log(0.1))
