@@ -104,10 +104,24 @@ inline void whiten_rows_inv(gpmi_ctx* c, const T* A, int64_t ld, const T* linv25
     if (pos < npad) plain_range(pos, npad);
 }
 
+// In-place whitening through the 64 x 64 inverses (the form that carries the refinement step), in two levels like
+// whiten_rows_inv: NB-blocks are grouped into super-blocks of WS = 1024 columns; inside one, block b first receives the
+// products of the super-block's earlier blocks (K = 256 b), then its four rows64 steps; the columns beyond the super-block
+// get ONE update with K = WS.  (FITC's W = Kfu Luu^-T, n = 1e6 rows: the K = 256 updates of the one-level form ran at
+// ~47 TFLOP/s — C traffic — the K = 1024 ones at ~62.)
 template <typename T>
 inline void whiten_rows(gpmi_ctx* c, const T* A, int64_t ld, const T* linv, int64_t npad, T* R, int64_t ldr, int64_t Mr) {
-    for (int64_t k0 = 0; k0 < npad; k0 += NB)
-        rows_block_solve<T>(c, A, ld, linv, npad, R, ldr, Mr, k0, std::min<int64_t>(NB, npad - k0));
+    const int64_t WS = std::max<int64_t>(NB, c->whiten_super);
+    for (int64_t ks = 0; ks < npad; ks += WS) {
+        const int64_t ke = std::min<int64_t>(ks + WS, npad);
+        for (int64_t k0 = ks; k0 < ke; k0 += NB) {
+            const int64_t nbk = std::min<int64_t>(NB, ke - k0);
+            if (k0 > ks) launch_gemm_nt<T>(c, R + k0, ldr, R + ks, ldr, A + k0 * ld + ks, ld, Mr, nbk, k0 - ks, 0, nullptr);
+            for (int64_t j0 = k0; j0 < k0 + nbk; j0 += IB)
+                launch_rows64<T>(c, R + k0, ldr, Mr, (int)(j0 - k0), A + j0 * ld + k0, ld, linv + (j0 / IB) * IB * IB, 0, nullptr);
+        }
+        if (ke < npad) launch_gemm_nt<T>(c, R + ke, ldr, R + ks, ldr, A + ke * ld + ks, ld, Mr, npad - ke, ke - ks, 0, nullptr);
+    }
 }
 
 // Blocked right-looking Cholesky of the row-major lower triangle of A (npad x npad), carrying
