@@ -189,30 +189,6 @@ int upload_program(gpmi_ctx* c, const gpmi_kernel* k, int d) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// device-pointer building blocks (row-block sharded path; also what cholesky_lower is made of)
-// ---------------------------------------------------------------------------------------------
-// in-place factorisation of ONE nb x nb diagonal block (nb multiple of 64); linv gets the nb/64 inverses
-template <typename T>
-static void potrf_block(gpmi_ctx* c, T* A, int64_t ld, int64_t nb, T* linv, T* invdiag, int64_t pivot_base, int* d_info) {
-    for (int64_t j0 = 0; j0 < nb; j0 += IB) {
-        T* linv_j = linv + (j0 / IB) * IB * IB;
-        launch_diag64<T>(c, A + j0 * ld + j0, ld, linv_j, invdiag + j0, d_info, pivot_base + j0);
-        const int64_t r0 = j0 + IB;
-        launch_rows64<T>(c, A + r0 * ld, ld, nb - r0, (int)j0, A + j0 * ld, ld, linv_j, nb - r0, d_info);
-    }
-}
-// X[M x nb] <- X * L^-T against a factored nb x nb block L (ldl) with its stored 64 x 64 inverses
-template <typename T>
-static void rows_solve_block(gpmi_ctx* c, T* X, int64_t ldx, int64_t M, const T* L, int64_t ldl, const T* linv, int64_t nb,
-                             const int* d_info) {
-    if (!c->refine_solves && (M + IB - 1) / IB <= c->num_cus && nb <= NB) {  // one fused launch (see factor_panel_below)
-        launch_rows256<T>(c, X, ldx, M, (int)(nb / IB), L, ldl, linv, d_info);
-        return;
-    }
-    for (int64_t j0 = 0; j0 < nb; j0 += IB)
-        launch_rows64<T>(c, X, ldx, M, (int)j0, L + j0 * ldl, ldl, linv + (j0 / IB) * IB * IB, 0, d_info);
-}
-
 template <typename T>
 static int fit_t(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int64_t n_noise, const void* y_minus_mu,
                  double* mll_out, void* alpha_out, int64_t* info_out) {
@@ -958,28 +934,7 @@ int gpmi_dev_cov_rows(gpmi_ctx* c, int dtype, int d, int64_t na, const void* xa_
     return GPMI_OK;
 }
 
-int gpmi_dev_potrf_block(gpmi_ctx* c, int dtype, void* A_dev, int64_t ld, int64_t nb, void* linv_dev, void* invdiag_dev,
-                         int64_t pivot_base) {
-    if (!c || !A_dev || !linv_dev || !invdiag_dev || nb <= 0 || nb % IB) return earg(c, "gpmi_dev_potrf_block: bad argument");
-    GPMI_HIP(c, hipSetDevice(c->device));
-    if (dtype == 64)
-        potrf_block<double>(c, (double*)A_dev, ld, nb, (double*)linv_dev, (double*)invdiag_dev, pivot_base, c->d_info);
-    else
-        potrf_block<float>(c, (float*)A_dev, ld, nb, (float*)linv_dev, (float*)invdiag_dev, pivot_base, c->d_info);
-    return GPMI_OK;
-}
 
-int gpmi_dev_rows_solve(gpmi_ctx* c, int dtype, void* X_dev, int64_t ldx, int64_t M, const void* L_dev, int64_t ldl,
-                        const void* linv_dev, int64_t nb) {
-    if (!c || !X_dev || !L_dev || !linv_dev || nb <= 0 || nb % IB) return earg(c, "gpmi_dev_rows_solve: bad argument");
-    if (M <= 0) return GPMI_OK;
-    GPMI_HIP(c, hipSetDevice(c->device));
-    if (dtype == 64)
-        rows_solve_block<double>(c, (double*)X_dev, ldx, M, (const double*)L_dev, ldl, (const double*)linv_dev, nb, c->d_info);
-    else
-        rows_solve_block<float>(c, (float*)X_dev, ldx, M, (const float*)L_dev, ldl, (const float*)linv_dev, nb, c->d_info);
-    return GPMI_OK;
-}
 
 int gpmi_dev_update_blocks(gpmi_ctx* c, int dtype, void* C_dev, int64_t ldc, const void* A_dev, int64_t lda, const void* B_dev,
                            int64_t ldb, int64_t M, int64_t N, int64_t K, int mode, int g0, int G, int nstair_tiles, int tpb, int flags) {

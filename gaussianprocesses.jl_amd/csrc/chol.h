@@ -8,20 +8,6 @@
 
 namespace gpmi {
 
-// Solve the block-column [k0, k0+nbk) of a row matrix R (Mr rows) against the already factored diagonal block
-// of A (64-column steps: left-looking update + multiplication by the stored inverse, one launch each), then push
-// the update into R's remaining columns:
-//   R[:, k0:kend] <- R[:, k0:kend] * L_kk^-T ;  R[:, kend:npad] -= R[:, k0:kend] * A[kend:npad, k0:kend]'
-template <typename T>
-inline void rows_block_solve(gpmi_ctx* c, const T* A, int64_t ld, const T* linv, int64_t npad, T* R, int64_t ldr,
-                             int64_t Mr, int64_t k0, int64_t nbk) {
-    const int64_t kend = k0 + nbk;
-    for (int64_t j0 = k0; j0 < kend; j0 += IB)
-        launch_rows64<T>(c, R + k0, ldr, Mr, (int)(j0 - k0), A + j0 * ld + k0, ld, linv + (j0 / IB) * IB * IB, 0, nullptr);
-    if (kend < npad)
-        launch_gemm_nt<T>(c, R + kend, ldr, R + k0, ldr, A + kend * ld + k0, ld, Mr, npad - kend, nbk, 0, nullptr);
-}
-
 // run launches on another stream of the context (the launchers read ctx->stream / ctx->num_cus)
 struct StreamScope {
     gpmi_ctx* c;

@@ -219,13 +219,6 @@ int gpmi_dev_assemble(gpmi_ctx*, int dtype, int d, int64_t n, const void* x_dev,
 /* C[i][j] = k(xa_i, xb_j), columns >= nb zero-filled up to ncols_total (K*' rows of predict, GP.jl:44) */
 int gpmi_dev_cov_rows(gpmi_ctx*, int dtype, int d, int64_t na, const void* xa_dev, int64_t nb, const void* xb_dev,
                       void* C_dev, int64_t ldc, int64_t ncols_total);
-/* in-place Cholesky of one nb x nb diagonal block (nb % 64 == 0); linv gets the nb/64 inverses of
- * its 64 x 64 diagonal blocks (64 x 64 row-major each, contiguous), invdiag gets 1 / L_ii       */
-int gpmi_dev_potrf_block(gpmi_ctx*, int dtype, void* A_dev, int64_t ld, int64_t nb, void* linv_dev, void* invdiag_dev,
-                         int64_t pivot_base);
-/* X[M x nb] <- X * L^-T against a factored diagonal block and its linv (panel solve / whiten!)  */
-int gpmi_dev_rows_solve(gpmi_ctx*, int dtype, void* X_dev, int64_t ldx, int64_t M, const void* L_dev, int64_t ldl,
-                        const void* linv_dev, int64_t nb);
 /* C[M x N] -= A[M x K] B[N x K]'.  mode 0: all tiles; 1: tiles with col <= row; 2: staircase of a
  * block-cyclic shard — local 256-row block i is global block g0 + i*G (relative to C's first
  * column), rows past nstair_tiles*128 are carried rows and get every column.                   */

@@ -59,31 +59,6 @@ class FakeOps:
         Cview.zero_()
         Cview[:, :K.shape[1]] = torch.from_numpy(K).to(self.tdtype)
 
-    def potrf_block(self, blk, linv, invd, pivot_base):
-        if self._info:
-            return
-        a = blk.numpy().astype(np.float64)
-        a = np.tril(a) + np.tril(a, -1).T
-        if not np.all(np.isfinite(a)):
-            self._info = pivot_base + 1
-            return
-        L, info = sla.lapack.dpotrf(a, lower=1, clean=1)
-        if info != 0:
-            self._info = pivot_base + int(info)
-            return
-        blk.copy_(torch.from_numpy(L).to(self.tdtype))
-        invd.copy_(torch.from_numpy(1.0 / np.diag(L)).to(self.tdtype))
-
-    def rows_solve(self, X, L, linv):
-        if self._info or X.shape[0] == 0:
-            return
-        l = np.tril(L.numpy().astype(np.float64))
-        try:
-            sol = sla.solve_triangular(l, X.numpy().astype(np.float64).T, lower=True, check_finite=False).T.copy()
-        except np.linalg.LinAlgError:  # a rank past a failed pivot works on garbage, like the device would (NaNs)
-            sol = np.full(X.shape, np.nan)
-        X.copy_(torch.from_numpy(sol).to(self.tdtype))
-
     def update(self, Cv, Av, Bv, mode, g0=0, G=1, nstair_tiles=0, tpb=2):
         if self._info or Cv.shape[0] == 0 or Cv.shape[1] == 0:
             return
