@@ -60,6 +60,15 @@ int main() {
                         int ntn = tpb * (g0 + (nblk ? (nblk - 1) * G : 0)) + tpb + 3;
                         for (int cut = 0; cut <= 6; cut += 3) { ++cases; bad += check(TileShape{ntm, ntn - cut > 0 ? ntn - cut : 1, 2, g0, G, tpb * nblk, tpb}); }
                     }
+    // the sizes of a real shard: 8 tiles per block, up to 25 local blocks, 8 ranks (N = 200 000 over 8 GPUs)
+    for (int G = 1; G <= 8; G += 7)
+        for (int g0 = 0; g0 <= G; g0 += G)
+            for (int nblk = 20; nblk <= 25; nblk += 5) {
+                int ntm = 8 * nblk + 1;
+                int ntn = 8 * (g0 + (nblk - 1) * G) + 8 + 5;
+                ++cases; bad += check(TileShape{ntm, ntn, 2, g0, G, 8 * nblk, 8});
+                ++cases; bad += check(TileShape{ntm, ntn - 40, 2, g0, G, 8 * nblk, 8});
+            }
     // staircase locality: 8 consecutive tiles at the start of an interior strip share one column
     {
         int a0, b0, a7, b7;
