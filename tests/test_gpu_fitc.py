@@ -118,6 +118,11 @@ GRAD_CASES = [  # (name, spec, d, m): Kuu conditioned 1e3 ... 6e4, where the fp6
     ("mat52+se_d3_m40", ("sum", ("mat52_ard", [-0.6, -0.4, -0.5], 0.1), ("se_iso", -0.2, -0.4)), 3, 40),
     ("prod_rq_d3_m40", ("prod", ("rq_iso", -0.3, 0.1, 0.4), ("mat32_iso", 0.2, -0.1)), 3, 40),
     ("mat32_ard_d2_m60", ("mat32_ard", [-0.9, -0.7], 0.1), 2, 60),
+    # composites whose leaves need the trace kernel's special cases: Noise (isapprox delta, only on the diagonal terms),
+    # Masked + Const under a product, a FixedKernel that exposes three of six parameters
+    ("se+noise_d3_m30", ("sum", ("se_ard", [-0.6, -0.4, -0.5], 0.1), ("noise", -1.5)), 3, 30),
+    ("masked*const_d3_m30", ("prod", ("masked", ("mat52_iso", -0.4, 0.2), (0, 2)), ("const", -0.3)), 3, 30),
+    ("fixed_d3_m30", ("fixed", ("sum", ("mat32_ard", [-0.6, -0.4, -0.5], 0.1), ("rq_iso", -0.2, -0.4, 0.3)), (0, 3, 5)), 3, 30),
 ]
 
 
@@ -132,10 +137,11 @@ def test_fitc_gradient_matches_the_oracle(name, spec, d, m):
     gp.update_dmll()
     ref = G.fitc_update_dmll(spec, x, xu, y, ln, ("const", 0.2))
     scale = np.abs(ref["dmll"]).max()
-    np.testing.assert_allclose(gp.dmll, ref["dmll"], rtol=1e-6, atol=1e-7 * scale)
+    tol = 1e-5 if name.startswith("masked") else 1e-6   # cond(Kuu) = 2e6 there: the literal statement itself is good to 3e-7
+    np.testing.assert_allclose(gp.dmll, ref["dmll"], rtol=tol, atol=0.1 * tol * scale)
     # the switches select the blocks (GPE.jl:298-324)
     gp.update_dmll(noise=False, domean=False)
-    np.testing.assert_allclose(gp.dmll, ref["dkern"], rtol=1e-6, atol=1e-7 * scale)
+    np.testing.assert_allclose(gp.dmll, ref["dkern"], rtol=tol, atol=0.1 * tol * scale)
 
 
 def test_fitc_gradient_when_kuu_is_ill_conditioned():
