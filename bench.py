@@ -124,7 +124,7 @@ def _cpu_fit_predict(n, d, p, ll):
     s2 = np.maximum(1.0 - np.sum(Lck * Lck, axis=0), 0.0)
     t4 = time.perf_counter()
     assert np.isfinite(mll) and np.all(np.isfinite(mu)) and np.all(np.isfinite(s2))
-    return {"cov": t1 - t0, "dpotrf": t2 - t1, "dpotrs_mll": t3 - t2, "predict": t4 - t3}, t4 - t0, mll
+    return {"cov": t1 - t0, "dpotrf": t2 - t1, "dpotrs_mll": t3 - t2, "predict": t4 - t3}, t4 - t0, mll, mu, s2
 
 
 def cpu_baseline(n_bench, d, p, ll, budget_s):
@@ -132,7 +132,7 @@ def cpu_baseline(n_bench, d, p, ll, budget_s):
     Nothing is scaled: `value` is 1 / (measured seconds) of the run named in `sample`."""
     model, blas, nthreads = _host_description()
     probe_n = min(6000, n_bench)
-    st, tot, _ = _cpu_fit_predict(probe_n, d, p, ll)
+    st, tot = _cpu_fit_predict(probe_n, d, p, ll)[:2]
     r = n_bench / probe_n
     est = st["cov"] * r**2 + st["dpotrf"] * r**3 + st["dpotrs_mll"] * r**2 + st["predict"] * r**2
     free_gb = None
@@ -149,8 +149,10 @@ def cpu_baseline(n_bench, d, p, ll, budget_s):
         n_meas = min(20000, n_bench)
         why = (f" (the bench size N={n_bench} was estimated at {est:.0f} s from a N={probe_n} probe / needs {need_gb:.0f} GB of "
                f"host RAM, over the {budget_s:.0f} s budget: measured at N={n_meas} instead — NOT the bench size)")
-    st, tot, mll = _cpu_fit_predict(n_meas, d, p, ll)
+    st, tot, mll, mu, s2 = _cpu_fit_predict(n_meas, d, p, ll)
     return {
+        "_mu": mu,       # popped by main() before printing: the oracle's predictions for the `parity` object
+        "_s2": s2,
         "value": 1.0 / tot,
         "unit": "GP fits/sec",
         "cores": os.cpu_count(),
@@ -196,6 +198,10 @@ def run_workload(g, ctx, n, d, p, dtype, steps, warmup, barrier, comm=None):
         gp = g.GP(x, y, g.MeanZero(), g.SEArd(ll, 0.0), log_noise, dtype=np_dt, ctx=ctx)  # uploads x, first fit
     t_build = time.perf_counter() - t_build0
     base = np.asarray(gp.get_params())
+    # the constructor's fit is at the BASE hyper-parameters — the ones the cpu_baseline oracle run uses: keep its mll and
+    # predictions so that the JSON line carries full-size parity (main(): `parity`)
+    base_mll = gp.mll
+    base_mu, base_s2 = gp.predict_f(xpred)
 
     def step(i):
         gp.set_params(base + 1e-3 * ((i % 7) + 1) * np.where(np.arange(len(base)) == 0, 0.0, 1.0))
@@ -215,7 +221,8 @@ def run_workload(g, ctx, n, d, p, dtype, steps, warmup, barrier, comm=None):
     prof = {name: ctx.profile_get(getattr(g._lib, "PROF_" + name)) for name in ("SYRK", "COV", "PANEL", "SOLVE", "PREDICT")}
     ctx.profile_enable(False)
     assert np.all(np.isfinite(mu)) and np.all(np.isfinite(s2)) and math.isfinite(gp.mll)
-    return {"elapsed": elapsed, "prof": prof, "syrk_bytes": syrk_bytes, "t_build": t_build, "mll": gp.mll, "ll": ll}
+    return {"elapsed": elapsed, "prof": prof, "syrk_bytes": syrk_bytes, "t_build": t_build, "mll": gp.mll, "ll": ll,
+            "base_mll": base_mll, "base_mu": np.asarray(base_mu, dtype=np.float64), "base_s2": np.asarray(base_s2, dtype=np.float64)}
 
 
 def roofline_object(args, res, n, d, p, dtype, steps):
@@ -253,6 +260,132 @@ def stage_object(res, steps):
     }
 
 
+def parity_object(res, cpu, n, dtype):
+    """Full-size parity of THIS line's workload: the device fit at the base hyper-parameters (the constructor's fit and a
+    predict_f on it, run_workload) against the cpu_baseline oracle run at the same N (same inputs, same parameters).
+    north_star's bar: rtol 1e-5 (fp64) / 1e-2 (fp32) on log-mll, posterior mean and variance."""
+    tol = 1e-5 if dtype == "f64" else 1e-2
+    mu_o, s2_o = cpu.pop("_mu", None), cpu.pop("_s2", None)
+    if mu_o is None or cpu.get("n_measured") != n:
+        return {"checked": False, "reason": f"the CPU oracle ran at N={cpu.get('n_measured')}, not at the bench size N={n}"}
+    mu, s2 = res["base_mu"], res["base_s2"]
+    mll_rel = abs(res["base_mll"] - cpu["mll"]) / abs(cpu["mll"])
+    mu_rel = float(np.abs(mu - mu_o).max() / np.abs(mu_o).max())
+    s2_rel = float(np.abs(s2 - s2_o).max() / np.abs(s2_o).max())
+    elem_ok = bool(np.allclose(mu, mu_o, rtol=tol, atol=tol * np.abs(mu_o).max()) and
+                   np.allclose(s2, s2_o, rtol=tol, atol=tol * np.abs(s2_o).max()))
+    return {
+        "checked": True,
+        "against": "cpu_baseline (oracle/gp_oracle + oracle/cov_oracle.c + LAPACK) at the same N, inputs and hyper-parameters",
+        "n": n,
+        "p": int(mu.shape[0]),
+        "tol": tol,
+        "mll_device": res["base_mll"],
+        "mll_oracle": cpu["mll"],
+        "mll_rel_err": mll_rel,
+        "mu_max_err_over_max_abs": mu_rel,
+        "var_max_err_over_max_abs": s2_rel,
+        "ok": bool(mll_rel <= tol and mu_rel <= tol and s2_rel <= tol and elem_ok),
+    }
+
+
+C3_SPEC_NOTE = "Sum(Sum(SEArd, Mat52Iso), Noise)"
+
+
+def run_c3(g, ctx, steps=3):
+    """BASELINE configs[2]: N = 50 000, d = 8, (SEArd + Mat52Iso) + Noise, fp64 — the composite-kernel cov! path."""
+    import gc
+
+    gc.collect()
+    n, d, p = 50000, 8, 1024
+    x, y, xpred = synthetic_inputs(n, d, p)
+    spec = ("sum", ("sum", ("se_ard", _ll(d), 0.0), ("mat52_iso", math.log(0.7), math.log(0.5))), ("noise", math.log(0.05)))
+    gp = g.GP(x, y, g.MeanZero(), g.from_spec(spec), math.log(0.1), ctx=ctx)
+    base = np.asarray(gp.get_params())
+    mll0 = gp.mll
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        gp.set_params(base + 1e-3 * (i + 1) * np.where(np.arange(len(base)) == 0, 0.0, 1.0))
+        gp.update_mll()
+        mu, s2 = gp.predict_f(xpred)
+    el = time.perf_counter() - t0
+    cov = ctx.profile_get(g._lib.PROF_COV)
+    ctx.profile_enable(False)
+    assert np.all(np.isfinite(mu)) and np.all(s2 >= 0) and math.isfinite(gp.mll)
+    return {
+        "workload": f"N={n}, d={d}, {C3_SPEC_NOTE} + MeanZero, f64, P={p} (BASELINE.json configs[2]), {steps} steps",
+        "ms_per_step": 1e3 * el / steps,
+        "fits_per_sec": steps / el,
+        "mll_base_params": mll0,
+        "cov_ms_per_step": cov[1] / steps,
+        "cov_GBps": (cov[2] / max(cov[1], 1e-9)) * 1e-6,
+    }
+
+
+def run_grad(g, ctx, n=50000, d=8):
+    """update_dmll! (src/GPE.jl:298-324) at the bench size: K^-1 via the whitened identity + the fused dK/dtheta trace pass."""
+    import gc
+
+    gc.collect()
+    x, y, _ = synthetic_inputs(n, d, 8)
+    gp = g.GP(x, y, g.MeanZero(), g.SEArd(_ll(d), 0.0), math.log(0.1), ctx=ctx)
+    gp.update_dmll()                      # first call allocates the two extra N x N buffers
+    t0 = time.perf_counter()
+    gp.update_dmll()
+    el = time.perf_counter() - t0
+    fl = 2.0 * float(n) ** 3 / 3.0        # L^-T rows (n^3/3) + K^-1 = L^-T L^-1 lower (n^3/3)
+    return {
+        "workload": f"update_dmll! at N={n}, d={d}, SEArd, f64 (after update_mll!; {len(gp.dmll)} parameters)",
+        "s_per_call": el,
+        "TFLOPs_on_2n3_over_3": fl / el * 1e-12,
+        "frac_of_fp64_matrix_peak": fl / el * 1e-12 / FP64_MFMA_PEAK_TFLOPS,
+        "mll": gp.mll,
+        "dmll_inf_norm": float(np.abs(gp.dmll).max()),
+    }
+
+
+def run_c5(g, ctx, n=1000000, m=4096, d=8):
+    """BASELINE configs[4]: FITC, N = 1e6, M = 4096 inducing points, SEArd, fp64, one GPU: update_mll!, predict_f, update_dmll!."""
+    import gc
+
+    gc.collect()
+    rng = np.random.default_rng(20240501)
+    x = rng.uniform(size=(d, n))
+    xu = rng.uniform(size=(d, m))
+    y = np.sin(2.0 * x.sum(axis=0)) + 0.1 * rng.standard_normal(n)
+    xs = rng.uniform(size=(d, 1024))
+    t0 = time.perf_counter()
+    gp = g.FITC(x, xu, y, g.MeanZero(), g.SEArd(_ll(d), 0.0), math.log(0.1), ctx=ctx)
+    t_first = time.perf_counter() - t0
+    mll0 = gp.mll
+    gp.set_params([v + 0.01 for v in gp.get_params()])
+    t0 = time.perf_counter()
+    gp.update_mll()
+    t_fit = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    mu, var = gp.predict_f(xs)
+    t_pred = time.perf_counter() - t0
+    gp.update_dmll()                      # first call allocates two more n x m buffers
+    t0 = time.perf_counter()
+    gp.update_dmll()
+    t_grad = time.perf_counter() - t0
+    assert np.all(np.isfinite(mu)) and np.all(var >= 0) and math.isfinite(gp.mll)
+    fl = 2.0 * n * float(m) * m           # W = Kfu Luu^-T (n m^2) + U'U'^T (n m^2)
+    return {
+        "workload": f"FITC N={n}, M={m}, d={d}, SEArd + MeanZero, f64 (BASELINE.json configs[4])",
+        "first_fit_incl_alloc_upload_s": t_first,
+        "update_mll_s": t_fit,
+        "update_mll_TFLOPs_on_2nm2": fl / t_fit * 1e-12,
+        "update_mll_frac_of_fp64_matrix_peak": fl / t_fit * 1e-12 / FP64_MFMA_PEAK_TFLOPS,
+        "predict_f_1024_ms": 1e3 * t_pred,
+        "update_dmll_s": t_grad,
+        "mll_base_params": mll0,
+        "mll": gp.mll,
+        "dmll_inf_norm": float(np.abs(gp.dmll).max()),
+    }
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -273,7 +406,8 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=240.0,
                     help="the CPU baseline is measured at the bench size when a probe estimates it under this many seconds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the c2 / c4 secondary objects")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the c2 / c4 / c3 / grad / c5 secondary objects")
+    ap.add_argument("--secondary", default="c2,c4,c3,grad,c5", help="comma-separated subset of the secondary objects to run")
     ap.add_argument("--mode", default=None, choices=["replicas", "sharded"],
                     help="N>1: ONE fit row-block sharded over the GPUs with the RCCL panel exchange (default, strong scaling) "
                          "or independent fits per GPU (replicas, weak scaling); N=1: sharded runs the sharded code path on one GPU")
@@ -374,9 +508,13 @@ def main():
             "first_fit_incl_upload_s": res["t_build"],
         }
 
+    want = set(args.secondary.split(","))
+
     def secondaries(sec):
-        """c2 / c4 objects (none of them is `value`)."""
+        """c2 / c4 / c3 / grad / c5 objects (none of them is `value`)."""
         try:
+            if "c2" not in want:
+                raise KeyError
             c2 = run_workload(g, ctx, 20000, 8, 1024, "f64", 5, 2, barrier, comm=make_comm() if sharded else None)
             c2_el = max_over_ranks(c2["elapsed"])
             sec["c2"] = {
@@ -386,9 +524,13 @@ def main():
                 "roofline_frac": roofline_object(args, c2, 20000, 8, 1024, "f64", 5)["frac"],
                 "stage_ms_per_step": {k: v for k, v in stage_object(c2, 5).items() if k != "note"},
             }
+        except KeyError:
+            pass
         except Exception as e:  # noqa: BLE001
             sec["c2"] = {"error": repr(e)[:300]}
         try:
+            if "c4" not in want:
+                raise KeyError
             # north_star's multi-GPU size as ONE fit: on one GPU (160 GB of fp32 factor fit the 288 GB) or sharded
             c4 = run_workload(g, ctx, 200000, 16, 1024, "f32", 1, 0, barrier, comm=make_comm() if sharded else None)
             c4_el = max_over_ranks(c4["elapsed"])
@@ -400,17 +542,36 @@ def main():
                 "chol_equiv_TFLOPs": (200000.0 ** 3 / 3.0) / c4_el * 1e-12,
                 "mll": c4["mll"],
             }
+        except KeyError:
+            pass
         except Exception as e:  # noqa: BLE001
             sec["c4_error"] = repr(e)[:300]
+        if world == 1 and not sharded:
+            for key, fn in (("c3", run_c3), ("grad", run_grad), ("c5", run_c5)):
+                if key not in want:
+                    continue
+                try:
+                    sec[key] = fn(g, ctx)
+                except Exception as e:  # noqa: BLE001
+                    sec[key] = {"error": repr(e)[:300]}
 
     if world == 1:
         if not args.no_secondary:
             sec = {}
             secondaries(sec)
             out.update(sec)
+        parity_failed = False
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, d, p, res["ll"], args.cpu_budget_s)
+            cpu = cpu_baseline(n, d, p, res["ll"], args.cpu_budget_s)
+            out["parity"] = parity_object(res, cpu, n, args.dtype)
+            cpu.pop("_mu", None)
+            cpu.pop("_s2", None)
+            out["cpu_baseline"] = cpu
+            parity_failed = out["parity"].get("checked", False) and not out["parity"]["ok"]
         print(json.dumps(out), flush=True)
+        if parity_failed:
+            sys.stderr.write("bench.py: PARITY FAILED against the CPU oracle at the bench size: " + json.dumps(out["parity"]) + "\n")
+            sys.exit(3)
     else:
         # The ONE JSON line of the contract goes out first: nothing after this point can cost the measurement.  The
         # secondary workloads of a multi-GPU run are reported on stderr and in gpurun_out/secondary_<N>.json, cut by a watchdog.

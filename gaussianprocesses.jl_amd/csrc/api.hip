@@ -581,7 +581,25 @@ int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
     {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = greatest priority (numerically lowest)
-        if (hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, hi) != hipSuccess) {
+        const char* cm = getenv("GPMI_CUMASK");
+        const bool want_mask = !(cm && atoi(cm) == 0) && c->num_cus == 256;
+        if (want_mask) {
+            // one CU per XCD for the chain: mask bit k * 33 (k = 0..7) lands on XCC k, one CU each (tools/cumask_probe.hip,
+            // profiles/r01_coresidency_cumask_probe.log); the update stream gets the other 248
+            uint32_t side_m[8] = {0}, upd_m[8];
+            for (int k = 0; k < 8; ++k) side_m[(k * 33) / 32] |= 1u << ((k * 33) % 32);
+            for (int w = 0; w < 8; ++w) upd_m[w] = ~side_m[w];
+            if (hipExtStreamCreateWithCUMask(&c->side_stream, 8, side_m) == hipSuccess &&
+                hipExtStreamCreateWithCUMask(&c->upd_stream, 8, upd_m) == hipSuccess) {
+                c->reserved_cus = 8;
+            } else {
+                (void)hipGetLastError();
+                if (c->side_stream) hipStreamDestroy(c->side_stream);
+                if (c->upd_stream) hipStreamDestroy(c->upd_stream);
+                c->side_stream = c->upd_stream = nullptr;
+            }
+        }
+        if (!c->side_stream && hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, hi) != hipSuccess) {
             (void)hipGetLastError();
             c->side_stream = nullptr;
         }
@@ -607,7 +625,9 @@ int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
     c->refine_solves = c->refine_default;
     if (const char* e = getenv("GPMI_GEMM_NI")) c->gemm_ni = atoi(e) == 2 ? 2 : atoi(e) == 4 ? 4 : 0;
     if (const char* e = getenv("GPMI_GEMM_WGS")) c->gemm_wgs_per_cu = atoi(e) == 1 ? 1 : 2;
-    if (getenv("GPMI_DEBUG")) fprintf(stderr, "[gpmi] device %d: %d CUs, look-ahead slots %d\n", dev, c->num_cus, c->lookahead_slots);
+    if (getenv("GPMI_DEBUG"))
+        fprintf(stderr, "[gpmi] device %d: %d CUs, look-ahead slots %d, CUs reserved for the chain %d\n", dev, c->num_cus, c->lookahead_slots,
+                c->reserved_cus);
     *out = c;
     return GPMI_OK;
 }
@@ -623,6 +643,7 @@ void gpmi_ctx_destroy(gpmi_ctx* c) {
     for (auto e : c->ev_pool) hipEventDestroy(e);
     for (auto e : c->la_events) hipEventDestroy(e);
     if (c->side_stream) hipStreamDestroy(c->side_stream);
+    if (c->upd_stream) hipStreamDestroy(c->upd_stream);
     for (void* p : {c->sup_lw, c->sup_lwt, c->sup_l256, c->sup_ut, c->sup_s, c->dev_noise})
         if (p) hipFree(p);
     if (c->d_prog) hipFree(c->d_prog);
@@ -946,13 +967,21 @@ int gpmi_dev_update_blocks(gpmi_ctx* c, int dtype, void* C_dev, int64_t ldc, con
     GPMI_HIP(c, hipSetDevice(c->device));
     TileShape sh{0, 0, mode, g0, G, nstair_tiles, tpb > 0 ? tpb : 2};
     const int gflags = (flags & 1) ? GEMM_OVERWRITE : 0;
-    // a side section is pending (gpmi_dev_side_end): this main-stream update leaves its slots free
-    if (c->side_pending && !c->beside_update) c->gemm_reserve = c->lookahead_slots;
-    if (dtype == 64)
-        launch_gemm_shape<double>(c, (double*)C_dev, ldc, (const double*)A_dev, lda, (const double*)B_dev, ldb, M, N, K, sh, c->d_info, gflags);
-    else
-        launch_gemm_shape<float>(c, (float*)C_dev, ldc, (const float*)A_dev, lda, (const float*)B_dev, ldb, M, N, K, sh, c->d_info, gflags);
-    c->gemm_reserve = 0;
+    auto go = [&]() {
+        if (dtype == 64)
+            launch_gemm_shape<double>(c, (double*)C_dev, ldc, (const double*)A_dev, lda, (const double*)B_dev, ldb, M, N, K, sh, c->d_info, gflags);
+        else
+            launch_gemm_shape<float>(c, (float*)C_dev, ldc, (const float*)A_dev, lda, (const float*)B_dev, ldb, M, N, K, sh, c->d_info, gflags);
+    };
+    // a side section is pending (gpmi_dev_side_end): this main-stream update runs beside its chain — on the CU-masked update
+    // stream when the context reserves whole CUs for the chain, else leaving its workgroup slots free (chol.h)
+    if (c->side_pending && !c->beside_update) {
+        hipEvent_t e = la_event(c);
+        GPMI_HIP(c, hipEventRecord(e, c->stream));
+        main_update_beside_chain<double>(c, e, go);
+    } else {
+        go();
+    }
     return GPMI_OK;
 }
 int gpmi_dev_update(gpmi_ctx* c, int dtype, void* C_dev, int64_t ldc, const void* A_dev, int64_t lda, const void* B_dev,

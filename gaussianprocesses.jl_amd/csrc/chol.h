@@ -184,6 +184,29 @@ inline void factor_panel_below(gpmi_ctx* c, T* A, int64_t ld, const T* linv, int
 // workgroup slots free, which is where the side stream's small kernels land.
 // (Two measured dead ends, tools/cumask_probe.hip + profiles/: splitting off the next panel's COLUMNS costs a
 // single-round GEMM launch as long as the chain it hides; CU-masked streams work but cost the GEMM 4 % for 8 CUs.)
+// The main-stream launch(es) that a side-stream chain hides under.  With reserved compute units (common.h: upd_stream) they
+// go to the CU-masked update stream — ordered after `after` (an event already recorded on the main stream) and joined back
+// into the main stream — and the grid is sized for the unreserved CUs; otherwise (round 2) they stay on the main stream and
+// leave `lookahead_slots` workgroup slots free.
+template <typename T, typename F>
+inline void main_update_beside_chain(gpmi_ctx* c, hipEvent_t after, F launch) {
+    if (c->upd_stream && c->reserved_cus > 0) {
+        hipStream_t main_s = c->stream;
+        (void)hipStreamWaitEvent(c->upd_stream, after, 0);
+        {
+            StreamScope sc(c, c->upd_stream, c->num_cus - c->reserved_cus);
+            launch();
+        }
+        hipEvent_t eu = la_event(c);
+        (void)hipEventRecord(eu, c->upd_stream);
+        (void)hipStreamWaitEvent(main_s, eu, 0);
+        return;
+    }
+    c->gemm_reserve = c->lookahead_slots;
+    launch();
+    c->gemm_reserve = 0;
+}
+
 inline int64_t super_width(const gpmi_ctx* c, int64_t trailing) {
     // widest first; widths are multiples of NB.  Below super_min[0] the factorisation is the plain NB = 256 one.
     for (int i = 2; i >= 0; --i)
@@ -363,10 +386,10 @@ inline int cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, in
             (void)hipEventRecord(ec, side);
             // everything below the next diagonal block: rows ke2.., columns ke.. up to each row tile's diagonal tile
             // (lower mode with offset: row tile ti keeps column tiles <= ti + g0)
-            c->gemm_reserve = c->lookahead_slots;
-            launch_gemm_shape<T>(c, A + ke2 * ld + ke, ld, A + ke2 * ld + ks, ld, A + ke * ld + ks, ld, Mtot - ke2, npad - ke, K,
-                                 TileShape{0, 0, 1, (int)((w2 + GEMM_BM - 1) / GEMM_BM), 1, 0}, d_info, 0);
-            c->gemm_reserve = 0;
+            main_update_beside_chain<T>(c, eb, [&]() {
+                launch_gemm_shape<T>(c, A + ke2 * ld + ke, ld, A + ke2 * ld + ks, ld, A + ke * ld + ks, ld, Mtot - ke2, npad - ke, K,
+                                     TileShape{0, 0, 1, (int)((w2 + GEMM_BM - 1) / GEMM_BM), 1, 0}, d_info, 0);
+            });
             (void)hipStreamWaitEvent(main_s, ec, 0);
         }
         ks = ke;

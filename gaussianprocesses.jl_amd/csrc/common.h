@@ -97,6 +97,13 @@ struct gpmi_ctx {
     // look-ahead Cholesky (api.hip: cholesky_lower): the next panel's serial chain runs on side_stream under the
     // trailing update, which leaves lookahead_slots workgroup slots free (gemm_reserve is set around that launch)
     hipStream_t side_stream = nullptr;
+    // round 3: WHOLE compute units for the look-ahead chain.  side_stream is created with a CU mask of `reserved_cus` CUs
+    // (one per XCD) and upd_stream with the complementary mask; the persistent update that the chain hides under is
+    // launched on upd_stream (event hop from / to the main stream), so the chain's single-wave kernels no longer share a
+    // SIMD with GEMM waves (diag64: 26 us alone, ~130 us beside a GEMM workgroup on the same CU — profiles/r02_c2_critical_path.txt).
+    // The capacity given up is what the 16 free workgroup slots already cost (8 CU-equivalents = 3.1 %).  GPMI_CUMASK=0: round 2's slots.
+    hipStream_t upd_stream = nullptr;
+    int reserved_cus = 0;
     int lookahead_slots = 0;
     int64_t lookahead_min_tiles = 650;   // update length (in 128 x 128 x 256 tile products) below which the serial order is
                                          // faster (update < chain); 650 = the lower tiles of a 4608-row trailing matrix

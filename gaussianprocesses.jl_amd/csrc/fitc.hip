@@ -511,6 +511,16 @@ int fitc_grad_t(gpmi_fitc* f, const gpmi_kernel* k, double log_noise, double* dk
         c->err = "gpmi_fitc_grad: n_kern does not match the kernel's number of hyper-parameters";
         return GPMI_EARG;
     }
+    // The per-point term sum_i q_i dk(x_i, x_i)/dtheta of fully_indep_train_conditional.jl:218 is evaluated as
+    // (sum_i q_i) * dk/dtheta at r = 0: valid because every leaf of include/gpmi.h is STATIONARY (k(x, x) does not depend
+    // on x).  A non-stationary leaf (Lin, Poly, ...) added to gpmi_op must be weighted per point here: refuse it until then.
+    for (int o = 0; o < c->h_prog->n_ops; ++o) {
+        const int op = c->h_prog->leaf[o].op;
+        if (!((op >= GPMI_K_SE_ISO && op <= GPMI_K_CONST) || op == GPMI_K_SUM || op == GPMI_K_PROD)) {
+            c->err = "gpmi_fitc_grad: the diagonal term assumes stationary leaves; this kernel has a leaf outside that set";
+            return GPMI_EARG;
+        }
+    }
     if (n_hyp > GRAD_MAX_HYP || f->d > GRAD_MAX_D || c->h_prog->n_ops > GRAD_MAX_NODES) {
         c->err = "gpmi_fitc_grad: the device gradient covers kernels with <= 48 hyper-parameters, <= 32 nodes, d <= 16";
         return GPMI_EARG;

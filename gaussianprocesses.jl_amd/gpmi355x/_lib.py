@@ -79,6 +79,11 @@ def load():
             import torch  # noqa: F401
         except ImportError:
             pass
+        except Exception as e:  # noqa: BLE001  (a torch install that fails to load must not take libgpmi down with it)
+            import warnings
+
+            warnings.warn(f"gpmi355x: importing torch failed ({e!r}); libgpmi is loaded without it — the torch-hosted "
+                          "communicators of gpmi355x.dist will not be usable in this process")
     lib = C.CDLL(LIB_PATH)
     vp, i64, dbl = C.c_void_p, C.c_int64, C.c_double
     lib.gpmi_version.restype = C.c_char_p

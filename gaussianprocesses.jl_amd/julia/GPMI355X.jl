@@ -93,8 +93,9 @@ mutable struct HIPPDMat <: AbstractPDMat{Float64}
     handle::Ptr{Cvoid}   # gpmi_gp*
     n::Int
     xref::Any            # the x the handle was created for (re-created by update_cK! when it changes)
+    xsum::UInt64         # content checksum of that x at upload time (in-place mutation of gp.x is detected, see ensure_handle!)
     function HIPPDMat(n)
-        a = new(C_NULL, n, nothing)
+        a = new(C_NULL, n, nothing, UInt64(0))
         finalizer(a) do a
             a.handle == C_NULL || ccall((:gpmi_gp_destroy, libgpmi), Cvoid, (Ptr{Cvoid},), a.handle)
         end
@@ -105,16 +106,19 @@ Base.size(a::HIPPDMat) = (a.n, a.n); Base.size(a::HIPPDMat, i::Int) = a.n; dim(a
 
 # The handle is keyed on the IDENTITY of the caller's x (gp.x, whatever its array type): the dense Float64 copy the C ABI
 # needs is made only when x actually has to be uploaded, so repeated update_cK! / update_mll! calls with the same gp.x
-# (every optimiser / MCMC step) reuse the resident x and buffers.
+# (every optimiser / MCMC step) reuse the resident x and buffers.  Identity alone would miss `gp.x .= ...` or an elastic
+# array grown in place: the number of observations and a content checksum (O(N d), negligible next to the O(N^2) cov!)
+# are compared as well, so a mutated x is re-uploaded instead of silently reusing the stale device copy.
+xchecksum(x::AbstractMatrix) = hash(x)
 function ensure_handle!(a::HIPPDMat, x::AbstractMatrix)
-    if a.handle == C_NULL || a.xref !== x
+    if a.handle == C_NULL || a.xref !== x || size(x, 2) != a.n || xchecksum(x) != a.xsum
         a.handle == C_NULL || ccall((:gpmi_gp_destroy, libgpmi), Cvoid, (Ptr{Cvoid},), a.handle)
         a.handle = C_NULL
         xd = x isa Matrix{Float64} ? x : Matrix{Float64}(x)
         h = Ref{Ptr{Cvoid}}(C_NULL)
         rc = ccall((:gpmi_gp_create, libgpmi), Cint, (Ptr{Cvoid}, Cint, Cint, Int64, Ptr{Float64}, Ptr{Ptr{Cvoid}}),
                    context(), 64, size(xd, 1), size(xd, 2), xd, h)
-        check(context(), rc); a.handle = h[]; a.xref = x; a.n = size(xd, 2)
+        check(context(), rc); a.handle = h[]; a.xref = x; a.n = size(xd, 2); a.xsum = xchecksum(x)
     end
     a
 end
@@ -249,8 +253,9 @@ mutable struct HIPFITCPDMat <: GaussianProcesses.SparsePDMat{Float64}
     n::Int
     inducing::Matrix{Float64}
     xref::Any
+    xsum::UInt64
     function HIPFITCPDMat(n, inducing)
-        a = new(C_NULL, n, Matrix{Float64}(inducing), nothing)
+        a = new(C_NULL, n, Matrix{Float64}(inducing), nothing, UInt64(0))
         finalizer(a) do a
             a.handle == C_NULL || ccall((:gpmi_fitc_destroy, libgpmi), Cvoid, (Ptr{Cvoid},), a.handle)
         end
@@ -260,7 +265,7 @@ alloc_cK(s::HIPFITC, nobs) = HIPFITCPDMat(nobs, s.inducing)             # replac
 GaussianProcesses.KernelData(k::Kernel, X1::AbstractMatrix, X2::AbstractMatrix, ::HIPFITC) = EmptyData()
 Base.size(a::HIPFITCPDMat) = (a.n, a.n); Base.size(a::HIPFITCPDMat, i::Int) = a.n; dim(a::HIPFITCPDMat) = a.n
 function ensure_handle!(a::HIPFITCPDMat, x::AbstractMatrix)
-    if a.handle == C_NULL || a.xref !== x
+    if a.handle == C_NULL || a.xref !== x || size(x, 2) != a.n || xchecksum(x) != a.xsum
         a.handle == C_NULL || ccall((:gpmi_fitc_destroy, libgpmi), Cvoid, (Ptr{Cvoid},), a.handle)
         a.handle = C_NULL
         xd = x isa Matrix{Float64} ? x : Matrix{Float64}(x)
@@ -268,7 +273,7 @@ function ensure_handle!(a::HIPFITCPDMat, x::AbstractMatrix)
         rc = ccall((:gpmi_fitc_create, libgpmi), Cint,
                    (Ptr{Cvoid}, Cint, Cint, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Ptr{Cvoid}}),
                    context(), 64, size(xd, 1), size(xd, 2), xd, size(a.inducing, 2), a.inducing, h)
-        check(context(), rc); a.handle = h[]; a.xref = x; a.n = size(xd, 2)
+        check(context(), rc); a.handle = h[]; a.xref = x; a.n = size(xd, 2); a.xsum = xchecksum(x)
     end
     a
 end

@@ -153,6 +153,8 @@ int gpmi_fitc_predict(gpmi_fitc*, const gpmi_kernel*, int64_t p, const void* xpr
 /* alpha_u = SigmaQR \ (Kuf (Lambda \ (y - mu))), m elements (get_alpha_u) */
 int gpmi_fitc_alpha_u(gpmi_fitc*, void* out);
 /* update_dmll! on the FITC model of the last gpmi_fitc_fit (same kernel, same log_noise): dmll_kern!
+ * (ASSUMES stationary leaves — every gpmi_op above is: the per-point term sum_i q_i dk(x_i,x_i)/dtheta of :218 is taken as
+ * (sum_i q_i) dk/dtheta at r = 0; a kernel with any other leaf is refused with GPMI_EARG.)
  * (src/sparse/fully_indep_train_conditional.jl:200-234 over subsetofregressors.jl:219-256) -> dkern_out[n_kern] in
  * get_params order, dmll_noise (:243-257) -> *dnoise_out.  The mean part (GPE.jl:282-288) is grad_stack' * alpha on the host. */
 int gpmi_fitc_grad(gpmi_fitc*, const gpmi_kernel*, double log_noise, double* dkern_out, int32_t n_kern, double* dnoise_out);

@@ -244,3 +244,85 @@ def test_fitc_c5_width_m4096_n262144_woodbury_residual():
     xs = rng.uniform(size=(d, 64))
     mu, var = gp.predict_f(xs)
     assert np.all(np.isfinite(mu)) and np.all(var >= 0) and np.all(var <= 1.0 + 1e-9)
+
+
+def test_fitc_c5_full_size_n1e6_m4096_woodbury_and_determinant_lemma():
+    """BASELINE configs[4] AT ITS OWN SIZE — N = 10^6, M = 4096, d = 8, SEArd, fp64 — checked through the size-independent
+    properties of the reference's FITC algebra (fully_indep_train_conditional.jl:38-41, :80, :134-156):
+        Woodbury residual   (W'W + Lambda) alpha = y - mu ,  W = Luu^-1 Kuf ,  Lambda = s2 + k(x,x) - diag(W'W)
+        determinant lemma   logdet = logdet(I + W Lambda^-1 W') + sum log Lambda   ->  mll
+    The 2 n m^2 flops of these checks run on the device as plain PyTorch fp64 (rocBLAS / rocSOLVER: an implementation that
+    shares nothing with libgpmi), in column chunks so that nothing n x m is resident twice; torch's Kuf itself is pinned to
+    the oracle's cov on a sample of entries."""
+    import gc
+
+    import torch
+
+    gc.collect()
+    torch.cuda.empty_cache()
+    n, m, d = 1000000, 4096, 8
+    rng = np.random.default_rng(20240503)
+    x = rng.uniform(size=(d, n))
+    xu = rng.uniform(size=(d, m))
+    y = np.sin(2.0 * x.sum(axis=0)) + 0.1 * rng.standard_normal(n)
+    ll = [math.log(0.5) + 0.05 * j for j in range(d)]
+    ln = math.log(0.1)
+    gp = g.FITC(x, xu, y, g.MeanZero(), g.SEArd(ll, 0.0), ln)
+    a_host = np.asarray(gp.alpha, dtype=np.float64)
+    mll_dev = gp.mll
+    xs = rng.uniform(size=(d, 64))
+    mu, var = gp.predict_f(xs)
+    assert np.all(np.isfinite(mu)) and np.all(var >= 0) and np.all(var <= 1.0 + 1e-9)
+    alpha_u = np.asarray(gp.cK.alpha_u(), dtype=np.float64) if hasattr(gp.cK, "alpha_u") else None
+    del gp
+    gc.collect()
+
+    dev = torch.device("cuda", 0)
+    w = torch.tensor(np.exp(-2.0 * np.asarray(ll)), dtype=torch.float64, device=dev)          # SEArd: il2 (se_ard.jl:31)
+    xu_t = torch.tensor(xu.T.copy(), dtype=torch.float64, device=dev)                          # m x d
+    a_t = torch.tensor(a_host, device=dev)
+    y_t = torch.tensor(y, device=dev)
+
+    def kmat(A, B):  # s2 exp(-r/2), r = sum_k il2_k (a_k - b_k)^2   (se_ard.jl:43), accumulated dimension by dimension
+        r = torch.zeros((A.shape[0], B.shape[0]), dtype=torch.float64, device=dev)
+        for k in range(d):
+            diff = A[:, k:k + 1] - B[:, k][None, :]
+            r.addcmul_(diff, diff, value=float(w[k]))
+        return torch.exp_(r.mul_(-0.5))
+
+    Kuu = kmat(xu_t, xu_t) + 1e-10 * torch.eye(m, dtype=torch.float64, device=dev)              # make_posdef! nugget
+    Luu = torch.linalg.cholesky(Kuu)
+    spec = ("se_ard", ll, 0.0)
+    chunk = 65536
+    B = torch.eye(m, dtype=torch.float64, device=dev)
+    t = torch.zeros(m, dtype=torch.float64, device=dev)
+    sum_log_lam = 0.0
+    lam_all = torch.empty(n, dtype=torch.float64, device=dev)
+    for c0 in range(0, n, chunk):
+        c1 = min(n, c0 + chunk)
+        xc = torch.tensor(x[:, c0:c1].T.copy(), dtype=torch.float64, device=dev)
+        Kuf = kmat(xu_t, xc)                                                                    # m x chunk
+        if c0 == 0:   # torch's covariance entries against the oracle's
+            np.testing.assert_allclose(Kuf[:48, :64].cpu().numpy(), G.cov(spec, xu[:, :48], x[:, :64]), rtol=1e-13, atol=1e-300)
+        W = torch.linalg.solve_triangular(Luu, Kuf, upper=False)
+        lam = math.exp(2 * ln) + 1.0 - (W * W).sum(dim=0)
+        assert bool((lam > 0).all())
+        lam_all[c0:c1] = lam
+        sum_log_lam += float(torch.log(lam).sum())
+        t += W @ a_t[c0:c1]
+        B += (W / lam) @ W.T
+        del Kuf, W, xc
+    resid_max = 0.0
+    for c0 in range(0, n, chunk):                                  # second pass: (W'W + Lambda) alpha - y, chunk by chunk
+        c1 = min(n, c0 + chunk)
+        xc = torch.tensor(x[:, c0:c1].T.copy(), dtype=torch.float64, device=dev)
+        W = torch.linalg.solve_triangular(Luu, kmat(xu_t, xc), upper=False)
+        res = W.T @ t + lam_all[c0:c1] * a_t[c0:c1] - y_t[c0:c1]
+        resid_max = max(resid_max, float(res.abs().max()))
+        del W, xc
+    logdet = 2.0 * float(torch.log(torch.diagonal(torch.linalg.cholesky(B))).sum()) + sum_log_lam
+    mll = -(float(y_t @ a_t) + logdet + n * math.log(2 * math.pi)) / 2
+    print(f"[FITC C5 full size] mll device {mll_dev:.6f}, determinant lemma {mll:.6f} (rel {abs(mll_dev / mll - 1):.2e}); "
+          f"Woodbury residual {resid_max:.2e} (|y| max {np.abs(y).max():.2f})")
+    assert resid_max <= 1e-6 * np.abs(y).max()
+    assert abs(mll_dev - mll) <= 1e-6 * abs(mll)

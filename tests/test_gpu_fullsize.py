@@ -200,3 +200,92 @@ def test_f3_packed_n220000_fp64_on_one_device_block_diagonal():
         mu_o, s2_o = G.predict_f(spec, x[:, sl], refs[c], xs[:, 16 * j:16 * (j + 1)])
         np.testing.assert_allclose(mu[16 * j:16 * (j + 1)], mu_o, rtol=1e-6, atol=1e-8)
         np.testing.assert_allclose(s2[16 * j:16 * (j + 1)], s2_o, rtol=1e-5, atol=1e-9)
+
+
+# --------------------------------------------------------------------------------------------
+# Round 3: every BASELINE config parity-checked AT ITS OWN SIZE.
+# --------------------------------------------------------------------------------------------
+def _free_device_memory():
+    import gc
+
+    import torch
+
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def test_c3_n50000_composite_direct_vs_oracle():
+    """BASELINE configs[2] — N = 50 000, d = 8, (SEArd + Mat52Iso) + Noise, fp64 — DIRECTLY against the CPU oracle: cov! +
+    nugget by the reference-order C loop (oracle/cov_oracle.c), LAPACK dpotrf / dpotrs on the host (the reference's
+    make_posdef! and `cK \\ y`), predict_f as src/GP.jl:64-79.  About two minutes of host time; bar: north_star's 1e-5."""
+    import scipy.linalg as sla
+
+    from oracle import c_oracle
+
+    _free_device_memory()
+    n, p = 50000, 256
+    x, y, xs = G.synthetic_inputs(n, 8, p=p)
+    spec = ("sum", ("sum", ("se_ard", LL8, 0.0), ("mat52_iso", math.log(0.7), math.log(0.5))), ("noise", math.log(0.05)))
+    log_noise = math.log(0.1)
+    gp = g.GP(x, y, g.MeanZero(), g.from_spec(spec), log_noise)
+    mu, s2 = gp.predict_f(xs)
+    mll_dev, alpha_dev = gp.mll, np.asarray(gp.alpha, dtype=np.float64)
+    del gp
+    K = c_oracle.assemble(spec, x, log_noise)                               # update_cK!: cov! + exp(2 logNoise) on the diagonal
+    U, info = sla.lapack.dpotrf(K, lower=0, clean=0, overwrite_a=1)         # make_posdef!
+    del K
+    assert info == 0
+    alpha = sla.cho_solve((U, False), y)
+    mll = -(float(y @ alpha) + 2.0 * float(np.sum(np.log(np.diag(U)))) + G.LOG2PI * n) / 2.0   # GPE.jl:210
+    Kc = c_oracle.cov(spec, x, xs)
+    mu_o = Kc.T @ alpha
+    Lck = sla.solve_triangular(U, Kc, trans="T", lower=False, overwrite_b=True)
+    kdiag = 1.0 + 0.25 + 0.05 ** 2
+    s2_o = np.maximum(kdiag - np.sum(Lck * Lck, axis=0), 0.0)
+    print(f"[C3 direct] mll device {mll_dev:.6f} oracle {mll:.6f} (rel {abs(mll_dev / mll - 1):.2e}); "
+          f"max|dmu| {np.abs(mu - mu_o).max():.2e}, max|ds2| {np.abs(s2 - s2_o).max():.2e}")
+    assert mll_dev == pytest.approx(mll, rel=1e-9)
+    np.testing.assert_allclose(alpha_dev, alpha, rtol=1e-5, atol=1e-6 * np.abs(alpha).max())
+    np.testing.assert_allclose(mu, mu_o, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(s2, s2_o, rtol=1e-5, atol=1e-9)
+
+
+def test_c4_fp32_n200000_d16_properties_at_full_size():
+    """BASELINE configs[3]'s size — N = 200 000, d = 16, SEArd, fp32 (160 GB factor on ONE device): the fp64 counterpart
+    (320 GB) exists nowhere, so parity is through size-independent properties evaluated by the fp64 oracle on sparse
+    probes: the solve residual (K + s2 I) alpha = y on 512 rows, the factor identity |L^-1 K v|^2 = v'Kv, the leading 4096
+    pivots against LAPACK in fp64, logdet from the fetched diagonal, mll from its parts, mu = K*' alpha; bar 1e-2 (fp32)."""
+    _free_device_memory()
+    n, d = 200000, 16
+    x, y, xs = G.synthetic_inputs(n, d, p=256)
+    spec = ("se_ard", LL16, 0.0)
+    log_noise = math.log(0.1)
+    nv = math.exp(2 * log_noise)
+    gp = g.GP(x, y, g.MeanZero(), g.from_spec(spec), log_noise, dtype=np.float32)   # raises PosDefException if not PD
+    a = np.asarray(gp.alpha, dtype=np.float64)
+    rng = np.random.default_rng(7)
+    rows = np.sort(rng.choice(n, 512, replace=False))
+    r = G.cov(spec, x[:, rows], x) @ a + nv * a[rows] - y[rows]
+    print(f"[fp32 N=200000] mll {gp.mll:.3f}; residual max {np.abs(r).max():.3e} (|y| max {np.abs(y).max():.2f})")
+    assert np.abs(r).max() <= 1e-2 * np.abs(y).max()
+    S = np.sort(rng.choice(n, 64, replace=False))
+    vS = rng.standard_normal(64)
+    KS = G.cov(spec, x, x[:, S])
+    Kv = KS @ vS
+    Kv[S] += nv * vS
+    w = np.asarray(gp.cK.whiten(Kv.astype(np.float32)), dtype=np.float64)
+    assert float(w @ w) == pytest.approx(float(vS @ Kv[S]), rel=1e-2)
+    dg = np.asarray(gp.cK.factor_diag(), dtype=np.float64)
+    assert np.all(dg > 0)
+    m = 4096
+    Ub = np.linalg.cholesky(G.cov(spec, x[:, :m]) + nv * np.eye(m))
+    np.testing.assert_allclose(dg[:m], np.diag(Ub), rtol=1e-3)
+    logdet_host = 2.0 * float(np.sum(np.log(dg)))
+    assert gp.cK.logdet() == pytest.approx(logdet_host, rel=1e-6)
+    assert gp.mll == pytest.approx(-(float(y @ a) + logdet_host + G.LOG2PI * n) / 2, rel=1e-5)
+    mu, s2 = gp.predict_f(xs)
+    assert np.all(np.isfinite(mu)) and np.all(s2 >= 0) and np.all(s2 <= 1.0 + 1e-5)
+    np.testing.assert_allclose(mu, G.cov(spec, xs, x) @ a, rtol=1e-2, atol=1e-3)
+    # predictions at training inputs reproduce the data within the noise (test/gp.jl:47-50)
+    mu_t, _ = gp.predict_f(x[:, :128])
+    np.testing.assert_allclose(mu_t, y[:128], atol=0.5)
