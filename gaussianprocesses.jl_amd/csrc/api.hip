@@ -589,17 +589,19 @@ int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
             uint32_t side_m[8] = {0}, upd_m[8];
             for (int k = 0; k < 8; ++k) side_m[(k * 33) / 32] |= 1u << ((k * 33) % 32);
             for (int w = 0; w < 8; ++w) upd_m[w] = ~side_m[w];
-            if (hipExtStreamCreateWithCUMask(&c->side_stream, 8, side_m) == hipSuccess &&
+            if (hipExtStreamCreateWithCUMask(&c->side_masked, 8, side_m) == hipSuccess &&
                 hipExtStreamCreateWithCUMask(&c->upd_stream, 8, upd_m) == hipSuccess) {
                 c->reserved_cus = 8;
             } else {
                 (void)hipGetLastError();
-                if (c->side_stream) hipStreamDestroy(c->side_stream);
+                if (c->side_masked) hipStreamDestroy(c->side_masked);
                 if (c->upd_stream) hipStreamDestroy(c->upd_stream);
-                c->side_stream = c->upd_stream = nullptr;
+    if (c->side_masked) hipStreamDestroy(c->side_masked);
+                c->side_masked = c->upd_stream = nullptr;
             }
         }
-        if (!c->side_stream && hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, hi) != hipSuccess) {
+        if (const char* e = getenv("GPMI_CUMASK_BELOW")) c->cumask_below = atoll(e);
+        if (hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, hi) != hipSuccess) {
             (void)hipGetLastError();
             c->side_stream = nullptr;
         }
@@ -607,7 +609,7 @@ int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
         if (const char* e = getenv("GPMI_LOOKAHEAD")) c->lookahead_slots = atoi(e) / 8 * 8;
         if (const char* e = getenv("GPMI_LOOKAHEAD_MIN")) {  // given as a trailing size, as in round 1
             const double t = atof(e);
-            c->lookahead_min_tiles = (int64_t)(0.5 * t * t / (GEMM_BM * GEMM_BN));
+            c->lookahead_min_tiles = c->lookahead_min_tiles_masked = (int64_t)(0.5 * t * t / (GEMM_BM * GEMM_BN));
         }
     }
     if (const char* e = getenv("GPMI_SUPER")) {  // "min512,min1024,min2048" (remaining rows from which each width is used)
@@ -644,6 +646,7 @@ void gpmi_ctx_destroy(gpmi_ctx* c) {
     for (auto e : c->la_events) hipEventDestroy(e);
     if (c->side_stream) hipStreamDestroy(c->side_stream);
     if (c->upd_stream) hipStreamDestroy(c->upd_stream);
+    if (c->side_masked) hipStreamDestroy(c->side_masked);
     for (void* p : {c->sup_lw, c->sup_lwt, c->sup_l256, c->sup_ut, c->sup_s, c->dev_noise})
         if (p) hipFree(p);
     if (c->d_prog) hipFree(c->d_prog);
@@ -1015,9 +1018,10 @@ int gpmi_dev_side_begin(gpmi_ctx* c) {
     GPMI_HIP(c, hipSetDevice(c->device));
     hipEvent_t e = la_event(c);
     GPMI_HIP(c, hipEventRecord(e, c->stream));
-    GPMI_HIP(c, hipStreamWaitEvent(c->side_stream, e, 0));
+    hipStream_t side = (c->side_masked && c->upd_stream) ? c->side_masked : c->side_stream;  // whole CUs for the chain when reserved
+    GPMI_HIP(c, hipStreamWaitEvent(side, e, 0));
     c->side_saved_stream = c->stream;
-    c->stream = c->side_stream;
+    c->stream = side;
     c->beside_update = true;
     return GPMI_OK;
 }

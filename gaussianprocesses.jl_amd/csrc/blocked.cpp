@@ -1,0 +1,621 @@
+// blocked.cpp — host-side driver of the blocked exact GP (blocked.h).  Plain C++: compiled by hipcc into libgpmi.so (back end:
+// dev_hip.hip) and by g++ into the CPU test library (back end: tests/hostdev/host_dev.cpp).
+//
+// FACTORISATION (fit): right-looking over block columns of WD rows, the two-level scheme of chol.h with the super-panel as
+// the distributed block.  Step k on every rank, with the gathered panel P_k (solved rows of block column k, global order):
+//   U1   own rows below block k  x  block column k+1          -= X_k P_k[k+1]'      (narrow; makes column k+1 current)
+//   chain (owner of block k+1, stream DS_SIDE)                 dpotrf of the diagonal block + its explicit inverse LW_{k+1}
+//   bcast LW_{k+1} (DS_SIDE)
+//   U2a  own rows  x  block columns [k+2, m)                   under the chain and the broadcast
+//   solve next panel: X_{k+1} <- X_{k+1} LW_{k+1}'  (out of place into S = the send buffer, copied back)
+//   all-gather of S into P_{k+1} (DS_SIDE)                     under U2b
+//   U2b  own rows  x  block columns [m, nblk)
+// so the chain, the broadcast and the panel exchange are all off the critical path (one-step look-ahead, HPL style); the
+// only host synchronisations are at the start and at the end of a call.  The right-hand side y - mu rides along as one extra
+// ("carried") row on every rank: when the loop ends it holds z = L^-1 (y - mu).
+#include "blocked.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+namespace gpmi {
+
+static const double LOG2PI = 1.8378770664093453;
+
+static int64_t default_block(int64_t n) { return n >= 16384 ? 1024 : (n >= 4096 ? 512 : 256); }
+
+BlockedGP::BlockedGP(Dev* dev, Comm* comm, int d, int64_t n, BlockedOpts o)
+    : dev_(dev), comm_(comm), rank_(comm ? comm->rank : 0), G_(comm ? comm->world : 1), d_(d), n_(n) {
+    es_ = dev->es;
+    WD_ = o.block > 0 ? o.block : default_block(n);
+    nblk_ = (n + WD_ - 1) / WD_;
+    npad_ = nblk_ * WD_;
+    tpb_ = (int)(WD_ / 128);
+    ldP_ = padded(WD_);
+    for (int64_t b = rank_; b < nblk_; b += G_) own_.push_back((int)b);
+    nown_ = (int)own_.size();
+    maxown_ = (int)((nblk_ + G_ - 1) / G_);
+    per_ = (o.stripe_blocks <= 0 || o.stripe_blocks >= nown_) ? std::max(nown_, 1) : o.stripe_blocks;
+}
+
+BlockedGP::~BlockedGP() {
+    for (void* p : allocs_) dev_->release(p);
+    for (char* p : {xp_, Rloc_, Vk_, small_, Kpp_, G1_, Vb_, Wt_, (char*)dacc_})
+        if (p) dev_->release(p);
+}
+
+void* BlockedGP::grab(int64_t bytes, bool zero) {
+    void* p = dev_->alloc(std::max<int64_t>(bytes, 64));
+    if (!p) return nullptr;
+    allocs_.push_back(p);
+    if (zero) dev_->zero(p, bytes);
+    return p;
+}
+
+int BlockedGP::grow(char** p, int64_t* cap, int64_t bytes) {
+    if (*cap >= bytes) return GPMI_OK;
+    if (*p) dev_->release(*p);
+    *cap = 0;
+    *p = (char*)dev_->alloc(bytes);
+    if (!*p) return fail(GPMI_EDEVICE, "blocked GP: out of device memory (" + dev_->err + ")");
+    *cap = bytes;
+    return GPMI_OK;
+}
+
+int BlockedGP::check_dev(const char* where) {
+    if (!dev_->err.empty()) return fail(GPMI_EDEVICE, std::string(where) + ": " + dev_->err);
+    if (comm_rc_) return fail(GPMI_EDEVICE, std::string(where) + ": a collective failed (rc " + std::to_string(comm_rc_) + ")");
+    return GPMI_OK;
+}
+
+int BlockedGP::init(const void* x_host) {
+    if (WD_ < 256 || WD_ % 256 || ((WD_ / 256) & (WD_ / 256 - 1))) return fail(GPMI_EARG, "the distributed block must be 256 * 2^s rows");
+    dev_->begin_call();
+    dev_->use(DS_MAIN);
+    // stripes of `per_` local blocks; stripe s holds the columns up to the diagonal of its last block (the last stripe, which
+    // also carries the y - mu row, all npad): N^2 (1 + 1/S) / 2 elements instead of N^2
+    for (int i0 = 0; i0 < std::max(nown_, 1); i0 += per_) {
+        const int i1 = std::min(i0 + per_, nown_);
+        const bool last = i1 >= nown_;
+        Stripe s;
+        s.i0 = i0;
+        s.i1 = std::max(i1, i0);
+        s.width = (last || nown_ == 0) ? npad_ : (int64_t)(own_[i1 - 1] + 1) * WD_;
+        s.ld = padded(s.width);
+        s.rows = (int64_t)(s.i1 - s.i0) * WD_ + (last ? 8 : 0);
+        s.p = (char*)grab(s.rows * s.ld * es_, true);
+        if (!s.p) return fail(GPMI_EDEVICE, "blocked GP: out of device memory for the factor (" + dev_->err + ")");
+        stored_bytes_ += s.rows * s.ld * es_;
+        stripes_.push_back(s);
+        if (last) break;
+    }
+    const int64_t srows = (int64_t)maxown_ * WD_ + 8;
+    bool ok = true;
+    auto take = [&](char** dst, int64_t bytes, bool zero) {
+        *dst = (char*)grab(bytes, zero);
+        ok = ok && *dst != nullptr;
+    };
+    take(&x_, n_ * d_ * es_, false);
+    take(&LW_, nblk_ * WD_ * WD_ * es_, true);
+    take(&linv_, (int64_t)std::max(nown_, 1) * WD_ * 64 * es_, true);
+    take(&invd_, (int64_t)std::max(nown_, 1) * WD_ * es_, true);
+    take(&alpha_, npad_ * es_, true);
+    take(&v_, npad_ * es_, true);
+    take(&ymu_, npad_ * es_, true);
+    take(&seg_, WD_ * es_, true);
+    take(&S_[0], srows * ldP_ * es_, true);
+    if (G_ == 1) {
+        take(&S_[1], srows * ldP_ * es_, true);  // one rank: the solved image IS the panel in global order; two of them alternate
+    } else {
+        take(&Praw_, (int64_t)G_ * maxown_ * WD_ * ldP_ * es_, false);
+        take(&P_[0], npad_ * ldP_ * es_, true);
+        take(&P_[1], npad_ * ldP_ * es_, true);
+    }
+    if (!ok) return fail(GPMI_EDEVICE, "blocked GP: out of device memory (" + dev_->err + ")");
+    dev_->upload(x_, x_host, n_ * d_ * es_);
+    dev_->sync();
+    return check_dev("blocked GP init");
+}
+
+const BlockedGP::Stripe& BlockedGP::stripe_of(int i) const {
+    for (const auto& s : stripes_)
+        if (i >= s.i0 && i < s.i1) return s;
+    return stripes_.back();
+}
+char* BlockedGP::block_ptr(int i, int64_t* ld, int64_t* width) const {
+    const Stripe& s = stripe_of(i);
+    *ld = s.ld;
+    *width = s.width;
+    return s.p + (int64_t)(i - s.i0) * WD_ * s.ld * es_;
+}
+char* BlockedGP::carried_ptr(int64_t* ld) const {
+    const Stripe& s = stripes_.back();
+    *ld = s.ld;
+    return s.p + (int64_t)(s.i1 - s.i0) * WD_ * s.ld * es_;
+}
+// the local blocks >= first_block, stripe by stripe; the last piece ends with the carried row when asked for
+std::vector<BlockedGP::Piece> BlockedGP::pieces(int first_block, bool carried) const {
+    std::vector<Piece> out;
+    for (size_t si = 0; si < stripes_.size(); ++si) {
+        const Stripe& s = stripes_[si];
+        const bool last = si + 1 == stripes_.size();
+        const int b0 = std::max(s.i0, first_block);
+        const int nb = std::max(0, s.i1 - b0);
+        const bool extra = carried && last;
+        if (nb == 0 && !extra) continue;
+        Piece p;
+        const int64_t r0 = nb ? (int64_t)(b0 - s.i0) * WD_ : (int64_t)(s.i1 - s.i0) * WD_;
+        p.p = s.p + r0 * s.ld * es_;
+        p.ld = s.ld;
+        p.width = s.width;
+        p.b0 = nb ? b0 : s.i1;
+        p.nb = nb;
+        p.carried = extra;
+        out.push_back(p);
+    }
+    return out;
+}
+// rows of global block b (> k) of the gathered panel k
+char* BlockedGP::panel_rows(int64_t k, int64_t b) const {
+    if (G_ == 1) return S_[k & 1] + (b - k - 1) * WD_ * ldP_ * es_;
+    return P_[k & 1] + b * WD_ * ldP_ * es_;
+}
+
+void BlockedGP::bcast_lw(int64_t k, DevEvent after) {
+    dev_->use(DS_SIDE);
+    if (after) dev_->wait(after);
+    if (comm_ && G_ > 1) comm_rc_ |= comm_->broadcast(LW_ + k * WD_ * WD_ * es_, WD_ * WD_ * es_, (int)(k % G_), dev_->native_stream());
+    ev_lw_ = dev_->record();
+}
+
+// Rows below block k (own blocks with global index > k, plus the carried row): X <- X LW_k' out of place into S (which is the
+// send buffer of the exchange and, on one rank, the panel itself), copied back into the factor; then the all-gather into P_k
+// in global row order.  from_factor: the rows are already solved (gradient: the panel is re-gathered from the stored factor).
+void BlockedGP::solve_and_gather(int64_t k, const char* from_factor) {
+    const int64_t k0 = k * WD_;
+    const int nle = n_le(rank_, k);
+    char* S = S_[G_ == 1 ? (k & 1) : 0];
+    dev_->use(DS_UPD);
+    if (!from_factor) dev_->wait(ev_lw_);
+    int64_t srow = 0;
+    DevShape rect;
+    for (const Piece& pc : pieces(nle, !from_factor)) {
+        const int64_t M = (int64_t)pc.nb * WD_ + (pc.carried ? 1 : 0);
+        char* X = pc.p + k0 * es_;
+        char* Si = S + srow * ldP_ * es_;
+        if (from_factor) {
+            dev_->copy2d(Si, ldP_ * es_, X, pc.ld * es_, WD_ * es_, M);
+        } else {
+            dev_->gemm(Si, ldP_, X, pc.ld, LW_ + k * WD_ * WD_ * es_, WD_, M, WD_, WD_, rect, DG_OVERWRITE | DG_KEND_COL);
+            dev_->copy2d(X, pc.ld * es_, Si, ldP_ * es_, WD_ * es_, M);
+        }
+        srow += M;
+    }
+    DevEvent ev_sr = dev_->record();
+    ev_p_ = ev_sr;
+    if (G_ == 1 || k + 1 >= nblk_) return;
+    dev_->use(DS_SIDE);
+    dev_->wait(ev_sr);
+    int maxsend = 0;
+    for (int q = 0; q < G_; ++q) maxsend = std::max(maxsend, n_below(q, k));
+    const int64_t each = (int64_t)maxsend * WD_ * ldP_ * es_;
+    comm_rc_ |= comm_->all_gather(S, Praw_, each, dev_->native_stream());
+    char* P = P_[k & 1];
+    for (int q = 0; q < G_; ++q) {
+        const int cnt = n_below(q, k);
+        if (cnt == 0) continue;
+        const int64_t first = (int64_t)n_le(q, k) * G_ + q;  // rank q's first block below k (global index)
+        dev_->copy2d(P + first * WD_ * ldP_ * es_, (int64_t)G_ * WD_ * ldP_ * es_, Praw_ + (int64_t)q * each, WD_ * ldP_ * es_, WD_ * ldP_ * es_, cnt);
+    }
+    ev_p_ = dev_->record();
+}
+
+// own rows (and the carried row) x block columns [c_lo, c_hi) -= X_k P_k' : the staircase of a block-cyclic shard, one launch
+// per stripe.  Only rows whose diagonal lies at or right of c_lo have entries there.
+void BlockedGP::update_cols(int64_t k, int64_t c_lo, int64_t c_hi) {
+    if (c_lo >= c_hi) return;
+    const int first = n_le(rank_, c_lo - 1);
+    for (const Piece& pc : pieces(first, true)) {
+        const int64_t M = (int64_t)pc.nb * WD_ + (pc.carried ? 1 : 0);
+        const int64_t ncols = std::min<int64_t>(c_hi * WD_, pc.width) - c_lo * WD_;
+        if (M <= 0 || ncols <= 0) continue;
+        DevShape sh;
+        sh.mode = 2;
+        sh.g0 = pc.nb ? (int)(own_[pc.b0] - c_lo) : 0;
+        sh.G = G_;
+        sh.nstair = tpb_ * pc.nb;
+        sh.tpb = tpb_;
+        dev_->gemm(pc.p + c_lo * WD_ * es_, pc.ld, pc.p + k * WD_ * es_, pc.ld, panel_rows(k, c_lo), ldP_, M, ncols, WD_, sh, 0);
+    }
+}
+
+int BlockedGP::fit(const gpmi_kernel* kern, const double* log_noise, int64_t n_noise, const void* ymu_host, double* mll_out, void* alpha_out,
+                   int64_t* info_out) {
+    fitted_ = false;
+    comm_rc_ = 0;
+    dev_->err.clear();
+    if (info_out) *info_out = 0;
+    if (n_noise != 1 && n_noise != n_) return fail(GPMI_EARG, "gpmi_fit: bad argument (logNoise must have length 1 or nobs)");
+    dev_->begin_call();
+    dev_->use(DS_MAIN);
+    int n_hyp = 0;
+    int rc = dev_->set_kernel(kern, d_, &kdiag_, &n_hyp);
+    if (rc != GPMI_OK) return fail(rc, dev_->err);
+    double nugget = 0.0;
+    const double* nvec = nullptr;
+    if (n_noise == 1) {
+        nugget = exp(2.0 * log_noise[0]);  // GPE.jl:173
+    } else {
+        if (!noise_) noise_ = (double*)grab(n_ * 8, false);
+        if (!noise_) return fail(GPMI_EDEVICE, "blocked GP: out of device memory");
+        std::vector<double> nv((size_t)n_);
+        for (int64_t i = 0; i < n_; ++i) nv[(size_t)i] = exp(2.0 * log_noise[i]);  // GPE.jl:181-183
+        dev_->upload(noise_, nv.data(), n_ * 8);
+        nvec = noise_;
+    }
+    dev_->zero(ymu_, npad_ * es_);
+    dev_->upload(ymu_, ymu_host, n_ * es_);
+    dev_->info(true);
+    for (int i = 0; i < nown_; ++i) {  // cov! + nugget, own block-rows only (lower tiles; identity padding past n)
+        int64_t ld, width;
+        char* blk = block_ptr(i, &ld, &width);
+        dev_->assemble(x_, n_, d_, (int64_t)own_[i] * WD_, WD_, nugget, nvec, blk, ld, width);
+    }
+    {
+        int64_t ldc;
+        char* cr = carried_ptr(&ldc);
+        dev_->copy2d(cr, ldc * es_, ymu_, npad_ * es_, npad_ * es_, 1);
+    }
+    DevEvent e0 = dev_->record();
+    dev_->use(DS_UPD);
+    dev_->wait(e0);
+    DevEvent after = e0;
+    if (rank_ == 0) {  // the first diagonal block has nothing to hide behind
+        int64_t ld, width;
+        char* blk = block_ptr(0, &ld, &width);
+        dev_->super_factor(blk, ld, WD_, linv_, invd_, LW_, 0);
+        after = dev_->record();
+    }
+    bcast_lw(0, after);
+    solve_and_gather(0, nullptr);
+    for (int64_t k = 0; k + 1 < nblk_; ++k) {
+        const int64_t k0 = k * WD_, k1 = k0 + WD_;
+        const int nle = n_le(rank_, k);
+        dev_->use(DS_UPD);
+        dev_->wait(ev_p_);
+        // U1: block column k+1 of every own row below block k
+        const bool mine_next = (k + 1) % G_ == rank_;
+        DevShape rect, lower;
+        lower.mode = 1;
+        bool first_piece = true;
+        for (const Piece& pc : pieces(nle, true)) {
+            int64_t M = (int64_t)pc.nb * WD_ + (pc.carried ? 1 : 0);
+            char* rows = pc.p;
+            if (first_piece && mine_next && pc.nb > 0) {  // the next diagonal block itself: its lower tiles only
+                dev_->gemm(rows + k1 * es_, pc.ld, rows + k0 * es_, pc.ld, panel_rows(k, k + 1), ldP_, WD_, WD_, WD_, lower, 0);
+                rows += WD_ * pc.ld * es_;
+                M -= WD_;
+            }
+            first_piece = false;
+            if (M > 0) dev_->gemm(rows + k1 * es_, pc.ld, rows + k0 * es_, pc.ld, panel_rows(k, k + 1), ldP_, M, WD_, WD_, rect, 0);
+        }
+        DevEvent ev_u1 = dev_->record();
+        DevEvent chain = ev_u1;
+        if (mine_next) {
+            const int li = (int)((k + 1) / G_);
+            int64_t ld, width;
+            char* blk = block_ptr(li, &ld, &width) + k1 * es_;
+            dev_->use(DS_SIDE);
+            dev_->wait(ev_u1);
+            dev_->super_factor(blk, ld, WD_, linv_ + (int64_t)li * WD_ * 64 * es_, invd_ + (int64_t)li * WD_ * es_, LW_ + (k + 1) * WD_ * WD_ * es_,
+                               k1);
+            chain = nullptr;  // same stream: the broadcast follows in order
+        }
+        bcast_lw(k + 1, chain);
+        // U2a: enough block columns to cover the chain and the broadcast, then the next panel, then the rest under the exchange
+        const int64_t rest = nblk_ - (k + 2);
+        const int64_t m = std::min<int64_t>(nblk_, k + 2 + std::max<int64_t>(rest > 0 ? 1 : 0, (rest + 3) / 4));
+        dev_->use(DS_UPD);
+        update_cols(k, k + 2, m);
+        solve_and_gather(k + 1, nullptr);
+        dev_->use(DS_UPD);
+        update_cols(k, m, nblk_);
+    }
+    // join the streams on the main one
+    dev_->use(DS_SIDE);
+    DevEvent es = dev_->record();
+    dev_->use(DS_UPD);
+    DevEvent eu = dev_->record();
+    dev_->use(DS_MAIN);
+    dev_->wait(es);
+    dev_->wait(eu);
+    // the FIRST failing pivot wins (ranks past it have been factoring garbage), as dpotrf reports it
+    double piv = (double)dev_->info(false);
+    if (piv <= 0) piv = 1e18;
+    if (comm_ && G_ > 1) comm_rc_ |= comm_->host_allreduce(&piv, 1, 1);
+    if ((rc = check_dev("gpmi_fit"))) return rc;
+    if (piv < 1e17) {
+        if (info_out) *info_out = (int64_t)piv;
+        return fail(GPMI_ENOTPD, "matrix is not positive definite; Cholesky factorization failed");
+    }
+    // logdet = 2 sum log L_ii: local share + all-reduce
+    double half = 0.0;
+    for (int i = 0; i < nown_; ++i) {
+        int64_t ld, width;
+        char* blk = block_ptr(i, &ld, &width);
+        half += dev_->logdiag_sum(blk, ld, WD_, (int64_t)own_[i] * WD_);
+    }
+    if (comm_ && G_ > 1) comm_rc_ |= comm_->host_allreduce(&half, 1, 0);
+    logdet_ = 2.0 * half;
+    // backward solve L' alpha = z, block-rows in reverse.  v = this rank's share of z - sum_{solved blocks} L_b' alpha_b: rank 0
+    // starts from z (every rank carried y - mu), the others from 0; the owner of block c needs the TOTAL of its WD entries
+    // (an all-reduce of WD numbers), solves, and folds L_c' alpha_c into its own v
+    {
+        int64_t ldc;
+        char* cr = carried_ptr(&ldc);
+        if (rank_ == 0)
+            dev_->copy2d(v_, npad_ * es_, cr, ldc * es_, npad_ * es_, 1);
+        else
+            dev_->zero(v_, npad_ * es_);
+        dev_->zero(alpha_, npad_ * es_);
+        for (int64_t c = nblk_ - 1; c >= 0; --c) {
+            const int owner = (int)(c % G_);
+            char* vc = v_ + c * WD_ * es_;
+            if (G_ > 1) {
+                dev_->copy2d(seg_, WD_ * es_, vc, WD_ * es_, WD_ * es_, 1);
+                comm_rc_ |= comm_->all_reduce_sum(seg_, WD_, es_, dev_->native_stream());
+                if (rank_ == owner) dev_->copy2d(vc, WD_ * es_, seg_, WD_ * es_, WD_ * es_, 1);
+            }
+            if (rank_ == owner) {
+                const int li = (int)(c / G_);
+                int64_t ld, width;
+                char* blk = block_ptr(li, &ld, &width);
+                dev_->bsolve_block(blk, ld, c * WD_, WD_, linv_ + (int64_t)li * WD_ * 64 * es_, v_, alpha_);
+            }
+        }
+        if (G_ > 1) comm_rc_ |= comm_->all_reduce_sum(alpha_, npad_, es_, dev_->native_stream());  // every block of alpha was written by one rank
+    }
+    const double dot = dev_->dot(ymu_, alpha_, n_);
+    if (alpha_out) dev_->download(alpha_out, alpha_, n_ * es_);
+    dev_->sync();
+    if ((rc = check_dev("gpmi_fit"))) return rc;
+    const double mll = -(dot + logdet_ + LOG2PI * (double)n_) / 2.0;  // GPE.jl:210
+    if (mll_out) *mll_out = mll;
+    fitted_ = true;
+    return GPMI_OK;
+}
+
+int BlockedGP::factor_diag(void* out_host) {
+    if (!fitted_) return fail(GPMI_EARG, "gpmi_factor_diag: no valid factorisation (call gpmi_fit first)");
+    dev_->begin_call();
+    dev_->use(DS_MAIN);
+    // gather 1 / L_ii-free: the diagonal itself, one strided copy per own block into v (scratch), all-reduced
+    dev_->zero(v_, npad_ * es_);
+    for (int i = 0; i < nown_; ++i) {
+        int64_t ld, width;
+        char* blk = block_ptr(i, &ld, &width);
+        const int64_t c0 = (int64_t)own_[i] * WD_;
+        dev_->copy2d(v_ + c0 * es_, es_, blk + c0 * es_, (ld + 1) * es_, es_, WD_);
+    }
+    if (comm_ && G_ > 1) comm_rc_ |= comm_->all_reduce_sum(v_, npad_, es_, dev_->native_stream());
+    dev_->download(out_host, v_, n_ * es_);
+    dev_->sync();
+    return check_dev("gpmi_factor_diag");
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// predict_f (GP.jl:64-84): the test points' cross-covariance is split by COLUMNS like the factor's rows: a rank holds
+// R[:, own blocks] (P x nown WD).  Right-looking whitening: the owner of block k forms V_k = R_k LW_k' and broadcasts it
+// (P x WD: N P elements per predict in total — nobody re-gathers the factor); every rank then updates ITS column blocks
+// c > k with its own rows of the factor, R_c -= V_k L_ck'.  sigma^2 and the full covariance accumulate from the V_k, which
+// every rank sees; mu = m + K*' alpha is a partial product over the own columns + one all-reduce of P numbers.
+// ------------------------------------------------------------------------------------------------------------------------
+int BlockedGP::predict(const gpmi_kernel* kern, int64_t P, const void* xpred_host, const void* mean_host, int full_cov, void* mu_out,
+                       void* var_out) {
+    if (!fitted_) return fail(GPMI_EARG, "gpmi_predict: no valid factorisation (call gpmi_fit first)");
+    comm_rc_ = 0;
+    dev_->err.clear();
+    dev_->begin_call();
+    dev_->use(DS_MAIN);
+    int n_hyp = 0, rc;
+    if ((rc = dev_->set_kernel(kern, d_, &kdiag_, &n_hyp)) != GPMI_OK) return fail(rc, dev_->err);
+    const int64_t Ppad = (P + 127) / 128 * 128;
+    const int64_t ldR = padded(std::max<int64_t>((int64_t)nown_ * WD_, WD_));
+    const int64_t ldK = padded(Ppad);
+    if ((rc = grow(&xp_, &xp_cap_, P * d_ * es_))) return rc;
+    if ((rc = grow(&Rloc_, &Rloc_cap_, Ppad * ldR * es_))) return rc;
+    if ((rc = grow(&Vk_, &Vk_cap_, Ppad * ldP_ * es_))) return rc;
+    if ((rc = grow(&small_, &small_cap_, (4 * Ppad + (int64_t)maxown_ * WD_) * es_ + 2 * Ppad * 8))) return rc;
+    if (full_cov && (rc = grow(&Kpp_, &Kpp_cap_, Ppad * ldK * es_))) return rc;
+    char* mean_d = small_;
+    char* mu_d = small_ + Ppad * es_;
+    char* var_d = small_ + 2 * Ppad * es_;
+    char* zero_d = small_ + 3 * Ppad * es_;
+    char* aloc = small_ + 4 * Ppad * es_;
+    double* s2acc = (double*)(aloc + (int64_t)maxown_ * WD_ * es_);
+    dev_->upload(xp_, xpred_host, P * d_ * es_);
+    dev_->zero(small_, small_cap_);
+    if (rank_ == 0) dev_->upload(mean_d, mean_host, P * es_);  // the prior mean enters once
+    dev_->zero(Rloc_, Ppad * ldR * es_);
+    DevShape rect;
+    // K*' restricted to the own column blocks (GP.jl:44), and alpha restricted the same way
+    for (int i = 0; i < nown_; ++i) {
+        const int64_t c0 = (int64_t)own_[i] * WD_;
+        const int64_t nb = std::max<int64_t>(0, std::min<int64_t>(WD_, n_ - c0));
+        if (nb > 0) dev_->cov_rows(xp_, P, x_ + c0 * d_ * es_, nb, d_, Rloc_ + (int64_t)i * WD_ * es_, ldR, WD_);
+        dev_->copy2d(aloc + (int64_t)i * WD_ * es_, WD_ * es_, alpha_ + c0 * es_, WD_ * es_, WD_ * es_, 1);
+    }
+    dev_->row_gemv(Rloc_, ldR, P, (int64_t)nown_ * WD_, aloc, mean_d, mu_d);  // mu = mx + Kfx' alpha (GP.jl:26), this rank's share
+    if (G_ > 1) comm_rc_ |= comm_->all_reduce_sum(mu_d, P, es_, dev_->native_stream());
+    if (full_cov) dev_->cov_rows(xp_, P, xp_, P, d_, Kpp_, ldK, Ppad);
+    for (int64_t k = 0; k < nblk_; ++k) {
+        const int owner = (int)(k % G_);
+        if (rank_ == owner) {
+            const int li = (int)(k / G_);
+            dev_->gemm(Vk_, ldP_, Rloc_ + (int64_t)li * WD_ * es_, ldR, LW_ + k * WD_ * WD_ * es_, WD_, P, WD_, WD_, rect, DG_OVERWRITE | DG_KEND_COL);
+        }
+        if (G_ > 1) comm_rc_ |= comm_->broadcast(Vk_, Ppad * ldP_ * es_, owner, dev_->native_stream());
+        if (!full_cov)
+            dev_->row_sumsq_acc(Vk_, ldP_, P, WD_, s2acc);
+        else
+            dev_->gemm(Kpp_, ldK, Vk_, ldP_, Vk_, ldP_, P, P, WD_, rect, 0);  // Kpred - Lck'Lck (GP.jl:45,51-54)
+        const int first = n_le(rank_, k);
+        for (const Piece& pc : pieces(first, false)) {  // own column blocks c > k:  R_c -= V_k L_ck'
+            const int64_t Nc = (int64_t)pc.nb * WD_;
+            if (Nc <= 0) continue;
+            dev_->gemm(Rloc_ + (int64_t)pc.b0 * WD_ * es_, ldR, Vk_, ldP_, pc.p + k * WD_ * es_, pc.ld, P, Nc, WD_, rect, 0);
+        }
+    }
+    dev_->download(mu_out, mu_d, P * es_);
+    if (!full_cov) {
+        std::vector<double> s2((size_t)P);
+        dev_->download(s2.data(), s2acc, P * 8);
+        dev_->sync();
+        if ((rc = check_dev("gpmi_predict"))) return rc;
+        for (int64_t p = 0; p < P; ++p) {  // max(k** - |V|^2, 0): the clamp of GP.jl:75
+            const double v = std::max(kdiag_ - s2[(size_t)p], 0.0);
+            if (es_ == 8)
+                ((double*)var_out)[p] = v;
+            else
+                ((float*)var_out)[p] = (float)v;
+        }
+        (void)var_d;
+        (void)zero_d;
+        return GPMI_OK;
+    }
+    std::vector<char> tmp((size_t)(P * ldK * es_));
+    dev_->download(tmp.data(), Kpp_, P * ldK * es_);
+    dev_->sync();
+    if ((rc = check_dev("gpmi_predict"))) return rc;
+    for (int64_t p = 0; p < P; ++p) memcpy((char*)var_out + p * P * es_, tmp.data() + p * ldK * es_, (size_t)(P * es_));
+    return GPMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// update_dmll! (GPE.jl:298-324).  K^-1 = L^-T L^-1 = V V' with V = L^-T, whose ROWS are the whitened identity rows.  A rank
+// whitens the identity rows of the blocks it owns (phase 1: the factor's panels are re-gathered, as in the factorisation),
+// then the block-rows of V are broadcast one by one (phase 2) and every rank forms the blocks K^-1[own rows i >= b, block b]
+// it needs, turns them into W = alpha alpha' - K^-1 and reduces <W, dK/dtheta> through the fused trace kernel — K^-1 is never
+// resident: the extra memory is ONE own-rows x N matrix (N^2 / G), not the two N x N of gpmi_grad.
+// ------------------------------------------------------------------------------------------------------------------------
+int BlockedGP::grad(const gpmi_kernel* kern, const double* log_noise, int64_t n_noise, double* dkern_out, int n_kern, double* dnoise_out) {
+    if (!fitted_) return fail(GPMI_EARG, "gpmi_grad: no valid factorisation (call gpmi_fit first)");
+    if (n_noise != 1 && dnoise_out) return fail(GPMI_EARG, "gpmi_grad: the noise gradient is defined for scalar logNoise only (GPE.jl:313)");
+    comm_rc_ = 0;
+    dev_->err.clear();
+    dev_->begin_call();
+    dev_->use(DS_MAIN);
+    int n_hyp = 0, rc;
+    if ((rc = dev_->set_kernel(kern, d_, &kdiag_, &n_hyp)) != GPMI_OK) return fail(rc, dev_->err);
+    if (n_hyp != n_kern) return fail(GPMI_EARG, "gpmi_grad: dkern_out length differs from the kernel's number of parameters");
+    const int64_t ldG = padded(npad_);
+    const int64_t own_rows = (int64_t)std::max(nown_, 1) * WD_;
+    if ((rc = grow(&G1_, &G1_cap_, own_rows * ldG * es_))) return rc;
+    if ((rc = grow(&Vb_, &Vb_cap_, WD_ * ldG * es_))) return rc;
+    if ((rc = grow(&Wt_, &Wt_cap_, own_rows * ldP_ * es_))) return rc;
+    if ((rc = grow((char**)&dacc_, &dacc_cap_, (int64_t)(n_hyp + 2) * 8))) return rc;
+    if (!xloc_) {  // the own rows' inputs and alpha, contiguous in local order
+        xloc_ = (char*)grab(own_rows * d_ * es_, true);
+        aloc_ = (char*)grab(own_rows * es_, true);
+        if (!xloc_ || !aloc_) return fail(GPMI_EDEVICE, "blocked GP: out of device memory");
+        for (int i = 0; i < nown_; ++i) {
+            const int64_t c0 = (int64_t)own_[i] * WD_, nb = std::max<int64_t>(0, std::min<int64_t>(WD_, n_ - c0));
+            if (nb > 0) dev_->copy2d(xloc_ + (int64_t)i * WD_ * d_ * es_, nb * d_ * es_, x_ + c0 * d_ * es_, nb * d_ * es_, nb * d_ * es_, 1);
+        }
+    }
+    for (int i = 0; i < nown_; ++i)
+        dev_->copy2d(aloc_ + (int64_t)i * WD_ * es_, WD_ * es_, alpha_ + (int64_t)own_[i] * WD_ * es_, WD_ * es_, WD_ * es_, 1);
+    dev_->zero(dacc_, (int64_t)(n_hyp + 2) * 8);
+    // ---- phase 1: V_own = I_own L^-T.  Row block i of the identity is zero left of column own[i] WD, so block column k only
+    //      concerns the own blocks with global index <= k.
+    for (int i = 0; i < nown_; ++i) dev_->set_identity_rows(G1_ + (int64_t)i * WD_ * ldG * es_, ldG, WD_, (int64_t)own_[i] * WD_);
+    DevEvent e0 = dev_->record();
+    dev_->use(DS_UPD);
+    dev_->wait(e0);
+    dev_->use(DS_SIDE);
+    dev_->wait(e0);
+    DevShape rect;
+    char* S2 = Wt_;  // out-of-place image of the solved columns (own_rows x ldP)
+    for (int64_t k = 0; k < nblk_; ++k) {
+        const int nrows_blk = n_le(rank_, k);  // own blocks <= k
+        const int64_t M = (int64_t)nrows_blk * WD_;
+        if (k + 1 < nblk_) solve_and_gather(k, "factor");  // P_k from the stored factor (UPD packs, SIDE gathers)
+        dev_->use(DS_UPD);
+        if (M > 0) {
+            dev_->gemm(S2, ldP_, G1_ + k * WD_ * es_, ldG, LW_ + k * WD_ * WD_ * es_, WD_, M, WD_, WD_, rect, DG_OVERWRITE | DG_KEND_COL);
+            dev_->copy2d(G1_ + k * WD_ * es_, ldG * es_, S2, ldP_ * es_, WD_ * es_, M);
+        }
+        if (k + 1 < nblk_) {
+            dev_->wait(ev_p_);
+            if (M > 0)
+                dev_->gemm(G1_ + (k + 1) * WD_ * es_, ldG, G1_ + k * WD_ * es_, ldG, panel_rows(k, k + 1), ldP_, M, npad_ - (k + 1) * WD_, WD_, rect, 0);
+        }
+    }
+    // ---- phase 2: block-rows of V broadcast in turn; K^-1[own rows of blocks >= b, block b] = V_i V_b' (K from the later of
+    //      the two diagonals), W = w (alpha alpha' - K^-1) with w = 1 below the diagonal block and 1/2 on it, trace kernel.
+    dev_->use(DS_UPD);
+    DevEvent e1 = dev_->record();
+    dev_->use(DS_MAIN);
+    dev_->wait(e1);
+    dev_->use(DS_SIDE);
+    DevEvent e2 = dev_->record();
+    dev_->use(DS_MAIN);
+    dev_->wait(e2);
+    for (int64_t b = 0; b < nblk_; ++b) {
+        const int owner = (int)(b % G_);
+        const int64_t b0 = b * WD_, nbc = std::max<int64_t>(0, std::min<int64_t>(WD_, n_ - b0));
+        const char* Vb = nullptr;
+        if (G_ == 1) {
+            Vb = G1_ + b * WD_ * ldG * es_;
+        } else {
+            if (rank_ == owner) dev_->copy2d(Vb_, ldG * es_, G1_ + (b / G_) * WD_ * ldG * es_, ldG * es_, ldG * es_, WD_);
+            comm_rc_ |= comm_->broadcast(Vb_, WD_ * ldG * es_, owner, dev_->native_stream());
+            Vb = Vb_;
+        }
+        if (nbc == 0) continue;
+        // own blocks with global index >= b, in up to four chunks: one product per chunk whose K loop starts at the chunk's
+        // first diagonal (rows further down are zero there: wasted flops bounded by the chunk's extent)
+        const int first = n_le(rank_, b - 1);
+        const int cnt = nown_ - first;
+        const int nch = std::min(4, cnt);
+        for (int c = 0; c < nch; ++c) {
+            const int i0 = first + cnt * c / nch, i1 = first + cnt * (c + 1) / nch;
+            if (i1 <= i0) continue;
+            const int64_t M = (int64_t)(i1 - i0) * WD_;
+            const int64_t ks = (int64_t)own_[i0] * WD_;  // >= b0
+            dev_->gemm(Wt_, ldP_, G1_ + ((int64_t)i0 * WD_ * ldG + ks) * es_, ldG, Vb + ks * es_, ldG, M, WD_, npad_ - ks, rect, DG_OVERWRITE);
+            const bool diag = own_[i0] == b;  // the chunk's first block is the diagonal block
+            int64_t r0 = 0;
+            if (diag) {
+                const int64_t nr = nbc;
+                dev_->qblock(Wt_, ldP_, nr, nbc, aloc_ + (int64_t)i0 * WD_ * es_, alpha_ + b0 * es_, 0.5, false, true, nr, dacc_ + n_hyp);
+                dev_->dmll_rect_acc(xloc_ + (int64_t)i0 * WD_ * d_ * es_, nr, x_ + b0 * d_ * es_, nbc, d_, Wt_, ldP_, n_hyp, dacc_);
+                r0 = WD_;
+            }
+            // rows of the chunk below the diagonal block: real observations only (identity padding has no kernel entries)
+            const int64_t lastrow = std::min<int64_t>((int64_t)own_[i1 - 1] * WD_ + WD_, n_);
+            (void)lastrow;
+            for (int i = i0 + (diag ? 1 : 0); i < i1; ++i) {
+                const int64_t g0 = (int64_t)own_[i] * WD_, nr = std::max<int64_t>(0, std::min<int64_t>(WD_, n_ - g0));
+                if (nr == 0) continue;
+                char* Wi = Wt_ + (int64_t)(i - i0) * WD_ * ldP_ * es_;
+                dev_->qblock(Wi, ldP_, nr, nbc, aloc_ + (int64_t)i * WD_ * es_, alpha_ + b0 * es_, 1.0, false, false, 0, nullptr);
+                dev_->dmll_rect_acc(xloc_ + (int64_t)i * WD_ * d_ * es_, nr, x_ + b0 * d_ * es_, nbc, d_, Wi, ldP_, n_hyp, dacc_);
+            }
+            (void)r0;
+        }
+    }
+    std::vector<double> h((size_t)n_hyp + 2);
+    dev_->download(h.data(), dacc_, (int64_t)(n_hyp + 2) * 8);
+    dev_->sync();
+    if ((rc = check_dev("gpmi_grad"))) return rc;
+    if (comm_ && G_ > 1) comm_rc_ |= comm_->host_allreduce(h.data(), n_hyp + 1, 0);
+    if ((rc = check_dev("gpmi_grad"))) return rc;
+    for (int p = 0; p < n_hyp; ++p) dkern_out[p] = h[(size_t)p];
+    if (dnoise_out) *dnoise_out = exp(2.0 * log_noise[0]) * h[(size_t)n_hyp];  // GPE.jl:273-275
+    return GPMI_OK;
+}
+
+}  // namespace gpmi

@@ -188,9 +188,12 @@ inline void factor_panel_below(gpmi_ctx* c, T* A, int64_t ld, const T* linv, int
 // go to the CU-masked update stream — ordered after `after` (an event already recorded on the main stream) and joined back
 // into the main stream — and the grid is sized for the unreserved CUs; otherwise (round 2) they stay on the main stream and
 // leave `lookahead_slots` workgroup slots free.
+inline bool chain_masked(const gpmi_ctx* c, int64_t rows_left) {
+    return c->upd_stream && c->side_masked && c->reserved_cus > 0 && rows_left < c->cumask_below;
+}
 template <typename T, typename F>
-inline void main_update_beside_chain(gpmi_ctx* c, hipEvent_t after, F launch) {
-    if (c->upd_stream && c->reserved_cus > 0) {
+inline void main_update_beside_chain(gpmi_ctx* c, hipEvent_t after, F launch, bool masked = true) {
+    if (masked && c->upd_stream && c->reserved_cus > 0) {
         hipStream_t main_s = c->stream;
         (void)hipStreamWaitEvent(c->upd_stream, after, 0);
         {
@@ -357,7 +360,9 @@ inline int cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, in
         // The side stream's chain takes ~0.4 ms per 256 columns beside the update (contended CUs): look ahead only while
         // the update is longer.  Update length in units of a 128 x 128 x 256 tile product:
         const double ntile = 0.5 * (double)(npad - ke2) * (double)(npad - ke2) / (GEMM_BM * GEMM_BN) * (double)K / NB;
-        if (!can_look || ntile < (double)c->lookahead_min_tiles * (double)((w2 + NB - 1) / NB)) {
+        const bool masked = chain_masked(c, npad - ke2);  // whole CUs for the chain (short updates) or free slots (long ones)
+        side = masked ? c->side_masked : c->side_stream;
+        if (!can_look || ntile < (double)(masked ? c->lookahead_min_tiles_masked : c->lookahead_min_tiles) * (double)((w2 + NB - 1) / NB)) {
             launch_gemm_nt<T>(c, A + ke * ld + ke, ld, A + ke * ld + ks, ld, A + ke * ld + ks, ld, Mtot - ke, npad - ke, K, 1, d_info);
             factor_diag_block<T>(c, A, ld, linv, invdiag, ke, w2, d_info);
             if (inv2) build_super_inverse<T>(c, A, ld, linv, ke, w2, LW2, wld2, d_info);
@@ -389,7 +394,7 @@ inline int cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, in
             main_update_beside_chain<T>(c, eb, [&]() {
                 launch_gemm_shape<T>(c, A + ke2 * ld + ke, ld, A + ke2 * ld + ks, ld, A + ke * ld + ks, ld, Mtot - ke2, npad - ke, K,
                                      TileShape{0, 0, 1, (int)((w2 + GEMM_BM - 1) / GEMM_BM), 1, 0}, d_info, 0);
-            });
+            }, masked);
             (void)hipStreamWaitEvent(main_s, ec, 0);
         }
         ks = ke;

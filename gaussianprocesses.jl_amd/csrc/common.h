@@ -102,8 +102,15 @@ struct gpmi_ctx {
     // launched on upd_stream (event hop from / to the main stream), so the chain's single-wave kernels no longer share a
     // SIMD with GEMM waves (diag64: 26 us alone, ~130 us beside a GEMM workgroup on the same CU — profiles/r02_c2_critical_path.txt).
     // The capacity given up is what the 16 free workgroup slots already cost (8 CU-equivalents = 3.1 %).  GPMI_CUMASK=0: round 2's slots.
+    // Measured (profiles/r03_a_cumask_ab.log): whole CUs cost the update 4.3 % (589 -> 615 ms at N = 50 000) where the free slots
+    // cost ~1.5 % (a CU with one GEMM workgroup runs it faster), and buy the chain a 5x shorter critical path (diag64 130 -> 26 us).
+    // So the choice is per look-ahead step: masked streams while fewer than cumask_below rows remain (the chain would be exposed),
+    // round 2's free slots + the unmasked high-priority side stream above that.  N = 20 000: 78.3 -> 73.0 ms per step.
     hipStream_t upd_stream = nullptr;
+    hipStream_t side_masked = nullptr;
     int reserved_cus = 0;
+    int64_t cumask_below = 20480;
+    int64_t lookahead_min_tiles_masked = 288;  // = a 3072-row trailing matrix at K = 256: the fast chain hides under shorter updates
     int lookahead_slots = 0;
     int64_t lookahead_min_tiles = 650;   // update length (in 128 x 128 x 256 tile products) below which the serial order is
                                          // faster (update < chain); 650 = the lower tiles of a 4608-row trailing matrix
