@@ -177,20 +177,21 @@ def _ll(d):
     return [math.log(0.5) + 0.05 * k for k in range(d)]
 
 
-def run_workload(g, ctx, n, d, p, dtype, steps, warmup, barrier, comm=None):
-    """set_params -> update_mll -> predict_f, `steps` timed.  comm != None: ONE fit sharded over comm's ranks."""
+def run_workload(g, ctx, n, d, p, dtype, steps, warmup, barrier, comm=None, sharded=False):
+    """set_params -> update_mll -> predict_f, `steps` timed.  sharded: ONE fit row-block sharded over comm's ranks (comm None: the
+    blocked code path on one rank)."""
     import gc
 
     import torch
 
     gc.collect()
-    torch.cuda.empty_cache()  # the sharded path allocates through torch: hand a previous workload's blocks back
+    torch.cuda.empty_cache()
     np_dt = np.float64 if dtype == "f64" else np.float32
     x, y, xpred = synthetic_inputs(n, d, p)
     ll = _ll(d)
     log_noise = math.log(0.1)
     t_build0 = time.perf_counter()
-    if comm is not None:
+    if sharded:
         from gpmi355x import dist as gd
 
         gp = gd.ShardedGPE(x, y, g.MeanZero(), g.SEArd(ll, 0.0), log_noise, dtype=np_dt, comm=comm, ctx=ctx)
@@ -460,10 +461,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def make_comm():
-        from gpmi355x import dist as gd
+    _comm = []
 
-        return gd.TorchDistComm() if dist is not None else gd.SingleComm()
+    def make_comm():
+        """ONE communicator per process, verified before the first fit: libgpmi's own RCCL communicator (the unique id travels
+        through the launcher's torch.distributed group), or — GPMI_DIST_COMM=torch — torch.distributed behind the callbacks."""
+        if dist is None:
+            return None
+        if not _comm:
+            from gpmi355x import dist as gd
+
+            if os.environ.get("GPMI_DIST_COMM", "rccl") == "torch":
+                c = gd.TorchDistComm(device=local_rank)
+            else:
+                c = gd.rccl_comm(ctx)
+            c.selftest(ctx)
+            _comm.append(c)
+        return _comm[0]
 
     def max_over_ranks(v):
         if dist is None:
@@ -472,7 +486,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    res = run_workload(g, ctx, n, d, p, args.dtype, args.steps, args.warmup, barrier, comm=make_comm() if sharded else None)
+    res = run_workload(g, ctx, n, d, p, args.dtype, args.steps, args.warmup, barrier, comm=make_comm() if sharded else None, sharded=sharded)
     elapsed = max_over_ranks(res["elapsed"])
 
     out = None
@@ -481,7 +495,8 @@ def main():
         if world == 1:
             par = "single GPU" + (" (sharded code path, one rank)" if sharded else "")
         elif sharded:
-            par = f"ONE fit row-block sharded over {world} GPUs (block-cyclic super-panel blocks of 1024 rows, RCCL inverse broadcast + panel all-gather per block)"
+            par = (f"ONE fit row-block sharded over {world} GPUs (block-cyclic super-panel blocks of 1024 rows; per block an RCCL broadcast of the "
+                   "diagonal block's inverse and an all-gather of the solved panel, both under the trailing update: csrc/blocked.cpp)")
         else:
             par = f"{world} independent fits, one per GPU (no data-path collective)"
         out = {
@@ -515,7 +530,7 @@ def main():
         try:
             if "c2" not in want:
                 raise KeyError
-            c2 = run_workload(g, ctx, 20000, 8, 1024, "f64", 5, 2, barrier, comm=make_comm() if sharded else None)
+            c2 = run_workload(g, ctx, 20000, 8, 1024, "f64", 5, 2, barrier, comm=make_comm() if sharded else None, sharded=sharded)
             c2_el = max_over_ranks(c2["elapsed"])
             sec["c2"] = {
                 "workload": "N=20000, d=8, SEArd + MeanZero, f64, P=1024 (BASELINE.json configs[1]), 5 steps after 2 warm-ups",
@@ -532,7 +547,7 @@ def main():
             if "c4" not in want:
                 raise KeyError
             # north_star's multi-GPU size as ONE fit: on one GPU (160 GB of fp32 factor fit the 288 GB) or sharded
-            c4 = run_workload(g, ctx, 200000, 16, 1024, "f32", 1, 0, barrier, comm=make_comm() if sharded else None)
+            c4 = run_workload(g, ctx, 200000, 16, 1024, "f32", 1, 0, barrier, comm=make_comm() if sharded else None, sharded=sharded)
             c4_el = max_over_ranks(c4["elapsed"])
             sec["c4_sharded" if (sharded and world > 1) else "c4_single_gpu"] = {
                 "workload": f"N=200000, d=16, SEArd + MeanZero, f32, P=1024: ONE fit+predict on {world} GPU(s), 1 step after the "

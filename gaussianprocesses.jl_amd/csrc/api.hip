@@ -9,6 +9,7 @@
 
 #include "common.h"
 #include "chol.h"
+#include "blocked.h"
 
 using namespace gpmi;
 
@@ -540,6 +541,15 @@ static int super_rows_t(gpmi_ctx* c, T* X, int64_t ldx, int64_t M, int64_t w, co
     return GPMI_OK;
 }
 
+namespace gpmi {
+template <typename T>
+int super_factor_block(gpmi_ctx* c, T* blk, int64_t ld, int64_t w, T* linv, T* invdiag, T* lw, int64_t pivot_base) {
+    return super_factor_t<T>(c, blk, ld, w, linv, invdiag, lw, pivot_base);
+}
+template int super_factor_block<double>(gpmi_ctx*, double*, int64_t, int64_t, double*, double*, double*, int64_t);
+template int super_factor_block<float>(gpmi_ctx*, float*, int64_t, int64_t, float*, float*, float*, int64_t);
+}  // namespace gpmi
+
 // GPMI_EARG with a message of its own (gpmi_last_error must never return the text of an unrelated earlier failure)
 static int earg(gpmi_ctx* c, const char* msg) {
     if (c) c->err = msg;
@@ -548,7 +558,7 @@ static int earg(gpmi_ctx* c, const char* msg) {
 
 extern "C" {
 
-const char* gpmi_version(void) { return "gpmi 0.1 (gfx950)"; }
+const char* gpmi_version(void) { return "gpmi 0.3 (gfx950)"; }
 
 int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
     if (!out) return GPMI_EARG;
@@ -704,6 +714,11 @@ void gpmi_gp_destroy(gpmi_gp* gp) {
         hipSetDevice(gp->ctx->device);
         hipStreamSynchronize(gp->ctx->stream);
     }
+    if (gp->blocked) {
+        blocked_destroy(gp->blocked);
+        delete gp;
+        return;
+    }
     void* ptrs[] = {gp->x, gp->A, gp->ymu, gp->alpha, gp->invdiag, gp->linv, gp->linv256, gp->noise, gp->rows, gp->xp, gp->small, gp->supinv,
                     gp->g1, gp->g2, gp->gpart};
     for (void* p : ptrs)
@@ -721,6 +736,11 @@ int gpmi_fit(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int64_t
         return GPMI_EARG;
     }
     GPMI_HIP(c, hipSetDevice(c->device));
+    if (BlockedGP* b = blocked_of(gp)) {
+        const int rc = b->fit(k, log_noise, n_noise, y_minus_mu, mll_out, alpha_out, info_out);
+        if (rc != GPMI_OK) c->err = b->error();
+        return rc;
+    }
     return gp->dtype == 64 ? fit_t<double>(gp, k, log_noise, n_noise, y_minus_mu, mll_out, alpha_out, info_out)
                            : fit_t<float>(gp, k, log_noise, n_noise, y_minus_mu, mll_out, alpha_out, info_out);
 }
@@ -732,6 +752,12 @@ int gpmi_predict(gpmi_gp* gp, const gpmi_kernel* k, int64_t p, const void* xpred
     if (!k || p <= 0 || !xpred || !mean_pred || !mu_out || !var_out) {
         c->err = "gpmi_predict: bad argument";
         return GPMI_EARG;
+    }
+    if (BlockedGP* b = blocked_of(gp)) {
+        GPMI_HIP(c, hipSetDevice(c->device));
+        const int rc = b->predict(k, p, xpred, mean_pred, full_cov, mu_out, var_out);
+        if (rc != GPMI_OK) c->err = b->error();
+        return rc;
     }
     if (!gp->fitted) {
         c->err = "gpmi_predict: no valid factorisation (call gpmi_fit first)";
@@ -753,6 +779,12 @@ int gpmi_grad(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int64_
     if (n_noise != 1 && dnoise_out) {
         c->err = "gpmi_grad: the noise gradient is defined for scalar logNoise only (GPE.jl:313)";
         return GPMI_EARG;
+    }
+    if (BlockedGP* b = blocked_of(gp)) {
+        GPMI_HIP(c, hipSetDevice(c->device));
+        const int rc = b->grad(k, log_noise, n_noise, dkern_out, n_kern, dnoise_out);
+        if (rc != GPMI_OK) c->err = b->error();
+        return rc;
     }
     if (!gp->fitted) {
         c->err = "gpmi_grad: no valid factorisation (call gpmi_fit first)";
@@ -782,8 +814,19 @@ int gpmi_cov(gpmi_ctx* c, const gpmi_kernel* k, int dtype, int d, int64_t n1, co
     return dtype == 64 ? cov_t<double>(c, k, d, n1, x1, n2, x2, out) : cov_t<float>(c, k, d, n1, x1, n2, x2, out);
 }
 
-static int need_fit(gpmi_gp* gp, const char* who) {
+static int need_fit(gpmi_gp* gp, const char* who, bool blocked_ok = false) {
     if (!gp) return GPMI_EARG;
+    if (BlockedGP* b = blocked_of(gp)) {
+        if (!blocked_ok) {
+            gp->ctx->err = std::string(who) + ": not provided on a blocked handle (gpmi_gp_create_blocked)";
+            return GPMI_EARG;
+        }
+        if (!b->fitted()) {
+            gp->ctx->err = std::string(who) + ": no valid factorisation (call gpmi_fit first)";
+            return GPMI_EARG;
+        }
+        return GPMI_OK;
+    }
     if (!gp->fitted) {
         gp->ctx->err = std::string(who) + ": no valid factorisation (call gpmi_fit first)";
         return GPMI_EARG;
@@ -816,9 +859,13 @@ int gpmi_inv_diag(gpmi_gp* gp, void* out) {
 }
 
 int gpmi_logdet(gpmi_gp* gp, double* out) {
-    int rc = need_fit(gp, "gpmi_logdet");
+    int rc = need_fit(gp, "gpmi_logdet", true);
     if (rc) return rc;
     if (!out) return earg((gp ? gp->ctx : nullptr), "gpmi_logdet: bad argument");
+    if (BlockedGP* b = blocked_of(gp)) {
+        *out = b->logdet();
+        return GPMI_OK;
+    }
     *out = gp->logdet;
     return GPMI_OK;
 }
@@ -839,7 +886,7 @@ int gpmi_factor_to_host(gpmi_gp* gp, void* U_out) {
 }
 
 int gpmi_factor_diag(gpmi_gp* gp, void* diag_out) {
-    int rc = need_fit(gp, "gpmi_factor_diag");
+    int rc = need_fit(gp, "gpmi_factor_diag", true);
     if (rc) return rc;
     gpmi_ctx* c = gp->ctx;
     if (!diag_out) {
@@ -847,6 +894,11 @@ int gpmi_factor_diag(gpmi_gp* gp, void* diag_out) {
         return GPMI_EARG;
     }
     GPMI_HIP(c, hipSetDevice(c->device));
+    if (BlockedGP* b = blocked_of(gp)) {
+        rc = b->factor_diag(diag_out);
+        if (rc != GPMI_OK) c->err = b->error();
+        return rc;
+    }
     const size_t es = gp->dtype == 64 ? 8 : 4;
     // one element per row, source pitch ld + 1 elements
     GPMI_HIP(c, hipMemcpy2D(diag_out, es, gp->A, (size_t)(gp->ld + 1) * es, es, (size_t)gp->n, hipMemcpyDeviceToHost));

@@ -164,9 +164,13 @@ char* BlockedGP::panel_rows(int64_t k, int64_t b) const {
 }
 
 void BlockedGP::bcast_lw(int64_t k, DevEvent after) {
-    dev_->use(DS_SIDE);
-    if (after) dev_->wait(after);
-    if (comm_ && G_ > 1) comm_rc_ |= comm_->broadcast(LW_ + k * WD_ * WD_ * es_, WD_ * WD_ * es_, (int)(k % G_), dev_->native_stream());
+    if (G_ == 1) {  // one rank: the inverse is where it was built; whoever needs it waits for the chain
+        ev_lw_ = after;
+        return;
+    }
+    dev_->use(DS_COMM);
+    dev_->wait(after);
+    comm_rc_ |= comm_->broadcast(LW_ + k * WD_ * WD_ * es_, WD_ * WD_ * es_, (int)(k % G_), dev_->native_stream());
     ev_lw_ = dev_->record();
 }
 
@@ -196,7 +200,7 @@ void BlockedGP::solve_and_gather(int64_t k, const char* from_factor) {
     DevEvent ev_sr = dev_->record();
     ev_p_ = ev_sr;
     if (G_ == 1 || k + 1 >= nblk_) return;
-    dev_->use(DS_SIDE);
+    dev_->use(DS_COMM);
     dev_->wait(ev_sr);
     int maxsend = 0;
     for (int q = 0; q < G_; ++q) maxsend = std::max(maxsend, n_below(q, k));
@@ -210,6 +214,17 @@ void BlockedGP::solve_and_gather(int64_t k, const char* from_factor) {
         dev_->copy2d(P + first * WD_ * ldP_ * es_, (int64_t)G_ * WD_ * ldP_ * es_, Praw_ + (int64_t)q * each, WD_ * ldP_ * es_, WD_ * ldP_ * es_, cnt);
     }
     ev_p_ = dev_->record();
+}
+
+void BlockedGP::join_on_main() {
+    DevEvent ev[3];
+    const DevStream ss[3] = {DS_SIDE, DS_COMM, DS_UPD};
+    for (int i = 0; i < 3; ++i) {
+        dev_->use(ss[i]);
+        ev[i] = dev_->record();
+    }
+    dev_->use(DS_MAIN);
+    for (int i = 0; i < 3; ++i) dev_->wait(ev[i]);
 }
 
 // own rows (and the carried row) x block columns [c_lo, c_hi) -= X_k P_k' : the staircase of a block-cyclic shard, one launch
@@ -311,7 +326,7 @@ int BlockedGP::fit(const gpmi_kernel* kern, const double* log_noise, int64_t n_n
             dev_->wait(ev_u1);
             dev_->super_factor(blk, ld, WD_, linv_ + (int64_t)li * WD_ * 64 * es_, invd_ + (int64_t)li * WD_ * es_, LW_ + (k + 1) * WD_ * WD_ * es_,
                                k1);
-            chain = nullptr;  // same stream: the broadcast follows in order
+            chain = dev_->record();
         }
         bcast_lw(k + 1, chain);
         // U2a: enough block columns to cover the chain and the broadcast, then the next panel, then the rest under the exchange
@@ -324,13 +339,7 @@ int BlockedGP::fit(const gpmi_kernel* kern, const double* log_noise, int64_t n_n
         update_cols(k, m, nblk_);
     }
     // join the streams on the main one
-    dev_->use(DS_SIDE);
-    DevEvent es = dev_->record();
-    dev_->use(DS_UPD);
-    DevEvent eu = dev_->record();
-    dev_->use(DS_MAIN);
-    dev_->wait(es);
-    dev_->wait(eu);
+    join_on_main();
     // the FIRST failing pivot wins (ranks past it have been factoring garbage), as dpotrf reports it
     double piv = (double)dev_->info(false);
     if (piv <= 0) piv = 1e18;
@@ -534,7 +543,7 @@ int BlockedGP::grad(const gpmi_kernel* kern, const double* log_noise, int64_t n_
     DevEvent e0 = dev_->record();
     dev_->use(DS_UPD);
     dev_->wait(e0);
-    dev_->use(DS_SIDE);
+    dev_->use(DS_COMM);
     dev_->wait(e0);
     DevShape rect;
     char* S2 = Wt_;  // out-of-place image of the solved columns (own_rows x ldP)
@@ -555,14 +564,7 @@ int BlockedGP::grad(const gpmi_kernel* kern, const double* log_noise, int64_t n_
     }
     // ---- phase 2: block-rows of V broadcast in turn; K^-1[own rows of blocks >= b, block b] = V_i V_b' (K from the later of
     //      the two diagonals), W = w (alpha alpha' - K^-1) with w = 1 below the diagonal block and 1/2 on it, trace kernel.
-    dev_->use(DS_UPD);
-    DevEvent e1 = dev_->record();
-    dev_->use(DS_MAIN);
-    dev_->wait(e1);
-    dev_->use(DS_SIDE);
-    DevEvent e2 = dev_->record();
-    dev_->use(DS_MAIN);
-    dev_->wait(e2);
+    join_on_main();
     for (int64_t b = 0; b < nblk_; ++b) {
         const int owner = (int)(b % G_);
         const int64_t b0 = b * WD_, nbc = std::max<int64_t>(0, std::min<int64_t>(WD_, n_ - b0));
@@ -587,24 +589,21 @@ int BlockedGP::grad(const gpmi_kernel* kern, const double* log_noise, int64_t n_
             const int64_t ks = (int64_t)own_[i0] * WD_;  // >= b0
             dev_->gemm(Wt_, ldP_, G1_ + ((int64_t)i0 * WD_ * ldG + ks) * es_, ldG, Vb + ks * es_, ldG, M, WD_, npad_ - ks, rect, DG_OVERWRITE);
             const bool diag = own_[i0] == b;  // the chunk's first block is the diagonal block
-            int64_t r0 = 0;
+            int ia = i0;
             if (diag) {
-                const int64_t nr = nbc;
-                dev_->qblock(Wt_, ldP_, nr, nbc, aloc_ + (int64_t)i0 * WD_ * es_, alpha_ + b0 * es_, 0.5, false, true, nr, dacc_ + n_hyp);
-                dev_->dmll_rect_acc(xloc_ + (int64_t)i0 * WD_ * d_ * es_, nr, x_ + b0 * d_ * es_, nbc, d_, Wt_, ldP_, n_hyp, dacc_);
-                r0 = WD_;
+                dev_->qblock(Wt_, ldP_, nbc, nbc, aloc_ + (int64_t)i0 * WD_ * es_, alpha_ + b0 * es_, 0.5, false, true, nbc, dacc_ + n_hyp);
+                dev_->dmll_rect_acc(xloc_ + (int64_t)i0 * WD_ * d_ * es_, nbc, x_ + b0 * d_ * es_, nbc, d_, Wt_, ldP_, n_hyp, dacc_);
+                ia = i0 + 1;
             }
-            // rows of the chunk below the diagonal block: real observations only (identity padding has no kernel entries)
-            const int64_t lastrow = std::min<int64_t>((int64_t)own_[i1 - 1] * WD_ + WD_, n_);
-            (void)lastrow;
-            for (int i = i0 + (diag ? 1 : 0); i < i1; ++i) {
-                const int64_t g0 = (int64_t)own_[i] * WD_, nr = std::max<int64_t>(0, std::min<int64_t>(WD_, n_ - g0));
-                if (nr == 0) continue;
-                char* Wi = Wt_ + (int64_t)(i - i0) * WD_ * ldP_ * es_;
-                dev_->qblock(Wi, ldP_, nr, nbc, aloc_ + (int64_t)i * WD_ * es_, alpha_ + b0 * es_, 1.0, false, false, 0, nullptr);
-                dev_->dmll_rect_acc(xloc_ + (int64_t)i * WD_ * d_ * es_, nr, x_ + b0 * d_ * es_, nbc, d_, Wi, ldP_, n_hyp, dacc_);
+            // the chunk's rows below the diagonal block in one pass: real observations only (they are a prefix: only the last
+            // global block carries identity padding, which has no kernel entries)
+            int64_t nr = 0;
+            for (int i = ia; i < i1; ++i) nr += std::max<int64_t>(0, std::min<int64_t>(WD_, n_ - (int64_t)own_[i] * WD_));
+            if (nr > 0) {
+                char* Wi = Wt_ + (int64_t)(ia - i0) * WD_ * ldP_ * es_;
+                dev_->qblock(Wi, ldP_, nr, nbc, aloc_ + (int64_t)ia * WD_ * es_, alpha_ + b0 * es_, 1.0, false, false, 0, nullptr);
+                dev_->dmll_rect_acc(xloc_ + (int64_t)ia * WD_ * d_ * es_, nr, x_ + b0 * d_ * es_, nbc, d_, Wi, ldP_, n_hyp, dacc_);
             }
-            (void)r0;
         }
     }
     std::vector<double> h((size_t)n_hyp + 2);

@@ -163,6 +163,7 @@ inline int64_t side_cap(const gpmi_ctx* c, int64_t nwg) {
 
 struct gpmi_gp {
     gpmi_ctx* ctx = nullptr;
+    void* blocked = nullptr;  // non-null: a BLOCKED handle (gpmi_gp_create_blocked; dev_hip.hip / blocked.cpp) — the dense fields below are unused
     int dtype = 64;
     int d = 0;
     int64_t n = 0;     // observations
@@ -196,6 +197,11 @@ struct gpmi_gp {
 };
 
 namespace gpmi {
+
+// blocked handles (dev_hip.hip)
+class BlockedGP;
+BlockedGP* blocked_of(gpmi_gp* gp);
+void blocked_destroy(void* p);
 
 // RAII-free helpers -------------------------------------------------------------------------
 #define GPMI_HIP(ctx, call)                                                                     \

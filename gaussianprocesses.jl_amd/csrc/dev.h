@@ -18,8 +18,10 @@ namespace gpmi {
 //   DS_MAIN  the context's stream (uploads, assembly, solves, predict)
 //   DS_UPD   the trailing updates and panel solves that run BESIDE the chain / the exchange: with reserved compute units
 //            the CU-masked update stream (common.h upd_stream), otherwise the main stream with free workgroup slots
-//   DS_SIDE  the look-ahead chain (factor + invert the next diagonal block) and the panel exchange (collectives)
-enum DevStream { DS_MAIN = 0, DS_UPD = 1, DS_SIDE = 2 };
+//   DS_SIDE  the look-ahead chain (factor + invert the next diagonal block): the CU-masked chain stream
+//   DS_COMM  the panel exchange: collectives and their scatter copies (an unmasked stream: RCCL's kernels and the copies
+//            land on the compute units the masked update leaves free)
+enum DevStream { DS_MAIN = 0, DS_UPD = 1, DS_SIDE = 2, DS_COMM = 3 };
 
 // product flags: the GemmFlags of common.h that the driver uses, by value
 enum DevGemmFlags { DG_OVERWRITE = 1, DG_KSTART_ROW = 2, DG_KEND_COL = 8, DG_NEGOUT = 256 };
@@ -47,7 +49,7 @@ struct Dev {
     virtual void use(DevStream s) = 0;
     virtual DevEvent record() = 0;   // on the current stream
     virtual void wait(DevEvent e) = 0;  // the current stream waits for e
-    virtual void sync() = 0;         // host waits for all three streams; returns after device errors are collected in err
+    virtual void sync() = 0;         // host waits for every stream; returns after device errors are collected in err
     virtual void* native_stream() = 0;  // the current stream, as the communicator wants it (hipStream_t; nullptr on the host)
     // ---- kernel program ----
     virtual int set_kernel(const gpmi_kernel* k, int d, double* kdiag, int* n_hyp) = 0;  // GPMI_* status
@@ -71,7 +73,6 @@ struct Dev {
     // ---- reductions over rows ----
     virtual void row_gemv(const void* R, int64_t ldr, int64_t P, int64_t n, const void* v, const void* add, void* out) = 0;  // out = add + R[:, :n] v
     virtual void row_sumsq_acc(const void* R, int64_t ldr, int64_t P, int64_t n, double* acc) = 0;                             // acc[p] += |R[p, :n]|^2 (double)
-    virtual void vec_axpy(void* y, const void* x, int64_t n, double a) = 0;                                                    // y += a x (elements)
     virtual double dot(const void* a, const void* b, int64_t n) = 0;                                                            // synchronises
     // ---- gradient (update_dmll!, GPE.jl:298-324) ----
     virtual void set_identity_rows(void* R, int64_t ldr, int64_t nrows, int64_t col_off) = 0;  // R = 0 except R[i][col_off + i] = 1

@@ -1,0 +1,555 @@
+// dev_hip.hip — the gfx950 back end of the blocked exact-GP driver (dev.h / blocked.cpp), the communicators (RCCL opened at
+// run time; caller-supplied callbacks) and the C ABI that creates blocked handles (include/gpmi.h: gpmi_gp_create_blocked,
+// gpmi_comm_*).  Every Dev operation is one of the launchers of common.h on the context's streams:
+//   DS_MAIN  ctx->stream as it was when the call began
+//   DS_UPD   the CU-masked update stream (248 CUs) when the context reserves compute units, else the main stream with
+//            `lookahead_slots` workgroup slots left free
+//   DS_SIDE  the CU-masked chain stream (the 8 reserved CUs), else the high-priority side stream; launches are capped to the
+//            free slots (common.h side_cap)
+//   DS_COMM  the unmasked high-priority stream: RCCL's kernels and the scatter copies land on the reserved CUs
+#include <dlfcn.h>
+#include <math.h>
+#include <string.h>
+
+#include <memory>
+#include <vector>
+
+#include "blocked.h"
+#include "chol.h"
+#include "comm_callbacks.h"
+#include "common.h"
+
+namespace gpmi {
+// defined in api.hip
+template <typename T>
+int super_factor_block(gpmi_ctx* c, T* blk, int64_t ld, int64_t w, T* linv, T* invdiag, T* lw, int64_t pivot_base);
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void row_sumsq_acc_kernel(const T* __restrict__ R, int64_t ldr, int64_t n, double* __restrict__ acc) {
+    __shared__ double sh[256];
+    const T* r = R + (int64_t)blockIdx.x * ldr;
+    double s = 0.0;
+    for (int64_t j = threadIdx.x; j < n; j += 256) {
+        const double v = (double)r[j];
+        s += v * v;
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) acc[blockIdx.x] += sh[0];
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void dot_kernel(const T* __restrict__ a, const T* __restrict__ b, int64_t n, double* __restrict__ out) {
+    __shared__ double sh[1024];
+    double s = 0.0;
+    for (int64_t j = threadIdx.x; j < n; j += 1024) s += (double)a[j] * (double)b[j];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 512; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+template <typename T>
+__global__ void identity_rows_kernel(T* __restrict__ R, int64_t ldr, int64_t nrows, int64_t col_off) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nrows) R[i * ldr + col_off + i] = T(1);
+}
+
+// Wt <- w (a_i a_j - sgn Wt) in place; diagonal blocks add sum_{i < ntrace} (a_i^2 - K^-1_ii) to *trace_acc (one workgroup
+// does the trace, in a fixed order: deterministic)
+template <typename T>
+__global__ __launch_bounds__(256) void qblock_kernel(T* __restrict__ Wt, int64_t ld, int64_t rows, int64_t cols, const T* __restrict__ ar,
+                                                     const T* __restrict__ ac, double w, double sgn) {
+    const int64_t i = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < rows && j < cols) {
+        const double q = (double)ar[i] * (double)ac[j] - sgn * (double)Wt[i * ld + j];
+        Wt[i * ld + j] = (T)(w * q);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(1024) void qtrace_kernel(const T* __restrict__ Wt, int64_t ld, int64_t ntrace, const T* __restrict__ ar, double sgn,
+                                                      double* __restrict__ trace_acc) {
+    __shared__ double sh[1024];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < ntrace; i += 1024) s += (double)ar[i] * (double)ar[i] - sgn * (double)Wt[i * ld + i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 512; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) trace_acc[0] += sh[0];
+}
+__global__ void acc_add_kernel(double* __restrict__ out, const double* __restrict__ add, int n) {
+    const int i = threadIdx.x;
+    if (i < n) out[i] += add[i];
+}
+
+template <typename T>
+struct HipDev : Dev {
+    gpmi_ctx* c;
+    hipStream_t main_s = nullptr;
+    double* partial = nullptr;   // dmll partials
+    int64_t partial_cap = 0;
+    explicit HipDev(gpmi_ctx* ctx) : c(ctx) { es = (int)sizeof(T); }
+    ~HipDev() override {
+        if (partial) hipFree(partial);
+    }
+    void note(hipError_t e, const char* what) {
+        if (e != hipSuccess && err.empty()) err = std::string(what) + ": " + hipGetErrorString(e);
+    }
+    void* alloc(int64_t bytes) override {
+        void* p = nullptr;
+        const hipError_t e = hipMalloc(&p, (size_t)bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            err = std::string("hipMalloc of ") + std::to_string(bytes >> 20) + " MiB: " + hipGetErrorString(e);
+            return nullptr;
+        }
+        return p;
+    }
+    void release(void* p) override { (void)hipFree(p); }
+    void zero(void* p, int64_t bytes) override { note(hipMemsetAsync(p, 0, (size_t)bytes, c->stream), "hipMemsetAsync"); }
+    void copy2d(void* dst, int64_t dp, const void* src, int64_t sp, int64_t w, int64_t rows) override {
+        if (rows <= 0 || w <= 0) return;
+        note(hipMemcpy2DAsync(dst, (size_t)dp, src, (size_t)sp, (size_t)w, (size_t)rows, hipMemcpyDeviceToDevice, c->stream), "hipMemcpy2DAsync");
+    }
+    void upload(void* dst, const void* host, int64_t bytes) override {
+        note(hipMemcpyAsync(dst, host, (size_t)bytes, hipMemcpyHostToDevice, c->stream), "hipMemcpyAsync H2D");
+        note(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+    }
+    void download(void* host, const void* src, int64_t bytes) override {
+        note(hipMemcpyAsync(host, src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream), "hipMemcpyAsync D2H");
+        note(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+    }
+    // ---- streams ----
+    bool masked() const { return c->upd_stream && c->side_masked && c->reserved_cus > 0; }
+    void begin_call() override {
+        (void)hipSetDevice(c->device);
+        if (!main_s) main_s = c->stream;
+        c->stream = main_s;
+        c->num_cus = full_cus();
+        c->beside_update = false;
+        c->gemm_reserve = 0;
+        la_reset(c);
+    }
+    int full_cus_ = 0;
+    int full_cus() {
+        if (!full_cus_) full_cus_ = c->num_cus;
+        return full_cus_;
+    }
+    void use(DevStream s) override {
+        c->beside_update = false;
+        c->gemm_reserve = 0;
+        c->num_cus = full_cus();
+        switch (s) {
+            case DS_MAIN: c->stream = main_s; break;
+            case DS_UPD:
+                if (masked()) {
+                    c->stream = c->upd_stream;
+                    c->num_cus = full_cus() - c->reserved_cus;
+                } else {
+                    c->stream = main_s;
+                    c->gemm_reserve = c->side_stream ? c->lookahead_slots : 0;
+                }
+                break;
+            case DS_SIDE:
+                c->stream = masked() ? c->side_masked : (c->side_stream ? c->side_stream : main_s);
+                c->beside_update = c->stream != main_s;
+                break;
+            case DS_COMM: c->stream = c->side_stream ? c->side_stream : main_s; break;
+        }
+    }
+    DevEvent record() override {
+        hipEvent_t e = la_event(c);
+        note(hipEventRecord(e, c->stream), "hipEventRecord");
+        return (DevEvent)e;
+    }
+    void wait(DevEvent e) override {
+        if (e) note(hipStreamWaitEvent(c->stream, (hipEvent_t)e, 0), "hipStreamWaitEvent");
+    }
+    void sync() override {
+        for (hipStream_t s : {c->upd_stream, c->side_masked, c->side_stream, main_s})
+            if (s) note(hipStreamSynchronize(s), "hipStreamSynchronize");
+        note(hipGetLastError(), "device");
+        c->stream = main_s;
+        c->num_cus = full_cus();
+        c->beside_update = false;
+        c->gemm_reserve = 0;
+    }
+    void* native_stream() override { return (void*)c->stream; }
+    // ---- ops ----
+    int set_kernel(const gpmi_kernel* k, int d, double* kdiag, int* n_hyp) override {
+        const int rc = upload_program(c, k, d);
+        if (rc != GPMI_OK) {
+            err = c->err;
+            return rc;
+        }
+        *kdiag = c->h_prog->kdiag;
+        *n_hyp = c->h_prog->n_hyp;
+        return GPMI_OK;
+    }
+    void assemble(const void* x, int64_t n, int d, int64_t row_off, int64_t nrows, double nugget, const double* nvec, void* A, int64_t ld,
+                  int64_t ncols) override {
+        const int64_t na = std::max<int64_t>(0, std::min<int64_t>(nrows, n - row_off));
+        const int64_t xoff = std::min<int64_t>(row_off, n - 1) * d;
+        launch_cov<T>(c, (const T*)x + xoff, na, (const T*)x, n, d, (T*)A, ld, nrows, ncols, COV_LOWER | COV_NUGGET | COV_PAD_IDENTITY, nugget, nvec,
+                      row_off);
+    }
+    void cov_rows(const void* xa, int64_t na, const void* xb, int64_t nb, int d, void* C, int64_t ldc, int64_t ncols_total) override {
+        launch_cov<T>(c, (const T*)xa, na, (const T*)xb, nb, d, (T*)C, ldc, na, ncols_total, 0, 0.0, nullptr);
+    }
+    int super_factor(void* blk, int64_t ld, int64_t w, void* linv, void* invd, void* lw, int64_t pivot_base) override {
+        const int rc = super_factor_block<T>(c, (T*)blk, ld, w, (T*)linv, (T*)invd, (T*)lw, pivot_base);
+        if (rc != GPMI_OK && err.empty()) err = c->err;
+        return rc;
+    }
+    void gemm(void* C, int64_t ldc, const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, DevShape s,
+              int flags) override {
+        if (M <= 0 || N <= 0 || K <= 0) return;
+        TileShape sh{0, 0, s.mode, s.g0, s.G, s.nstair, s.tpb > 0 ? s.tpb : 2};
+        launch_gemm_shape<T>(c, (T*)C, ldc, (const T*)A, lda, (const T*)B, ldb, M, N, K, sh, c->d_info, flags);
+    }
+    void bsolve_block(const void* Lrows, int64_t ld, int64_t c0, int64_t nb, const void* linv, void* z, void* alpha) override {
+        for (int64_t j = nb - IB; j >= 0; j -= IB)
+            launch_bsolve_step<T>(c, (const T*)Lrows + j * ld, ld, c0 + j, (const T*)linv + (j / IB) * IB * IB, (T*)z, (T*)alpha);
+    }
+    double logdiag_sum(const void* A, int64_t ld, int64_t nrows, int64_t col_off) override {
+        launch_logdiag<T>(c, (const T*)A, ld, nrows, col_off, c->d_scal);
+        note(hipMemcpyAsync(c->h_scal, c->d_scal, sizeof(double), hipMemcpyDeviceToHost, c->stream), "hipMemcpyAsync");
+        note(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+        return c->h_scal[0];
+    }
+    int64_t info(bool reset) override {
+        if (reset) {
+            note(hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream), "hipMemsetAsync");
+            return 0;
+        }
+        int h = 0;
+        note(hipMemcpyAsync(&h, c->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream), "hipMemcpyAsync");
+        note(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+        return h;
+    }
+    void row_gemv(const void* R, int64_t ldr, int64_t P, int64_t n, const void* v, const void* add, void* out) override {
+        launch_row_gemv<T>(c, (const T*)R, ldr, P, n, (const T*)v, (const T*)add, (T*)out);
+    }
+    void row_sumsq_acc(const void* R, int64_t ldr, int64_t P, int64_t n, double* acc) override {
+        if (P > 0) hipLaunchKernelGGL(row_sumsq_acc_kernel<T>, dim3((unsigned)P), dim3(256), 0, c->stream, (const T*)R, ldr, n, acc);
+    }
+    double dot(const void* a, const void* b, int64_t n) override {
+        hipLaunchKernelGGL(dot_kernel<T>, dim3(1), dim3(1024), 0, c->stream, (const T*)a, (const T*)b, n, c->d_scal + 4);
+        note(hipMemcpyAsync(c->h_scal + 4, c->d_scal + 4, sizeof(double), hipMemcpyDeviceToHost, c->stream), "hipMemcpyAsync");
+        note(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+        return c->h_scal[4];
+    }
+    void set_identity_rows(void* R, int64_t ldr, int64_t nrows, int64_t col_off) override {
+        note(hipMemsetAsync(R, 0, (size_t)(nrows * ldr) * sizeof(T), c->stream), "hipMemsetAsync");
+        hipLaunchKernelGGL(identity_rows_kernel<T>, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, c->stream, (T*)R, ldr, nrows, col_off);
+    }
+    void qblock(void* Wt, int64_t ld, int64_t rows, int64_t cols, const void* ar, const void* ac, double w, bool neg, bool diag, int64_t ntrace,
+                double* trace_acc) override {
+        if (rows <= 0 || cols <= 0) return;
+        const double sgn = neg ? -1.0 : 1.0;
+        if (diag && trace_acc && ntrace > 0)
+            hipLaunchKernelGGL(qtrace_kernel<T>, dim3(1), dim3(1024), 0, c->stream, (const T*)Wt, ld, ntrace, (const T*)ar, sgn, trace_acc);
+        hipLaunchKernelGGL(qblock_kernel<T>, dim3((unsigned)((cols + 255) / 256), (unsigned)rows), dim3(256), 0, c->stream, (T*)Wt, ld, rows, cols,
+                           (const T*)ar, (const T*)ac, w, sgn);
+    }
+    void dmll_rect_acc(const void* xa, int64_t na, const void* xb, int64_t nb, int d, const void* Wt, int64_t ld, int n_hyp, double* out) override {
+        if (na <= 0 || nb <= 0) return;
+        const int64_t nblocks = ((na + 63) / 64) * ((nb + 63) / 64);
+        const int64_t need = (nblocks + 1) * (int64_t)(n_hyp + 1) * 8;
+        if (partial_cap < need) {
+            note(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+            if (partial) (void)hipFree(partial);
+            partial = nullptr;
+            partial_cap = 0;
+            if (hipMalloc(&partial, (size_t)(2 * need)) != hipSuccess) {
+                (void)hipGetLastError();
+                if (err.empty()) err = "out of device memory (gradient partial sums)";
+                return;
+            }
+            partial_cap = 2 * need;
+        }
+        const int64_t nb2 = launch_dmll_rect<T>(c, (const T*)xa, na, (const T*)xb, nb, d, (const T*)Wt, ld, partial, n_hyp);
+        double* red = partial + nb2 * (n_hyp + 1);
+        launch_reduce_partials(c, partial, nb2, n_hyp + 1, red);
+        hipLaunchKernelGGL(acc_add_kernel, dim3(1), dim3(64), 0, c->stream, out, (const double*)red, n_hyp);
+    }
+};
+
+// ---- RCCL, opened at run time (no link-time dependency: a single-GPU user never loads it) --------------------------------
+struct Rccl {
+    typedef struct { char internal[128]; } UniqueId;
+    void* lib = nullptr;
+    int (*GetUniqueId)(UniqueId*) = nullptr;
+    int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string err;
+    bool load() {
+        if (lib) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);  // the copy a host program (torch) already loaded, if any
+            if (lib) break;
+        }
+        if (!lib)
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+                lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (lib) break;
+            }
+        if (!lib) {
+            err = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : "");
+            return false;
+        }
+        auto sym = [&](const char* n) { return dlsym(lib, n); };
+        GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
+        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        Broadcast = (decltype(Broadcast))sym("ncclBroadcast");
+        AllGather = (decltype(AllGather))sym("ncclAllGather");
+        AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
+        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        if (!GetUniqueId || !CommInitRank || !CommDestroy || !Broadcast || !AllGather || !AllReduce) {
+            err = "librccl.so lacks an nccl* entry point";
+            return false;
+        }
+        return true;
+    }
+};
+static Rccl g_rccl;
+
+// nccl data types / ops by value (nccl.h): ncclInt8 0 / ncclChar 0, ncclFloat32 7, ncclFloat64 8; ncclSum 0, ncclMax 2, ncclMin 3
+struct RcclComm : Comm {
+    void* comm = nullptr;
+    gpmi_ctx* ctx;
+    double* d_tmp = nullptr;
+    explicit RcclComm(gpmi_ctx* c) : ctx(c) {}
+    ~RcclComm() override {
+        if (comm) g_rccl.CommDestroy(comm);
+        if (d_tmp) (void)hipFree(d_tmp);
+    }
+    int broadcast(void* buf, int64_t bytes, int root, void* stream) override {
+        return g_rccl.Broadcast(buf, buf, (size_t)bytes, 0, root, comm, (hipStream_t)stream);
+    }
+    int all_gather(const void* send, void* recv, int64_t bytes_each, void* stream) override {
+        return g_rccl.AllGather(send, recv, (size_t)bytes_each, 0, comm, (hipStream_t)stream);
+    }
+    int all_reduce_sum(void* buf, int64_t count, int es, void* stream) override {
+        return g_rccl.AllReduce(buf, buf, (size_t)count, es == 8 ? 8 : 7, 0, comm, (hipStream_t)stream);
+    }
+    int host_allreduce(double* vals, int n, int op) override {
+        if (n > 64) return 1;
+        if (!d_tmp && hipMalloc(&d_tmp, 64 * sizeof(double)) != hipSuccess) return 1;
+        hipStream_t s = ctx->stream;
+        if (hipMemcpyAsync(d_tmp, vals, (size_t)n * 8, hipMemcpyHostToDevice, s) != hipSuccess) return 1;
+        const int rc = g_rccl.AllReduce(d_tmp, d_tmp, (size_t)n, 8, op == 0 ? 0 : (op == 1 ? 3 : 2), comm, s);
+        if (rc) return rc;
+        if (hipMemcpyAsync(vals, d_tmp, (size_t)n * 8, hipMemcpyDeviceToHost, s) != hipSuccess) return 1;
+        return hipStreamSynchronize(s) == hipSuccess ? 0 : 1;
+    }
+};
+
+}  // namespace
+
+// what a blocked gpmi_gp owns (common.h: gpmi_gp::blocked)
+struct BlockedHandle {
+    std::unique_ptr<Dev> dev;
+    std::unique_ptr<BlockedGP> gp;
+};
+void blocked_destroy(void* p) { delete (BlockedHandle*)p; }
+BlockedGP* blocked_of(gpmi_gp* gp) { return gp && gp->blocked ? ((BlockedHandle*)gp->blocked)->gp.get() : nullptr; }
+
+}  // namespace gpmi
+
+struct gpmi_comm {
+    std::unique_ptr<gpmi::Comm> impl;
+};
+
+using namespace gpmi;
+
+extern "C" {
+
+int gpmi_comm_create_callbacks(const gpmi_comm_callbacks* cb, int rank, int world, gpmi_comm** out) {
+    if (!cb || !out || world < 1 || rank < 0 || rank >= world || !cb->broadcast || !cb->all_gather || !cb->all_reduce_sum || !cb->host_allreduce)
+        return GPMI_EARG;
+    gpmi_comm* cm = new gpmi_comm();
+    cm->impl.reset(new CallbackComm(*cb, rank, world));
+    *out = cm;
+    return GPMI_OK;
+}
+
+int gpmi_comm_unique_id(void* id128_out) {
+    if (!id128_out) return GPMI_EARG;
+    if (!g_rccl.load()) return GPMI_EDEVICE;
+    Rccl::UniqueId id;
+    if (g_rccl.GetUniqueId(&id) != 0) return GPMI_EDEVICE;
+    memcpy(id128_out, id.internal, 128);
+    return GPMI_OK;
+}
+
+int gpmi_comm_create_rccl(gpmi_ctx* c, const void* id128, int rank, int world, gpmi_comm** out) {
+    if (!c) return GPMI_EARG;
+    if (!id128 || !out || world < 1 || rank < 0 || rank >= world) {
+        c->err = "gpmi_comm_create_rccl: bad argument";
+        return GPMI_EARG;
+    }
+    if (!g_rccl.load()) {
+        c->err = g_rccl.err;
+        return GPMI_EDEVICE;
+    }
+    GPMI_HIP(c, hipSetDevice(c->device));
+    Rccl::UniqueId id;
+    memcpy(id.internal, id128, 128);
+    std::unique_ptr<RcclComm> rc(new RcclComm(c));
+    rc->rank = rank;
+    rc->world = world;
+    const int e = g_rccl.CommInitRank(&rc->comm, world, id, rank);
+    if (e != 0) {
+        c->err = std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error");
+        rc->comm = nullptr;
+        return GPMI_EDEVICE;
+    }
+    gpmi_comm* cm = new gpmi_comm();
+    cm->impl = std::move(rc);
+    *out = cm;
+    return GPMI_OK;
+}
+
+void gpmi_comm_destroy(gpmi_comm* cm) { delete cm; }
+
+// Every collective of the communicator on small device buffers with rank-dependent patterns, verified on the host: a launcher
+// calls this once before its first fit so that a broken transport fails HERE, with a message, instead of inside a factorisation.
+int gpmi_comm_selftest(gpmi_ctx* c, gpmi_comm* cm) {
+    if (!c) return GPMI_EARG;
+    if (!cm || !cm->impl) {
+        c->err = "gpmi_comm_selftest: null communicator";
+        return GPMI_EARG;
+    }
+    Comm* k = cm->impl.get();
+    GPMI_HIP(c, hipSetDevice(c->device));
+    const int W = k->world, r = k->rank, n = 1000;
+    double *d_a = nullptr, *d_g = nullptr;
+    float* d_f = nullptr;
+    GPMI_HIP(c, hipMalloc(&d_a, n * sizeof(double)));
+    GPMI_HIP(c, hipMalloc(&d_g, (size_t)W * n * sizeof(double)));
+    GPMI_HIP(c, hipMalloc(&d_f, n * sizeof(float)));
+    std::vector<double> h(n), hg((size_t)W * n);
+    std::vector<float> hf(n);
+    std::string bad;
+    auto fill = [&](double scale) {
+        for (int i = 0; i < n; ++i) {
+            h[i] = scale * (r + 1) + 0.001 * i;
+            hf[i] = (float)(r + 1) + 0.5f * (float)(i % 7);
+        }
+        (void)hipMemcpy(d_a, h.data(), n * sizeof(double), hipMemcpyHostToDevice);
+        (void)hipMemcpy(d_f, hf.data(), n * sizeof(float), hipMemcpyHostToDevice);
+    };
+    hipStream_t s = c->stream;
+    int rc = 0;
+    // broadcast from the last rank
+    fill(1.0);
+    rc |= k->broadcast(d_a, n * sizeof(double), W - 1, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h.data(), d_a, n * sizeof(double), hipMemcpyDeviceToHost);
+    for (int i = 0; i < n && bad.empty(); ++i)
+        if (h[i] != 1.0 * W + 0.001 * i) bad = "broadcast";
+    // all-gather
+    fill(2.0);
+    rc |= k->all_gather(d_a, d_g, n * sizeof(double), s);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(hg.data(), d_g, (size_t)W * n * sizeof(double), hipMemcpyDeviceToHost);
+    for (int q = 0; q < W && bad.empty(); ++q)
+        for (int i = 0; i < n; ++i)
+            if (hg[(size_t)q * n + i] != 2.0 * (q + 1) + 0.001 * i) {
+                bad = "all_gather";
+                break;
+            }
+    // all-reduce, double and float
+    fill(3.0);
+    rc |= k->all_reduce_sum(d_a, n, 8, s);
+    rc |= k->all_reduce_sum(d_f, n, 4, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h.data(), d_a, n * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(hf.data(), d_f, n * sizeof(float), hipMemcpyDeviceToHost);
+    const double tri = 0.5 * W * (W + 1);
+    for (int i = 0; i < n && bad.empty(); ++i) {
+        if (fabs(h[i] - (3.0 * tri + 0.001 * i * W)) > 1e-9) bad = "all_reduce_sum (double)";
+        if (fabsf(hf[i] - ((float)tri + 0.5f * (float)(i % 7) * (float)W)) > 1e-3f) bad = "all_reduce_sum (float)";
+    }
+    // host scalars
+    double v[3] = {(double)(r + 1), (double)(r + 1), (double)(r + 1)};
+    rc |= k->host_allreduce(v, 1, 0);
+    rc |= k->host_allreduce(v + 1, 1, 1);
+    rc |= k->host_allreduce(v + 2, 1, 2);
+    if (bad.empty() && (v[0] != tri || v[1] != 1.0 || v[2] != (double)W)) bad = "host_allreduce";
+    (void)hipFree(d_a);
+    (void)hipFree(d_g);
+    (void)hipFree(d_f);
+    if (rc != 0 || !bad.empty()) {
+        c->err = "gpmi_comm_selftest: " + (bad.empty() ? std::string("a collective returned an error") : bad + " delivered wrong data") +
+                 " (rank " + std::to_string(r) + " of " + std::to_string(W) + ")";
+        return GPMI_EDEVICE;
+    }
+    return GPMI_OK;
+}
+
+int gpmi_gp_create_blocked(gpmi_ctx* c, gpmi_comm* comm, int dtype, int d, int64_t n, const void* x, int64_t block_rows, int stripe_blocks,
+                           gpmi_gp** out) {
+    if (!c) return GPMI_EARG;
+    if (!out || !x || (dtype != 64 && dtype != 32) || d <= 0 || d > MAX_D || n <= 0 || block_rows < 0 || stripe_blocks < 0) {
+        c->err = "gpmi_gp_create_blocked: bad argument (dtype must be 64|32, 1 <= d <= 64, n >= 1)";
+        return GPMI_EARG;
+    }
+    *out = nullptr;
+    GPMI_HIP(c, hipSetDevice(c->device));
+    std::unique_ptr<BlockedHandle> h(new BlockedHandle());
+    if (dtype == 64)
+        h->dev.reset(new HipDev<double>(c));
+    else
+        h->dev.reset(new HipDev<float>(c));
+    BlockedOpts o;
+    o.block = block_rows;
+    o.stripe_blocks = stripe_blocks;
+    h->gp.reset(new BlockedGP(h->dev.get(), comm ? comm->impl.get() : nullptr, d, n, o));
+    const int rc = h->gp->init(x);
+    if (rc != GPMI_OK) {
+        c->err = h->gp->error();
+        return rc;
+    }
+    gpmi_gp* gp = new gpmi_gp();
+    gp->ctx = c;
+    gp->dtype = dtype;
+    gp->d = d;
+    gp->n = n;
+    gp->blocked = h.release();
+    *out = gp;
+    return GPMI_OK;
+}
+
+int gpmi_gp_blocked_info(gpmi_gp* gp, int64_t* block_rows, int32_t* n_stripes, int64_t* factor_bytes) {
+    BlockedGP* b = blocked_of(gp);
+    if (!b) {
+        if (gp && gp->ctx) gp->ctx->err = "gpmi_gp_blocked_info: not a blocked handle";
+        return GPMI_EARG;
+    }
+    if (block_rows) *block_rows = b->block_rows();
+    if (n_stripes) *n_stripes = b->nstripes();
+    if (factor_bytes) *factor_bytes = b->stored_bytes();
+    return GPMI_OK;
+}
+
+}  // extern "C"

@@ -28,7 +28,20 @@ SYMBOLS = [
     "gpmi_dev_update", "gpmi_dev_bsolve_block", "gpmi_dev_row_gemv", "gpmi_dev_row_var", "gpmi_dev_logdiag_sum",
     "gpmi_dev_info", "gpmi_dev_sync", "gpmi_dev_update_blocks", "gpmi_dev_super_factor", "gpmi_dev_super_rows",
     "gpmi_dev_side_begin", "gpmi_dev_side_end", "gpmi_dev_side_join", "gpmi_ctx_set_stream",
+    "gpmi_comm_create_callbacks", "gpmi_comm_unique_id", "gpmi_comm_create_rccl", "gpmi_comm_destroy", "gpmi_comm_selftest", "gpmi_gp_create_blocked",
+    "gpmi_gp_blocked_info",
 ]
+
+
+class GpmiCommCallbacks(C.Structure):
+    """gpmi_comm_callbacks (include/gpmi.h): collectives on device buffers supplied by the host program"""
+    _fields_ = [
+        ("user", C.c_void_p),
+        ("broadcast", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)),
+        ("all_gather", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)),
+        ("all_reduce_sum", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)),
+        ("host_allreduce", C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_int32)),
+    ]
 
 
 class GpmiKernel(C.Structure):
@@ -135,6 +148,14 @@ def load():
     lib.gpmi_dev_side_end.argtypes = [vp]
     lib.gpmi_dev_side_join.argtypes = [vp]
     lib.gpmi_ctx_set_stream.argtypes = [vp, vp, C.c_int]
+    lib.gpmi_comm_create_callbacks.argtypes = [C.POINTER(GpmiCommCallbacks), ci, ci, C.POINTER(vp)]
+    lib.gpmi_comm_unique_id.argtypes = [vp]
+    lib.gpmi_comm_create_rccl.argtypes = [vp, vp, ci, ci, C.POINTER(vp)]
+    lib.gpmi_comm_destroy.argtypes = [vp]
+    lib.gpmi_comm_destroy.restype = None
+    lib.gpmi_comm_selftest.argtypes = [vp, vp]
+    lib.gpmi_gp_create_blocked.argtypes = [vp, vp, ci, ci, i64, vp, i64, ci, C.POINTER(vp)]
+    lib.gpmi_gp_blocked_info.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_int32), C.POINTER(i64)]
     _lib = lib
     return lib
 

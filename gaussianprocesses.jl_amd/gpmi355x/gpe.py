@@ -123,7 +123,7 @@ class GPE:
         self.y = y
         self.dim, self.nobs = self.x.shape
         if self.covstrat is None:
-            self.cK = HIPPDMat(self.ctx, self.x, self.bits)  # alloc_cK (GP.jl:14-20)
+            self.cK = self._alloc_cK()  # alloc_cK (GP.jl:14-20)
         else:
             from .sparse import FullyIndepPDMat, FullyIndepStrat
             if not isinstance(self.covstrat, FullyIndepStrat):
@@ -132,6 +132,10 @@ class GPE:
             self.cK = FullyIndepPDMat(self.ctx, self.x, xu, self.bits)  # alloc_cK, fully_indep…:118-132
         self.initialise_target()
         return self
+
+    def _alloc_cK(self):
+        """alloc_cK(::CovarianceStrategy, nobs) — src/GP.jl:14-20: the dense device handle (dist.ShardedGPE: a blocked one)"""
+        return HIPPDMat(self.ctx, self.x, self.bits)
 
     # -- update_mll! : GPE.jl:202-212 ------------------------------------------
     def update_mll(self, noise=True, domean=True, kern=True):
@@ -327,13 +331,14 @@ def GP(x, y, mean=None, kernel=None, logNoise=-2.0, packed=False, **kw):
 
     packed=True: the factor is kept in PACKED storage (stripes of block-rows that stop at their own diagonal — no upper
     triangle, N²/2·(1 + 1/S) elements), which lifts the single-device ceiling from N ≈ 180 000 to
-    N ≈ 250 000 in fp64.  The object is the row-block path of gpmi355x.dist on one rank (update_mll / predict_f /
-    predict_y / set_params; no gradient at that size: it needs two more N × N matrices)."""
-    if packed:
+    N ≈ 250 000 in fp64.  comm=<gpmi355x.dist communicator>: the factor row-block sharded over the ranks (one process per GPU).
+    Either way the object is a GPE on a BLOCKED handle (gpmi_gp_create_blocked): every GPE verb works, update_dmll / optimize
+    included (the blocked gradient needs one more own-rows × N matrix instead of two N × N)."""
+    if packed or kw.get("comm") is not None:
         from .dist import ShardedGPE
 
         return ShardedGPE(x, y, mean, kernel, logNoise, dtype=kw.pop("dtype", np.float64), ctx=kw.pop("ctx", None),
-                          block=kw.pop("block", 1024), stripe_blocks=kw.pop("stripe_blocks", 8), **kw)
+                          block=kw.pop("block", 1024 if packed else None), stripe_blocks=kw.pop("stripe_blocks", 8 if packed else 0), **kw)
     return GPE(x, y, mean, kernel, logNoise, **kw)
 
 

@@ -86,7 +86,38 @@ withkernel(f, kd::KernelDesc) = GC.@preserve kd f(Ref(CKernel(length(kd.ops), po
                                                            pointer(kd.dims), pointer(kd.params), length(kd.params))))
 
 # ---- CovarianceStrategy + AbstractPDMat ----------------------------------------------------
-struct HIPCovariance <: CovarianceStrategy end
+# HIPCovariance()                      the dense device path: ONE n x n factor buffer (gpmi_gp_create)
+# HIPCovariance(packed=true)           a BLOCKED handle on one device (gpmi_gp_create_blocked): block-rows in stripes that stop
+#                                      at their own diagonal — no upper triangle, N = 250 000 in fp64 on 288 GB
+# HIPCovariance(comm=rccl_comm(...))   the factor row-block sharded over the ranks of a communicator: one Julia process per GPU
+#                                      (MPI.jl / Distributed launch), every rank runs the same script on the same data and gets the
+#                                      same mll / alpha / predictions / gradient back
+# update_mll!, update_dmll! / optimize!, predict_f (both full_cov branches) and predict_y work on all three; `\`, whiten!, tr,
+# Matrix(cK) are dense-only (libgpmi returns GPMI_EARG -> ArgumentError on a blocked handle).
+struct HIPCovariance <: CovarianceStrategy
+    packed::Bool
+    block::Int            # rows per block (0: library default — 1024 from 16 384 points)
+    stripe_blocks::Int    # local blocks per storage stripe (packed)
+    comm::Ptr{Cvoid}      # gpmi_comm* or C_NULL
+end
+HIPCovariance(; packed::Bool=false, block::Integer=0, stripe_blocks::Integer=8, comm::Ptr{Cvoid}=C_NULL) =
+    HIPCovariance(packed, block, packed ? stripe_blocks : 0, comm)
+blocked(s::HIPCovariance) = s.packed || s.comm != C_NULL
+
+# libgpmi's own RCCL communicator (librccl opened at run time).  `exchange(id::Union{Vector{UInt8},Nothing}) -> Vector{UInt8}` moves the
+# 128-byte unique id from rank 0 to every rank (MPI.bcast, a shared file, Distributed.remotecall_fetch ...).
+function rccl_comm(rank::Integer, world::Integer, exchange::Function)
+    id = rank == 0 ? Vector{UInt8}(undef, 128) : nothing
+    if rank == 0
+        ccall((:gpmi_comm_unique_id, libgpmi), Cint, (Ptr{UInt8},), id) == 0 || error("libgpmi: librccl.so could not be opened")
+    end
+    id = exchange(id)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(context(), ccall((:gpmi_comm_create_rccl, libgpmi), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint, Ptr{Ptr{Cvoid}}),
+                           context(), id, rank, world, h))
+    check(context(), ccall((:gpmi_comm_selftest, libgpmi), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), context(), h[]))   # fail here, not inside a fit
+    h[]
+end
 GaussianProcesses.KernelData(k::Kernel, X1::AbstractMatrix, X2::AbstractMatrix, ::HIPCovariance) = EmptyData()
 
 mutable struct HIPPDMat <: AbstractPDMat{Float64}
@@ -94,14 +125,15 @@ mutable struct HIPPDMat <: AbstractPDMat{Float64}
     n::Int
     xref::Any            # the x the handle was created for (re-created by update_cK! when it changes)
     xsum::UInt64         # content checksum of that x at upload time (in-place mutation of gp.x is detected, see ensure_handle!)
-    function HIPPDMat(n)
-        a = new(C_NULL, n, nothing, UInt64(0))
+    strat::HIPCovariance # dense, packed or sharded (decides which create call makes the handle)
+    function HIPPDMat(n, strat::HIPCovariance=HIPCovariance())
+        a = new(C_NULL, n, nothing, UInt64(0), strat)
         finalizer(a) do a
             a.handle == C_NULL || ccall((:gpmi_gp_destroy, libgpmi), Cvoid, (Ptr{Cvoid},), a.handle)
         end
     end
 end
-alloc_cK(::HIPCovariance, nobs) = HIPPDMat(nobs)                      # replaces src/GP.jl:14-20
+alloc_cK(s::HIPCovariance, nobs) = HIPPDMat(nobs, s)                  # replaces src/GP.jl:14-20
 Base.size(a::HIPPDMat) = (a.n, a.n); Base.size(a::HIPPDMat, i::Int) = a.n; dim(a::HIPPDMat) = a.n
 
 # The handle is keyed on the IDENTITY of the caller's x (gp.x, whatever its array type): the dense Float64 copy the C ABI
@@ -116,8 +148,14 @@ function ensure_handle!(a::HIPPDMat, x::AbstractMatrix)
         a.handle = C_NULL
         xd = x isa Matrix{Float64} ? x : Matrix{Float64}(x)
         h = Ref{Ptr{Cvoid}}(C_NULL)
-        rc = ccall((:gpmi_gp_create, libgpmi), Cint, (Ptr{Cvoid}, Cint, Cint, Int64, Ptr{Float64}, Ptr{Ptr{Cvoid}}),
-                   context(), 64, size(xd, 1), size(xd, 2), xd, h)
+        rc = if blocked(a.strat)
+            ccall((:gpmi_gp_create_blocked, libgpmi), Cint,
+                  (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Int64, Ptr{Float64}, Int64, Cint, Ptr{Ptr{Cvoid}}),
+                  context(), a.strat.comm, 64, size(xd, 1), size(xd, 2), xd, a.strat.block, a.strat.stripe_blocks, h)
+        else
+            ccall((:gpmi_gp_create, libgpmi), Cint, (Ptr{Cvoid}, Cint, Cint, Int64, Ptr{Float64}, Ptr{Ptr{Cvoid}}),
+                  context(), 64, size(xd, 1), size(xd, 2), xd, h)
+        end
         check(context(), rc); a.handle = h[]; a.xref = x; a.n = size(xd, 2); a.xsum = xchecksum(x)
     end
     a
@@ -240,7 +278,7 @@ predictMVN(xpred::AbstractMatrix, xtrain::AbstractMatrix, ytrain::AbstractVector
            alpha::AbstractVector, ::HIPCovariance, Ktrain::HIPPDMat) = hip_predict(Ktrain, kernel, meanf, xpred, true)
 
 # convenience constructor, as SoR(...)/FITC(...) are (src/sparse/subsetofregressors.jl:324-327)
-GP_hip(x::AbstractMatrix, y::AbstractVector, m::Mean, k::Kernel, logNoise=-2.0) = GPE(x, y, m, k, logNoise, HIPCovariance())
+GP_hip(x::AbstractMatrix, y::AbstractVector, m::Mean, k::Kernel, logNoise=-2.0; kw...) = GPE(x, y, m, k, logNoise, HIPCovariance(; kw...))
 
 # ---- FITC (src/sparse/fully_indep_train_conditional.jl) on the device ------------------------------------
 # HIPFITC plays FullyIndepStrat's role (:111-113); HIPFITCPDMat the FullyIndepPDMat's (:8-19): the n x m matrices,
@@ -329,5 +367,5 @@ end
 FITC_hip(x::AbstractMatrix, inducing::AbstractMatrix, y::AbstractVector, m::Mean, k::Kernel, logNoise::Real) =
     GPE(x, y, m, k, logNoise, HIPFITC(inducing))                        # as FITC(...) :333-336
 
-export HIPCovariance, HIPPDMat, GP_hip, HIPFITC, HIPFITCPDMat, FITC_hip
+export HIPCovariance, HIPPDMat, GP_hip, rccl_comm, HIPFITC, HIPFITCPDMat, FITC_hip
 end # module

@@ -159,6 +159,41 @@ int gpmi_fitc_alpha_u(gpmi_fitc*, void* out);
  * get_params order, dmll_noise (:243-257) -> *dnoise_out.  The mean part (GPE.jl:282-288) is grad_stack' * alpha on the host. */
 int gpmi_fitc_grad(gpmi_fitc*, const gpmi_kernel*, double log_noise, double* dkern_out, int32_t n_kern, double* dnoise_out);
 
+/* ---- blocked model object: packed storage on one device, row-block sharding over several ---------
+ * The same gpmi_gp handle type and the same gpmi_fit / gpmi_predict / gpmi_grad / gpmi_logdet / gpmi_factor_diag, with the
+ * factor of K + noise held as block-rows of block_rows = 256 * 2^s rows (0: 1024 from 16 384 points, 512 from 4096, else 256)
+ *   - dealt round-robin over the ranks of `comm` (one process per GPU; every rank makes the same calls with the same
+ *     arguments and receives the same results: mll, alpha, mu, var, gradient are replicated), and
+ *   - per rank, in stripes of stripe_blocks local blocks that stop at their own diagonal (0: one stripe = full rows), so the
+ *     upper triangle is never allocated: N^2 (1 + 1/S) / 2 elements instead of alloc_cK's two N x N (src/GP.jl:14-20).
+ * comm == NULL: one rank (a single device past the N x N ceiling: N = 250 000 fp64 on 288 GB).  gpmi_grad on a blocked
+ * handle needs ONE more own-rows x N matrix (N^2 / world) instead of two N x N.  gpmi_solve / gpmi_whiten / gpmi_inv_diag /
+ * gpmi_factor_to_host are not provided on a blocked handle (GPMI_EARG).                                                  */
+typedef struct gpmi_comm gpmi_comm;
+/* Collectives on DEVICE buffers, to be enqueued on the HIP stream passed as `stream` (ordered after the work already on it;
+ * later work on it must see the result); host_allreduce reduces n host doubles in place (op 0 sum, 1 min, 2 max).
+ * Every function returns 0 on success.                                                                                    */
+typedef struct gpmi_comm_callbacks {
+    void* user;
+    int (*broadcast)(void* user, void* buf, int64_t bytes, int root, void* stream);
+    int (*all_gather)(void* user, const void* send, void* recv /* world x bytes_each */, int64_t bytes_each, void* stream);
+    int (*all_reduce_sum)(void* user, void* buf, int64_t count, int elem_bytes /* 8: double, 4: float */, void* stream);
+    int (*host_allreduce)(void* user, double* vals, int32_t n, int32_t op);
+} gpmi_comm_callbacks;
+int gpmi_comm_create_callbacks(const gpmi_comm_callbacks* cb, int rank, int world, gpmi_comm** out);
+/* RCCL directly (librccl.so is opened at run time): rank 0 calls gpmi_comm_unique_id and hands the 128 bytes to every rank
+ * (any out-of-band channel: the launcher's store, a file, MPI); every rank then calls gpmi_comm_create_rccl on its context.  */
+int gpmi_comm_unique_id(void* id128_out);
+int gpmi_comm_create_rccl(gpmi_ctx*, const void* id128, int rank, int world, gpmi_comm** out);
+void gpmi_comm_destroy(gpmi_comm*);
+/* every collective of `comm` on small device buffers with rank-dependent patterns, verified on the host (collective call:
+ * all ranks).  A launcher runs it once before its first fit so that a broken transport fails with a message of its own.  */
+int gpmi_comm_selftest(gpmi_ctx*, gpmi_comm*);
+int gpmi_gp_create_blocked(gpmi_ctx*, gpmi_comm* comm /* NULL: one rank */, int dtype, int d, int64_t n, const void* x,
+                           int64_t block_rows, int stripe_blocks, gpmi_gp** out);
+/* what the handle occupies: rows per block, stripes on this rank, bytes of factor storage on this rank */
+int gpmi_gp_blocked_info(gpmi_gp*, int64_t* block_rows, int32_t* n_stripes, int64_t* factor_bytes);
+
 /* ---- cov: replaces cov / cov! (src/kernels/kernels.jl:31-71) -------------
  * out is n1 x n2 col-major; x2 == NULL selects the symmetric X1 === X2 form. */
 int gpmi_cov(gpmi_ctx*, const gpmi_kernel*, int dtype, int d, int64_t n1, const void* x1,

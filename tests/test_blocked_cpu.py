@@ -1,0 +1,180 @@
+"""N > 1 path on CPU: the PRODUCT's blocked-GP orchestration (gaussianprocesses.jl_amd/csrc/blocked.cpp — the source that
+libgpmi.so ships behind gpmi_gp_create_blocked) compiled with g++ against a host stand-in for the device (tests/hostdev),
+  * as one rank (plain rows and packed stripes),
+  * as G virtual ranks (threads, in-process communicator),
+  * as world_size-2 / -3 process groups under real torch.distributed collectives (gloo),
+checked against the oracle: mll, alpha, logdet, diag(U), predict_f (variance and full covariance), update_dmll! (kernel and
+noise parts) and the PosDefException contract.  The stand-in honours the tile shapes the driver requests exactly, so the
+block-cyclic ownership, the staircase bookkeeping, the look-ahead split of every update (U1 / U2a / U2b), the padded
+all-gather + scatter into global row order, the distributed backward solve and the order of the collectives are all pinned."""
+import math
+import os
+import socket
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import hostdev as H  # noqa: E402
+from oracle import gp_oracle as G  # noqa: E402
+
+SPEC = ("sum", ("se_ard", [-0.5, -0.3, -0.6], 0.2), ("mat52_iso", -0.4, -0.5))
+LN = math.log(0.1)
+MEAN = ("const", 0.2)
+
+
+def _problem(n, seed=5, p=37):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(size=(3, n))
+    y = np.sin(3 * x.sum(axis=0)) + 0.1 * rng.standard_normal(n)
+    return x, y, rng.uniform(size=(3, p))
+
+
+def _check_all(gp, x, y, xs, spec=SPEC, ln=LN, grad=True):
+    ref = G.update_mll(spec, x, y, ln, MEAN)
+    assert abs(gp.mll - ref["mll"]) <= 1e-10 * abs(ref["mll"]), (gp.mll, ref["mll"])
+    np.testing.assert_allclose(gp.alpha, ref["alpha"], rtol=1e-7, atol=1e-9)
+    assert abs(gp.logdet - ref["logdet"]) <= 1e-10 * abs(ref["logdet"])
+    np.testing.assert_allclose(gp.factor_diag(), np.diag(ref["U"]), rtol=1e-10)
+    mu, s2 = gp.predict_f(xs)
+    mu_o, s2_o = G.predict_f(spec, x, ref, xs, MEAN)
+    np.testing.assert_allclose(mu, mu_o, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(s2, s2_o, rtol=1e-6, atol=1e-10)
+    mu_f, S = gp.predict_f(xs, full_cov=True)
+    _, S_o = G.predict_f(spec, x, ref, xs, MEAN, full_cov=True)
+    np.testing.assert_allclose(mu_f, mu_o, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(S, S_o, rtol=1e-6, atol=1e-10)
+    if grad:
+        gp.update_dmll()
+        d = G.update_dmll(spec, x, y, ln, MEAN, fit=ref)
+        np.testing.assert_allclose(gp.dkern, d["dkern"], rtol=1e-8, atol=1e-9 * np.abs(d["dkern"]).max())
+        assert abs(gp.dnoise - d["dnoise"]) <= 1e-8 * abs(d["dnoise"])
+
+
+@pytest.mark.parametrize("n,block,stripes", [(300, 0, 0), (1100, 256, 2), (1900, 512, 0), (2100, 256, 3)])
+def test_one_rank(n, block, stripes):
+    x, y, xs = _problem(n)
+    gp = H.HostBlockedGP(SPEC, x, y, LN, mean_const=0.2, block=block, stripe_blocks=stripes)
+    assert gp.block_rows == (block or 256)
+    if stripes:
+        assert gp.nstripes > 1
+        nb = -(-n // gp.block_rows)
+        assert gp.stored_bytes < 0.8 * 8 * (nb * gp.block_rows) ** 2          # packed: no upper triangle
+    _check_all(gp, x, y, xs)
+    # a second fit with other hyper-parameters reuses every buffer
+    spec2 = ("sum", ("se_ard", [-0.45, -0.25, -0.55], 0.25), ("mat52_iso", -0.35, -0.45))
+    gp.set_spec(spec2, LN + 0.05)
+    gp.update_mll()
+    _check_all(gp, x, y, xs, spec2, LN + 0.05, grad=False)
+    gp.close()
+
+
+def _run_threads(world, body):
+    shared = H.ThreadComm.Shared(world)
+    errs, out = [], {}
+
+    def run(rank):
+        try:
+            out[rank] = body(H.ThreadComm(shared, rank))
+        except BaseException as e:  # noqa: BLE001
+            import traceback
+
+            errs.append((rank, repr(e), traceback.format_exc()))
+            shared.barrier.abort()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    return out
+
+
+@pytest.mark.parametrize("world,n,block,stripes", [(2, 700, 0, 0), (3, 1300, 0, 0), (2, 2100, 256, 2), (4, 2600, 256, 0), (3, 2500, 512, 0),
+                                                   (5, 900, 0, 0)])
+def test_virtual_ranks(world, n, block, stripes):
+    """(5, 900): more ranks than blocks — a rank that owns nothing still takes part in every collective."""
+    x, y, xs = _problem(n)
+    H.build()
+
+    def body(comm):
+        gp = H.HostBlockedGP(SPEC, x, y, LN, mean_const=0.2, comm=comm, block=block, stripe_blocks=stripes)
+        _check_all(gp, x, y, xs)
+        sb = gp.stored_bytes
+        gp.close()
+        return comm.log, sb
+
+    out = _run_threads(world, body)
+    # every rank issued the same collectives in the same order (what RCCL requires), and the factor really is split
+    logs = [out[r][0] for r in range(world)]
+    assert all(lg == logs[0] for lg in logs[1:]) and len(logs[0]) > 0
+    nb = -(-n // (block or 256))
+    if nb >= 2 * world:
+        full = 8 * (nb * (block or 256)) ** 2
+        assert max(out[r][1] for r in range(world)) < 0.75 * full
+
+
+def test_not_positive_definite_same_pivot_on_every_rank():
+    """far-apart points (K ~ I) with one exact duplicate inside block 1 (owned by rank 1): pivot 301 is exactly 1 - 1 = 0 for
+    dpotrf and for the sharded factorisation alike; every rank reports it, and the handle stays usable"""
+    n = 600
+    x = np.zeros((3, n))
+    x[0] = np.arange(n)
+    x[:, 300] = x[:, 5]
+    y = np.ones(n)
+    nspec = ("se_iso", -3.0, 0.0)
+    with pytest.raises(G.NotPosDef) as eo:
+        G.update_mll(nspec, x, y, -400.0)
+    assert eo.value.info == 301
+    H.build()
+
+    def body(comm):
+        with pytest.raises(H.PosDef) as ei:
+            H.HostBlockedGP(nspec, x, y, -400.0, comm=comm)
+        return ei.value.info
+
+    out = _run_threads(2, body)
+    assert out == {0: 301, 1: 301}
+
+
+# ---- real process groups (gloo) --------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gloo_worker(rank, world, port, n, block, stripes):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+
+    import hostdev as HH
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        x, y, xs = _problem(n)
+        gp = HH.HostBlockedGP(SPEC, x, y, LN, mean_const=0.2, comm=HH.TorchComm(), block=block, stripe_blocks=stripes)
+        _check_all(gp, x, y, xs)
+        gp.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,block,stripes", [(2, 1100, 0, 0), (3, 1300, 0, 0), (2, 2100, 256, 2), (2, 1900, 512, 0)])
+def test_gloo_process_groups(world, n, block, stripes):
+    import torch.multiprocessing as mp
+
+    H.build()
+    mp.spawn(_gloo_worker, args=(world, _free_port(), n, block, stripes), nprocs=world, join=True)

@@ -1,9 +1,17 @@
-"""Sharded path on the GPU: the real HIP building blocks (gpmi_dev_*) under the row-block-cyclic
-orchestration, (a) as a single rank and (b) as G virtual ranks (threads, each with its own gpmi context and
-stream) sharing the one GPU of the test box through an in-process communicator.  Together with
-tests/test_dist_cpu.py (real torch.distributed collectives, stand-in ops) this covers both halves of the
-multi-GPU path; the RCCL transport itself is torch.distributed's."""
+"""Blocked / sharded path on the GPU: the orchestration below the C ABI (gpmi_gp_create_blocked) on the real HIP kernels,
+  (a) as a single rank — plain rows and packed stripes — including the gradient and optimize,
+  (b) as G virtual ranks (threads, each with its own gpmi context) sharing the one GPU through an in-process communicator
+      built on gpmi_comm_callbacks,
+  (c) as TWO PROCESSES on the one GPU under real torch.distributed collectives (gloo on device buffers, through the product's
+      TorchDistComm) at N = 12 288 — stream ordering between asynchronous collectives and gpmi kernels across processes,
+  (d) RCCL itself in a group of one: libgpmi's own RCCL communicator (gpmi_comm_create_rccl) and torch's "nccl" backend behind
+      the callbacks, each through gpmi_comm_selftest.
+Together with tests/test_blocked_cpu.py (the same orchestration source on a host stand-in: thread ranks and gloo process groups
+of 2 and 3) this covers the multi-GPU path as far as one GPU allows; what cannot run here is RCCL between >= 2 devices."""
 import math
+import os
+import subprocess
+import sys
 import threading
 
 import numpy as np
@@ -17,6 +25,7 @@ from oracle import gp_oracle as G
 pytestmark = pytest.mark.gpu
 
 SPEC = ("sum", ("se_ard", [-0.5, -0.3, -0.6, -0.2], 0.2), ("mat52_iso", -0.4, -0.5))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _problem(n, p=45, seed=3):
@@ -27,26 +36,35 @@ def _problem(n, p=45, seed=3):
     return x, y, xs
 
 
-def _check(gp, x, y, xs, ln, mspec, rtol_mll=1e-10):
+def _check(gp, x, y, xs, ln, mspec, rtol_mll=1e-10, grad=False):
     ref = G.update_mll(SPEC, x, y, ln, mspec)
     assert abs(gp.mll - ref["mll"]) <= rtol_mll * abs(ref["mll"]), (gp.mll, ref["mll"])
     np.testing.assert_allclose(gp.alpha, ref["alpha"], rtol=1e-7, atol=1e-8 * np.abs(ref["alpha"]).max())
     assert abs(gp.logdet - ref["logdet"]) <= 1e-10 * abs(ref["logdet"])
+    np.testing.assert_allclose(gp.cK.factor_diag(), np.diag(ref["U"]), rtol=1e-9)
     mu, s2 = gp.predict_f(xs)
     mu_o, s2_o = G.predict_f(SPEC, x, ref, xs, mspec)
     np.testing.assert_allclose(mu, mu_o, rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(s2, s2_o, rtol=1e-6, atol=1e-10)
+    mu_f, S = gp.predict_f(xs, full_cov=True)                      # the other branch of predict_f (GP.jl:80-84)
+    _, S_o = G.predict_f(SPEC, x, ref, xs, mspec, full_cov=True)
+    np.testing.assert_allclose(mu_f, mu_o, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(S, S_o, rtol=1e-6, atol=1e-9)
+    if grad:
+        gp.update_dmll()
+        d = G.update_dmll(SPEC, x, y, ln, mspec, fit=ref)["dmll"]
+        np.testing.assert_allclose(gp.dmll, d, rtol=1e-6, atol=1e-8 * np.abs(d).max())
 
 
 @pytest.mark.parametrize("n,block", [(300, None), (1000, None), (1793, None), (5000, None), (3000, 1024), (4500, 2048)])
 def test_single_rank_device_ops(n, block):
-    """block None: 256-row blocks below 4096 points, 512 from there (dist.default_block); the look-ahead — next diagonal
-    block updated first, factored and inverted on the side stream under the rest of the update — runs at every step."""
+    """block None: 256-row blocks below 4096 points, 512 from there; every step runs the look-ahead pipeline (next diagonal
+    block factored and inverted on the chain stream under the update)."""
     x, y, xs = _problem(n)
     ln = math.log(0.1)
     gp = gd.ShardedGPE(x, y, g.MeanConst(0.1), g.from_spec(SPEC), ln, block=block)
     assert gp.WD == (block or (512 if n >= 4096 else 256))
-    _check(gp, x, y, xs, ln, ("const", 0.1))
+    _check(gp, x, y, xs, ln, ("const", 0.1), grad=True)
 
 
 @pytest.mark.parametrize("n,block,per", [(2300, 256, 2), (5000, 512, 3), (9000, 1024, 2)])
@@ -54,26 +72,59 @@ def test_single_rank_packed_stripes(n, block, per):
     """SURVEY §8f-3 on the device: stripes that stop at their own diagonal; every update is one launch per stripe."""
     x, y, xs = _problem(n)
     ln = math.log(0.1)
-    gp = gd.ShardedGPE(x, y, g.MeanConst(0.1), g.from_spec(SPEC), ln, block=block, stripe_blocks=per)
-    assert len(gp.S.items) > 1 and gp.S.items[0][2].shape[1] < gp.npad
-    _check(gp, x, y, xs, ln, ("const", 0.1))
+    gp = g.GP(x, y, g.MeanConst(0.1), g.from_spec(SPEC), ln, packed=True, block=block, stripe_blocks=per)
+    assert gp.cK.nstripes > 1 and gp.cK.factor_bytes < 0.8 * 8 * (gp.nblk * gp.WD) ** 2
+    _check(gp, x, y, xs, ln, ("const", 0.1), grad=True)
 
 
-@pytest.mark.parametrize("world,n,block", [(2, 1000, None), (3, 1793, None), (4, 2600, None), (2, 2600, 512), (3, 4200, 1024)])
-def test_virtual_ranks_on_one_gpu(world, n, block):
+def test_fp32_blocked_handle_vs_fp64_oracle():
+    x, y, xs = _problem(5000)
+    ln = math.log(0.1)
+    gp = g.GP(x, y, g.MeanZero(), g.from_spec(SPEC), ln, packed=True, block=512, stripe_blocks=3, dtype=np.float32)
+    ref = G.update_mll(SPEC, x, y, ln)
+    assert abs(gp.mll - ref["mll"]) <= 1e-2 * abs(ref["mll"])
+    mu, s2 = gp.predict_f(xs)
+    mu_o, s2_o = G.predict_f(SPEC, x, ref, xs)
+    np.testing.assert_allclose(mu, mu_o, rtol=1e-2, atol=1e-2 * np.abs(mu_o).max())
+    np.testing.assert_allclose(s2, s2_o, rtol=1e-2, atol=1e-2 * np.abs(s2_o).max())
+
+
+def test_optimize_on_a_packed_model_reaches_the_dense_optimum():
+    """optimize! (src/optimize.jl:19-37) on a blocked handle: target and gradient from gpmi_fit / gpmi_grad of the blocked driver;
+    same optimum as the dense device path from the same start."""
+    x, y, _ = _problem(1500)
+    k1 = g.SEArd([0.0, 0.0, 0.0, 0.0], 0.0)
+    k2 = g.SEArd([0.0, 0.0, 0.0, 0.0], 0.0)
+    dense = g.GP(x, y, g.MeanZero(), k1, -1.0)
+    packed = g.GP(x, y, g.MeanZero(), k2, -1.0, packed=True, block=256, stripe_blocks=2)
+    assert packed.mll == pytest.approx(dense.mll, rel=1e-10)
+    rd = g.optimize(dense, options={"maxiter": 12})
+    rp = g.optimize(packed, options={"maxiter": 12})
+    assert packed.mll > -1e300 and rp.fun == pytest.approx(rd.fun, rel=1e-6)
+    np.testing.assert_allclose(rp.x, rd.x, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("world,n,block,per", [(2, 1000, None, 0), (3, 1793, None, 0), (4, 2600, None, 0), (2, 2600, 512, 0), (3, 4200, 1024, 0),
+                                               (2, 3000, 256, 2)])
+def test_virtual_ranks_on_one_gpu(world, n, block, per):
     x, y, xs = _problem(n)
     ln = math.log(0.1)
     shared = LocalThreadComm.Shared(world)
-    errs = []
+    errs, logs = [], {}
 
     def run(rank):
         try:
-            ctx = g.Context(0)  # own stream per virtual rank
-            gp = gd.ShardedGPE(x, y, g.MeanConst(0.1), g.from_spec(SPEC), ln, comm=LocalThreadComm(shared, rank), ctx=ctx, block=block)
+            ctx = g.Context(0)  # own streams per virtual rank
+            comm = LocalThreadComm(shared, rank)
+            comm.selftest(ctx)
+            gp = gd.ShardedGPE(x, y, g.MeanConst(0.1), g.from_spec(SPEC), ln, comm=comm, ctx=ctx, block=block, stripe_blocks=per)
             assert gp.nown == len(range(rank, gp.nblk, world))
-            _check(gp, x, y, xs, ln, ("const", 0.1))
+            _check(gp, x, y, xs, ln, ("const", 0.1), grad=True)
+            logs[rank] = comm.log
         except BaseException as e:  # noqa: BLE001
-            errs.append((rank, repr(e)))
+            import traceback
+
+            errs.append((rank, repr(e), traceback.format_exc()[-1500:]))
             shared.barrier.abort()
 
     ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
@@ -82,6 +133,7 @@ def test_virtual_ranks_on_one_gpu(world, n, block):
     for t in ts:
         t.join()
     assert not errs, errs
+    assert all(logs[r] == logs[0] for r in range(1, world))
 
 
 def test_virtual_ranks_not_posdef():
@@ -111,38 +163,105 @@ def test_virtual_ranks_not_posdef():
     assert infos == [301, 301]
 
 
-def test_rccl_collectives_in_a_group_of_one():
-    """The RCCL calls themselves (broadcast / all_gather_into_tensor / all_reduce on the library's device buffers) with the
-    nccl backend in a single-rank group, collectives forced: everything about the real multi-GPU transport that one GPU can
-    exercise.  Runs in a subprocess (its own process group)."""
-    import os
-    import subprocess
-    import sys
-
-    code = r"""
+_TWO_PROC = r"""
 import math, os, sys
 import numpy as np
+import torch, torch.distributed as dist
+root = os.getcwd()
+sys.path.insert(0, os.path.join(root, "gaussianprocesses.jl_amd")); sys.path.insert(0, root)
+import gpmi355x as g
+from gpmi355x import dist as gd
+rank, world, port, n = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+rng = np.random.default_rng(11)
+d = 8
+x = rng.uniform(size=(d, n)); y = np.sin(2 * x.sum(axis=0)) + 0.1 * rng.standard_normal(n); xs = rng.uniform(size=(d, 200))
+ll = [math.log(0.5) + 0.05 * k for k in range(d)]
+ctx = g.Context(0)
+comm = gd.TorchDistComm(device=0)
+comm.selftest(ctx)
+gp = gd.ShardedGPE(x, y, g.MeanZero(), g.SEArd(ll, 0.0), math.log(0.1), comm=comm, ctx=ctx, block=1024)
+assert gp.nown == len(range(rank, gp.nblk, world)) and gp.WD == 1024
+mu, s2 = gp.predict_f(xs)
+_, S = gp.predict_f(xs[:, :64], full_cov=True)
+gp.update_dmll()
+# the single-GPU dense path on the same inputs, in this process
+ref = g.GP(x, y, g.MeanZero(), g.SEArd(ll, 0.0), math.log(0.1), ctx=ctx)
+mu_r, s2_r = ref.predict_f(xs)
+_, S_r = ref.predict_f(xs[:, :64], full_cov=True)
+ref.update_dmll()
+assert abs(gp.mll - ref.mll) <= 1e-10 * abs(ref.mll), (gp.mll, ref.mll)
+np.testing.assert_allclose(gp.alpha, ref.alpha, rtol=1e-6, atol=1e-8 * np.abs(ref.alpha).max())
+np.testing.assert_allclose(mu, mu_r, rtol=1e-7, atol=1e-9)
+np.testing.assert_allclose(s2, s2_r, rtol=1e-6, atol=1e-10)
+np.testing.assert_allclose(S, S_r, rtol=1e-6, atol=1e-9)
+np.testing.assert_allclose(gp.dmll, ref.dmll, rtol=1e-6, atol=1e-8 * np.abs(ref.dmll).max())
+# a second fit (new hyper-parameters) on the same handles
+hyp = gp.get_params(); gp.set_params([h + 0.02 for h in hyp]); gp.update_mll()
+ref.set_params([h + 0.02 for h in hyp]); ref.update_mll()
+assert abs(gp.mll - ref.mll) <= 1e-10 * abs(ref.mll)
+dist.barrier()
+print(f"two-proc rank {rank} ok mll {gp.mll:.6f}", flush=True)
+dist.destroy_process_group()
+"""
+
+
+def test_two_processes_on_one_gpu_gloo_device_buffers():
+    """two PROCESSES, real torch.distributed collectives on libgpmi's device buffers (gloo moves them
+    through the host; the callbacks enqueue on libgpmi's stream), N = 12 288 in 1024-row blocks, against the dense path."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = [subprocess.Popen([sys.executable, "-c", _TWO_PROC, str(r), "2", str(port), "12288"], cwd=ROOT, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o, e))
+    for r, (rc, o, e) in enumerate(outs):
+        assert rc == 0 and f"two-proc rank {r} ok" in o, (o[-1500:], e[-3000:])
+
+
+def test_rccl_native_communicator_in_a_group_of_one():
+    """libgpmi's own RCCL communicator (librccl opened at run time, ncclCommInitRank / Broadcast / AllGather / AllReduce) with one
+    rank: gpmi_comm_selftest, then a blocked fit with it (the collectives are skipped at world 1, the handle plumbing is not)."""
+    ctx = g.Context(0)
+    comm = gd.RcclComm(ctx, 0, 1, exchange_id=lambda b: b)
+    comm.selftest(ctx)
+    x, y, xs = _problem(1300)
+    ln = math.log(0.1)
+    gp = gd.ShardedGPE(x, y, g.MeanZero(), g.from_spec(SPEC), ln, comm=comm, ctx=ctx)
+    _check(gp, x, y, xs, ln, ("zero",))
+
+
+def test_torch_nccl_backend_behind_the_callbacks_in_a_group_of_one():
+    """torch.distributed's "nccl" backend (= RCCL) through TorchDistComm's callbacks: tensor views of raw device pointers, the
+    external stream, every collective — gpmi_comm_selftest in a one-rank group (its own process group, so a subprocess)."""
+    code = r"""
+import os, sys
 import torch, torch.distributed as dist
 sys.path.insert(0, os.path.join(os.getcwd(), "gaussianprocesses.jl_amd")); sys.path.insert(0, os.getcwd())
 import gpmi355x as g
 from gpmi355x import dist as gd
-from oracle import gp_oracle as G
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29611")
 torch.cuda.set_device(0)
 dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-rng = np.random.default_rng(3)
-n = 1300
-x = rng.uniform(size=(4, n)); y = np.sin(3 * x.sum(axis=0)) + 0.1 * rng.standard_normal(n); xs = rng.uniform(size=(4, 33))
-spec = ("sum", ("se_ard", [-0.5, -0.3, -0.6, -0.2], 0.2), ("mat52_iso", -0.4, -0.5))
-gp = gd.ShardedGPE(x, y, g.MeanZero(), g.from_spec(spec), math.log(0.1), comm=gd.TorchDistComm(force=True))
-ref = G.update_mll(spec, x, y, math.log(0.1))
-assert abs(gp.mll - ref["mll"]) <= 1e-10 * abs(ref["mll"]), (gp.mll, ref["mll"])
-mu, s2 = gp.predict_f(xs)
-mu_o, s2_o = G.predict_f(spec, x, ref, xs)
-np.testing.assert_allclose(mu, mu_o, rtol=1e-7, atol=1e-9); np.testing.assert_allclose(s2, s2_o, rtol=1e-6, atol=1e-10)
-print("rccl-one-rank ok", gp.mll)
+ctx = g.Context(0)
+comm = gd.TorchDistComm(device=0)
+comm.selftest(ctx)
+rc = gd.rccl_comm(ctx)       # the unique id through broadcast_object_list, then libgpmi's own RCCL communicator
+rc.selftest(ctx)
+print("nccl-callbacks ok", comm.error)
 dist.destroy_process_group()
 """
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0 and "rccl-one-rank ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "nccl-callbacks ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

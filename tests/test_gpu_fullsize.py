@@ -156,7 +156,7 @@ def test_c4_fp32_n100000_d16_properties_and_fp64_device():
 
 def test_f3_packed_n220000_fp64_on_one_device_block_diagonal():
     """N = 220 000 in fp64 on ONE device — past the ~180 000 ceiling of a full N x N buffer — in packed
-    storage (stripes of block-rows that stop at their own diagonal, gpmi355x.dist._Stripes).  Size-independent exactness:
+    storage (stripes of block-rows that stop at their own diagonal, csrc/blocked.cpp behind gpmi_gp_create_blocked).  Size-independent exactness:
     220 clusters of 1000 points, 100 length-scale units apart, make K + s2 I EXACTLY block diagonal (exp(-r^2 / 2 l^2)
     underflows to 0.0 across clusters), so mll, alpha and the predictions of the full factorisation — which does all
     N^3 / 3 flops, knows nothing of the zeros, and whose 1024-row blocks and 8192-row stripes straddle the 1000-point
@@ -176,9 +176,9 @@ def test_f3_packed_n220000_fp64_on_one_device_block_diagonal():
     spec = ("se_iso", math.log(0.3), 0.0)
     ln = math.log(0.1)
     gp = g.GP(x, y, g.MeanZero(), g.from_spec(spec), ln, packed=True)
-    assert gp.nobs == n and len(gp.S.items) > 20
-    print(f"[f3] N = {n}: packed factor {gp.S.nbytes_rows * 8 / 1e9:.1f} GB in {len(gp.S.items)} stripes, mll {gp.mll:.6f}")
-    packed_bytes = gp.S.nbytes_rows * 8
+    assert gp.nobs == n and gp.cK.nstripes > 20
+    print(f"[f3] N = {n}: packed factor {gp.cK.factor_bytes / 1e9:.1f} GB in {gp.cK.nstripes} stripes, mll {gp.mll:.6f}")
+    packed_bytes = gp.cK.factor_bytes
     assert packed_bytes < 0.56 * 8.0 * n * n, packed_bytes          # the full square would be 387 GB: it does not fit
     # reference: the clusters one by one
     mll_ref, alpha_ref = 0.0, np.empty(n)
