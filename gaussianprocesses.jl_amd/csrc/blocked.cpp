@@ -283,9 +283,13 @@ int BlockedGP::fit(const gpmi_kernel* kern, const double* log_noise, int64_t n_n
         char* cr = carried_ptr(&ldc);
         dev_->copy2d(cr, ldc * es_, ymu_, npad_ * es_, npad_ * es_, 1);
     }
+    whole_now_ = G_ > 1 || npad_ - 2 * WD_ < 20480;
+    dev_->whole_cus(whole_now_);
     DevEvent e0 = dev_->record();
-    dev_->use(DS_UPD);
-    dev_->wait(e0);
+    for (DevStream s : {DS_SIDE, DS_COMM, DS_UPD}) {
+        dev_->use(s);
+        dev_->wait(e0);
+    }
     DevEvent after = e0;
     if (rank_ == 0) {  // the first diagonal block has nothing to hide behind
         int64_t ld, width;
@@ -298,6 +302,20 @@ int BlockedGP::fit(const gpmi_kernel* kern, const double* log_noise, int64_t n_n
     for (int64_t k = 0; k + 1 < nblk_; ++k) {
         const int64_t k0 = k * WD_, k1 = k0 + WD_;
         const int nle = n_le(rank_, k);
+        // Whole CUs for the chain and the exchange when collectives must find room beside the update (G > 1) or the update
+        // is short enough for the chain to be exposed (chol.h: cumask_below); free slots beside a full-width update otherwise.
+        // The switch happens between steps, on an event that joins the step's streams (the two modes use different streams).
+        const bool whole = G_ > 1 || npad_ - (k + 2) * WD_ < 20480;
+        if (whole != whole_now_) {
+            join_on_main();
+            DevEvent ej = dev_->record();
+            dev_->whole_cus(whole);
+            whole_now_ = whole;
+            for (DevStream s : {DS_UPD, DS_SIDE, DS_COMM}) {
+                dev_->use(s);
+                dev_->wait(ej);
+            }
+        }
         dev_->use(DS_UPD);
         dev_->wait(ev_p_);
         // U1: block column k+1 of every own row below block k
@@ -540,6 +558,7 @@ int BlockedGP::grad(const gpmi_kernel* kern, const double* log_noise, int64_t n_
     // ---- phase 1: V_own = I_own L^-T.  Row block i of the identity is zero left of column own[i] WD, so block column k only
     //      concerns the own blocks with global index <= k.
     for (int i = 0; i < nown_; ++i) dev_->set_identity_rows(G1_ + (int64_t)i * WD_ * ldG * es_, ldG, WD_, (int64_t)own_[i] * WD_);
+    dev_->whole_cus(G_ > 1);
     DevEvent e0 = dev_->record();
     dev_->use(DS_UPD);
     dev_->wait(e0);

@@ -95,8 +95,8 @@ class BlockedGP {
     void solve_and_gather(int64_t k, const char* from_A_only);
     void update_cols(int64_t k, int64_t c_lo, int64_t c_hi);
     void join_on_main();
-    void pack_panel_from_factor(int64_t k);  // gradient: re-gather panel k from the stored factor
     int comm_rc_ = 0;
+    bool whole_now_ = true;
 };
 
 }  // namespace gpmi

@@ -47,6 +47,10 @@ struct Dev {
     // ---- streams ----
     virtual void begin_call() = 0;   // a new API call: every event of the previous one is free again
     virtual void use(DevStream s) = 0;
+    // how DS_UPD / DS_SIDE share the chip from now on: whole compute units reserved for the chain and the exchange (the update
+    // gives up ~4 % but the chain runs undisturbed and collectives find free CUs) or free workgroup slots beside a full-width
+    // update (~1.5 %, the chain crawls: fine while the update is long).  The driver decides per step (blocked.cpp).
+    virtual void whole_cus(bool on) = 0;
     virtual DevEvent record() = 0;   // on the current stream
     virtual void wait(DevEvent e) = 0;  // the current stream waits for e
     virtual void sync() = 0;         // host waits for every stream; returns after device errors are collected in err

@@ -133,7 +133,9 @@ struct HipDev : Dev {
         note(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
     }
     // ---- streams ----
-    bool masked() const { return c->upd_stream && c->side_masked && c->reserved_cus > 0; }
+    bool want_whole = true;
+    void whole_cus(bool on) override { want_whole = on; }
+    bool masked() const { return want_whole && c->upd_stream && c->side_masked && c->reserved_cus > 0; }
     void begin_call() override {
         (void)hipSetDevice(c->device);
         if (!main_s) main_s = c->stream;

@@ -46,6 +46,7 @@ struct HostDev : Dev {
     void download(void* host, const void* src, int64_t bytes) override { memcpy(host, src, (size_t)bytes); }
     void begin_call() override {}
     void use(DevStream) override {}
+    void whole_cus(bool) override {}
     DevEvent record() override { return (DevEvent)1; }
     void wait(DevEvent) override {}
     void sync() override {}
