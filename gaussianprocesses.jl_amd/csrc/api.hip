@@ -177,6 +177,46 @@ static int drain_profile(gpmi_ctx* c) {
     return GPMI_OK;
 }
 
+int set_lookahead_mode(gpmi_ctx* c, bool whole) {
+    const int want = (whole && c->mask_ok) ? 1 : 0;
+    if (c->la_mode == want) return want;
+    for (hipStream_t* st : {&c->side_stream, &c->upd_stream, &c->side_masked})
+        if (*st) {
+            (void)hipStreamSynchronize(*st);
+            (void)hipStreamDestroy(*st);
+            *st = nullptr;
+        }
+    c->reserved_cus = 0;
+    if (want == 1) {
+        // one CU per XCD for the chain: mask bit k * 33 (k = 0..7) lands on XCC k, one CU each (tools/cumask_probe.hip,
+        // profiles/r01_coresidency_cumask_probe.log); the update stream gets the other 248
+        uint32_t side_m[8] = {0}, upd_m[8];
+        for (int k = 0; k < 8; ++k) side_m[(k * 33) / 32] |= 1u << ((k * 33) % 32);
+        for (int w = 0; w < 8; ++w) upd_m[w] = ~side_m[w];
+        if (hipExtStreamCreateWithCUMask(&c->side_masked, 8, side_m) == hipSuccess &&
+            hipExtStreamCreateWithCUMask(&c->upd_stream, 8, upd_m) == hipSuccess) {
+            c->reserved_cus = 8;
+            c->la_mode = 1;
+            return 1;
+        }
+        (void)hipGetLastError();
+        for (hipStream_t* st : {&c->upd_stream, &c->side_masked})
+            if (*st) {
+                (void)hipStreamDestroy(*st);
+                *st = nullptr;
+            }
+        c->mask_ok = false;  // not on this device / runtime: free slots from now on
+    }
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = greatest priority (numerically lowest)
+    if (hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, hi) != hipSuccess) {
+        (void)hipGetLastError();
+        c->side_stream = nullptr;
+    }
+    c->la_mode = 0;
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // drivers
 // ---------------------------------------------------------------------------------------------
@@ -529,18 +569,6 @@ static int super_factor_t(gpmi_ctx* c, T* blk, int64_t ld, int64_t w, T* linv, T
     build_super_inverse<T>(c, Av, ld, linv_v, k, w, lw, w, c->d_info);
     return GPMI_OK;
 }
-template <typename T>
-static int super_rows_t(gpmi_ctx* c, T* X, int64_t ldx, int64_t M, int64_t w, const T* lw) {
-    int rc;
-    const int64_t lds = w + IB;  // never a 4 KiB-multiple row stride
-    if ((rc = grow(c, &c->sup_s, &c->sup_s_cap, M * lds * (int64_t)sizeof(T)))) return rc;
-    T* S = (T*)c->sup_s;
-    launch_gemm_shape<T>(c, S, lds, X, ldx, lw, w, M, w, w, TileShape{0, 0, 0, 0, 1, 0}, c->d_info, GEMM_OVERWRITE | GEMM_KEND_COL | GEMM_AUX);
-    GPMI_HIP(c, hipMemcpy2DAsync(X, (size_t)ldx * sizeof(T), S, (size_t)lds * sizeof(T), (size_t)w * sizeof(T), (size_t)M, hipMemcpyDeviceToDevice,
-                                 c->stream));
-    return GPMI_OK;
-}
-
 namespace gpmi {
 template <typename T>
 int super_factor_block(gpmi_ctx* c, T* blk, int64_t ld, int64_t w, T* linv, T* invdiag, T* lw, int64_t pivot_base) {
@@ -592,29 +620,8 @@ int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = greatest priority (numerically lowest)
         const char* cm = getenv("GPMI_CUMASK");
-        const bool want_mask = !(cm && atoi(cm) == 0) && c->num_cus == 256;
-        if (want_mask) {
-            // one CU per XCD for the chain: mask bit k * 33 (k = 0..7) lands on XCC k, one CU each (tools/cumask_probe.hip,
-            // profiles/r01_coresidency_cumask_probe.log); the update stream gets the other 248
-            uint32_t side_m[8] = {0}, upd_m[8];
-            for (int k = 0; k < 8; ++k) side_m[(k * 33) / 32] |= 1u << ((k * 33) % 32);
-            for (int w = 0; w < 8; ++w) upd_m[w] = ~side_m[w];
-            if (hipExtStreamCreateWithCUMask(&c->side_masked, 8, side_m) == hipSuccess &&
-                hipExtStreamCreateWithCUMask(&c->upd_stream, 8, upd_m) == hipSuccess) {
-                c->reserved_cus = 8;
-            } else {
-                (void)hipGetLastError();
-                if (c->side_masked) hipStreamDestroy(c->side_masked);
-                if (c->upd_stream) hipStreamDestroy(c->upd_stream);
-    if (c->side_masked) hipStreamDestroy(c->side_masked);
-                c->side_masked = c->upd_stream = nullptr;
-            }
-        }
-        if (const char* e = getenv("GPMI_CUMASK_BELOW")) c->cumask_below = atoll(e);
-        if (hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, hi) != hipSuccess) {
-            (void)hipGetLastError();
-            c->side_stream = nullptr;
-        }
+        c->mask_ok = !(cm && atoi(cm) == 0) && c->num_cus == 256;
+        (void)hi;
         c->lookahead_slots = 16;  // 8 in round 1 (a 7-launch chain per panel); the super-block factorisation has launches of up to 28 workgroups
         if (const char* e = getenv("GPMI_LOOKAHEAD")) c->lookahead_slots = atoi(e) / 8 * 8;
         if (const char* e = getenv("GPMI_LOOKAHEAD_MIN")) {  // given as a trailing size, as in round 1
@@ -622,21 +629,33 @@ int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
             c->lookahead_min_tiles = c->lookahead_min_tiles_masked = (int64_t)(0.5 * t * t / (GEMM_BM * GEMM_BN));
         }
     }
+    // ---- environment, read once per context.  Four knobs steer the factorisation (defaults are the measured optimum):
+    //   GPMI_SUPER=a,b,c       rows remaining from which super-panels of 512 / 1024 / 2048 columns are used
+    //   GPMI_LOOKAHEAD=slots   workgroup slots left free beside the update (0 = serial factorisation)
+    //   GPMI_LOOKAHEAD_MIN=n   smallest trailing size whose update still hides a 256-block chain
+    //   GPMI_CUMASK=0          never reserve whole compute units for the chain (round 2's free slots everywhere)
+    // and four TEST HOOKS select the alternative code paths (NB-block substitution instead of the stored super-block inverses,
+    // the one-product K^-1) at sizes a test can afford — tests/test_gpu_twolevel.py:
+    //   GPMI_SUPER_INV=0  GPMI_WHITEN_INV=0  GPMI_WHITEN_SUPER=w  GPMI_GRAD_CHUNK=k
+    // Everything else (tile-shape overrides, the phase lock, refinement everywhere, C access width) is bring-up tooling and only
+    // exists in a GPMI_TOOLS build (make TOOLS=1).
     if (const char* e = getenv("GPMI_SUPER")) {  // "min512,min1024,min2048" (remaining rows from which each width is used)
         long long a = 0, b = 0, d = 0;
         sscanf(e, "%lld,%lld,%lld", &a, &b, &d);
         c->super_min[0] = a; c->super_min[1] = b; c->super_min[2] = d;
     }
     if (const char* e = getenv("GPMI_GRAD_CHUNK")) c->grad_chunk = std::max<long long>(0, atoll(e) / NB * NB);
-    if (const char* e = getenv("GPMI_POTRF256")) c->fused_potrf = atoi(e) != 0;
-    if (const char* e = getenv("GPMI_PHASE_LOCK")) c->phase_lock_min_k = atoll(e);
     if (const char* e = getenv("GPMI_SUPER_INV")) c->super_inverse = atoi(e) != 0;
     if (const char* e = getenv("GPMI_WHITEN_INV")) c->whiten_by_super_inverse = atoi(e) != 0;
     if (const char* e = getenv("GPMI_WHITEN_SUPER")) c->whiten_super = std::max<long long>(NB, atoll(e) / NB * NB);
+#ifdef GPMI_TOOLS
+    if (const char* e = getenv("GPMI_CUMASK_BELOW")) c->whole_cus_below = atoll(e);
+    if (const char* e = getenv("GPMI_PHASE_LOCK")) c->phase_lock_min_k = atoll(e);
     if (const char* e = getenv("GPMI_REFINE")) c->refine_default = atoi(e) != 0;
-    c->refine_solves = c->refine_default;
     if (const char* e = getenv("GPMI_GEMM_NI")) c->gemm_ni = atoi(e) == 2 ? 2 : atoi(e) == 4 ? 4 : 0;
     if (const char* e = getenv("GPMI_GEMM_WGS")) c->gemm_wgs_per_cu = atoi(e) == 1 ? 1 : 2;
+#endif
+    c->refine_solves = c->refine_default;
     if (getenv("GPMI_DEBUG"))
         fprintf(stderr, "[gpmi] device %d: %d CUs, look-ahead slots %d, CUs reserved for the chain %d\n", dev, c->num_cus, c->lookahead_slots,
                 c->reserved_cus);
@@ -654,10 +673,12 @@ void gpmi_ctx_destroy(gpmi_ctx* c) {
     }
     for (auto e : c->ev_pool) hipEventDestroy(e);
     for (auto e : c->la_events) hipEventDestroy(e);
-    if (c->side_stream) hipStreamDestroy(c->side_stream);
-    if (c->upd_stream) hipStreamDestroy(c->upd_stream);
-    if (c->side_masked) hipStreamDestroy(c->side_masked);
-    for (void* p : {c->sup_lw, c->sup_lwt, c->sup_l256, c->sup_ut, c->sup_s, c->dev_noise})
+    for (hipStream_t st : {c->side_stream, c->upd_stream, c->side_masked})
+        if (st) {
+            hipStreamSynchronize(st);
+            hipStreamDestroy(st);
+        }
+    for (void* p : {c->sup_lw, c->sup_lwt, c->sup_l256, c->sup_ut, c->sup_s})
         if (p) hipFree(p);
     if (c->d_prog) hipFree(c->d_prog);
     if (c->h_prog) hipHostFree(c->h_prog);
@@ -947,6 +968,9 @@ int gpmi_bench_gemm(gpmi_ctx* c, int dtype, int64_t M, int64_t N, int64_t K, int
                     double* ms_out) {
     if (!c || !ms_out || (dtype != 64 && dtype != 32) || M <= 0 || N <= 0 || K <= 0 || iters <= 0 || N > M) return earg(c, "gpmi_bench_gemm: bad argument");
     if (K % 64 != 0) return earg(c, "gpmi_bench_gemm: bad argument");
+#ifndef GPMI_TOOLS
+    if (variant != 0) return earg(c, "gpmi_bench_gemm: ablation variants exist in a GPMI_TOOLS build only (make TOOLS=1)");
+#endif
     GPMI_HIP(c, hipSetDevice(c->device));
     return dtype == 64 ? gemm_bench<double>(c, M, N, K, lower, variant, iters, ms_out)
                        : gemm_bench<float>(c, M, N, K, lower, variant, iters, ms_out);
@@ -956,229 +980,6 @@ int gpmi_mfma_peak(gpmi_ctx* c, int dtype, double* tflops_out) {
     if (!c || !tflops_out || (dtype != 64 && dtype != 32)) return earg(c, "gpmi_mfma_peak: bad argument");
     GPMI_HIP(c, hipSetDevice(c->device));
     return dtype == 64 ? mfma_peak<double>(c, tflops_out) : mfma_peak<float>(c, tflops_out);
-}
-
-/* ---- device-pointer building blocks of the row-block sharded path --------------------------- */
-int gpmi_dev_set_kernel(gpmi_ctx* c, const gpmi_kernel* k, int d, double* kdiag_out) {
-    if (!c || !k) return earg(c, "gpmi_dev_set_kernel: bad argument");
-    GPMI_HIP(c, hipSetDevice(c->device));
-    int rc = upload_program(c, k, d);
-    if (rc == GPMI_OK && kdiag_out) *kdiag_out = c->h_prog->kdiag;
-    return rc;
-}
-
-int gpmi_dev_assemble(gpmi_ctx* c, int dtype, int d, int64_t n, const void* x_dev, int64_t row_off, int64_t nrows,
-                      const double* log_noise, int64_t n_noise, void* A_dev, int64_t ld, int64_t ncols) {
-    if (!c || !x_dev || !A_dev || !log_noise || (n_noise != 1 && n_noise != n) || nrows <= 0) return earg(c, "gpmi_dev_assemble: bad argument");
-    GPMI_HIP(c, hipSetDevice(c->device));
-    double nugget = 0.0;
-    double* d_noise = nullptr;
-    if (n_noise == 1) {
-        nugget = exp(2.0 * log_noise[0]);
-    } else {
-        std::vector<double> nv((size_t)n);
-        for (int64_t i = 0; i < n; ++i) nv[(size_t)i] = exp(2.0 * log_noise[i]);
-        // a context buffer, grown once: no allocation / synchronisation / free per call (a shard calls this once per block)
-        const int rc_n = grow(c, &c->dev_noise, &c->dev_noise_cap, n * (int64_t)sizeof(double));
-        if (rc_n) return rc_n;
-        d_noise = (double*)c->dev_noise;
-        GPMI_HIP(c, hipMemcpyAsync(d_noise, nv.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        GPMI_HIP(c, hipStreamSynchronize(c->stream));  // nv is a local: the copy must have left the host before it goes
-    }
-    const int64_t na = std::max<int64_t>(0, std::min<int64_t>(nrows, n - row_off));
-    const int flags = COV_LOWER | COV_NUGGET | COV_PAD_IDENTITY;
-    const int64_t xoff = std::min<int64_t>(row_off, n - 1) * d;
-    if (dtype == 64)
-        launch_cov<double>(c, (const double*)x_dev + xoff, na, (const double*)x_dev, n, d, (double*)A_dev, ld, nrows, ncols,
-                           flags, nugget, d_noise, row_off);
-    else
-        launch_cov<float>(c, (const float*)x_dev + xoff, na, (const float*)x_dev, n, d, (float*)A_dev, ld, nrows, ncols, flags,
-                          nugget, d_noise, row_off);
-    return GPMI_OK;
-}
-
-int gpmi_dev_cov_rows(gpmi_ctx* c, int dtype, int d, int64_t na, const void* xa_dev, int64_t nb, const void* xb_dev,
-                      void* C_dev, int64_t ldc, int64_t ncols_total) {
-    if (!c || !xa_dev || !xb_dev || !C_dev || na <= 0 || nb <= 0) return earg(c, "gpmi_dev_cov_rows: bad argument");
-    GPMI_HIP(c, hipSetDevice(c->device));
-    if (dtype == 64)
-        launch_cov<double>(c, (const double*)xa_dev, na, (const double*)xb_dev, nb, d, (double*)C_dev, ldc, na, ncols_total, 0,
-                           0.0, nullptr);
-    else
-        launch_cov<float>(c, (const float*)xa_dev, na, (const float*)xb_dev, nb, d, (float*)C_dev, ldc, na, ncols_total, 0, 0.0,
-                          nullptr);
-    return GPMI_OK;
-}
-
-
-
-int gpmi_dev_update_blocks(gpmi_ctx* c, int dtype, void* C_dev, int64_t ldc, const void* A_dev, int64_t lda, const void* B_dev,
-                           int64_t ldb, int64_t M, int64_t N, int64_t K, int mode, int g0, int G, int nstair_tiles, int tpb, int flags) {
-    if (!c || !C_dev || !A_dev || !B_dev || K <= 0 || K % IB || mode < 0 || mode > 2 || (mode == 2 && (G <= 0 || tpb <= 0))) {
-        if (c) c->err = "gpmi_dev_update: bad argument";
-        return GPMI_EARG;
-    }
-    if (M <= 0 || N <= 0) return GPMI_OK;
-    GPMI_HIP(c, hipSetDevice(c->device));
-    TileShape sh{0, 0, mode, g0, G, nstair_tiles, tpb > 0 ? tpb : 2};
-    const int gflags = (flags & 1) ? GEMM_OVERWRITE : 0;
-    auto go = [&]() {
-        if (dtype == 64)
-            launch_gemm_shape<double>(c, (double*)C_dev, ldc, (const double*)A_dev, lda, (const double*)B_dev, ldb, M, N, K, sh, c->d_info, gflags);
-        else
-            launch_gemm_shape<float>(c, (float*)C_dev, ldc, (const float*)A_dev, lda, (const float*)B_dev, ldb, M, N, K, sh, c->d_info, gflags);
-    };
-    // a side section is pending (gpmi_dev_side_end): this main-stream update runs beside its chain — on the CU-masked update
-    // stream when the context reserves whole CUs for the chain, else leaving its workgroup slots free (chol.h)
-    if (c->side_pending && !c->beside_update) {
-        hipEvent_t e = la_event(c);
-        GPMI_HIP(c, hipEventRecord(e, c->stream));
-        main_update_beside_chain<double>(c, e, go);
-    } else {
-        go();
-    }
-    return GPMI_OK;
-}
-int gpmi_dev_update(gpmi_ctx* c, int dtype, void* C_dev, int64_t ldc, const void* A_dev, int64_t lda, const void* B_dev,
-                    int64_t ldb, int64_t M, int64_t N, int64_t K, int mode, int g0, int G, int nstair_tiles) {
-    return gpmi_dev_update_blocks(c, dtype, C_dev, ldc, A_dev, lda, B_dev, ldb, M, N, K, mode, g0, G, nstair_tiles, 2, 0);
-}
-
-int gpmi_dev_super_factor(gpmi_ctx* c, int dtype, void* blk_dev, int64_t ld, int64_t w, void* linv_dev, void* invdiag_dev,
-                          void* lw_dev, int64_t pivot_base) {
-    if (!c || !blk_dev || !linv_dev || !invdiag_dev || !lw_dev || w < NB || w % NB || (w / NB & (w / NB - 1)) || pivot_base % IB) {
-        if (c) c->err = "gpmi_dev_super_factor: the block width must be 256 * 2^s, the pivot base a multiple of 64";
-        return GPMI_EARG;
-    }
-    GPMI_HIP(c, hipSetDevice(c->device));
-    return dtype == 64 ? super_factor_t<double>(c, (double*)blk_dev, ld, w, (double*)linv_dev, (double*)invdiag_dev, (double*)lw_dev, pivot_base)
-                       : super_factor_t<float>(c, (float*)blk_dev, ld, w, (float*)linv_dev, (float*)invdiag_dev, (float*)lw_dev, pivot_base);
-}
-int gpmi_dev_super_rows(gpmi_ctx* c, int dtype, void* X_dev, int64_t ldx, int64_t M, int64_t w, const void* lw_dev) {
-    if (!c || !X_dev || !lw_dev || w <= 0 || w % IB) {
-        if (c) c->err = "gpmi_dev_super_rows: bad argument";
-        return GPMI_EARG;
-    }
-    if (M <= 0) return GPMI_OK;
-    GPMI_HIP(c, hipSetDevice(c->device));
-    return dtype == 64 ? super_rows_t<double>(c, (double*)X_dev, ldx, M, w, (const double*)lw_dev)
-                       : super_rows_t<float>(c, (float*)X_dev, ldx, M, w, (const float*)lw_dev);
-}
-int gpmi_dev_side_begin(gpmi_ctx* c) {
-    if (!c) return earg(c, "gpmi_dev_side_begin: bad argument");
-    if (!c->side_stream || c->lookahead_slots <= 0 || c->beside_update) return GPMI_OK;  // no look-ahead: the section runs in line
-    GPMI_HIP(c, hipSetDevice(c->device));
-    hipEvent_t e = la_event(c);
-    GPMI_HIP(c, hipEventRecord(e, c->stream));
-    hipStream_t side = (c->side_masked && c->upd_stream) ? c->side_masked : c->side_stream;  // whole CUs for the chain when reserved
-    GPMI_HIP(c, hipStreamWaitEvent(side, e, 0));
-    c->side_saved_stream = c->stream;
-    c->stream = side;
-    c->beside_update = true;
-    return GPMI_OK;
-}
-int gpmi_dev_side_end(gpmi_ctx* c) {
-    if (!c) return earg(c, "gpmi_dev_side_end: bad argument");
-    if (!c->beside_update) return GPMI_OK;
-    GPMI_HIP(c, hipSetDevice(c->device));
-    c->side_event = la_event(c);
-    GPMI_HIP(c, hipEventRecord(c->side_event, c->stream));
-    c->stream = c->side_saved_stream;
-    c->beside_update = false;
-    c->side_pending = true;
-    return GPMI_OK;
-}
-int gpmi_dev_side_join(gpmi_ctx* c) {
-    if (!c) return earg(c, "gpmi_dev_side_join: bad argument");
-    if (!c->side_pending) return GPMI_OK;
-    GPMI_HIP(c, hipSetDevice(c->device));
-    GPMI_HIP(c, hipStreamWaitEvent(c->stream, c->side_event, 0));
-    c->side_pending = false;
-    return GPMI_OK;
-}
-int gpmi_ctx_set_stream(gpmi_ctx* c, void* hip_stream, int use_caller_stream) {
-    if (!c) return earg(c, "gpmi_ctx_set_stream: bad argument");
-    if (c->beside_update || c->side_pending) {
-        c->err = "gpmi_ctx_set_stream: a side section is open";
-        return GPMI_EARG;
-    }
-    GPMI_HIP(c, hipSetDevice(c->device));
-    GPMI_HIP(c, hipStreamSynchronize(c->stream));
-    c->stream = use_caller_stream ? (hipStream_t)hip_stream : c->own_stream;  // NULL is a stream too (the default one)
-    return GPMI_OK;
-}
-int gpmi_dev_bsolve_block(gpmi_ctx* c, int dtype, const void* Lrows_dev, int64_t ld, int64_t c0, int64_t nb,
-                          const void* linv_dev, void* z_dev, void* alpha_dev) {
-    if (!c || !Lrows_dev || !linv_dev || !z_dev || !alpha_dev || nb <= 0 || nb % IB) return earg(c, "gpmi_dev_bsolve_block: bad argument");
-    GPMI_HIP(c, hipSetDevice(c->device));
-    const size_t es = dtype == 64 ? 8 : 4;
-    for (int64_t j = nb - IB; j >= 0; j -= IB) {
-        const char* row = (const char*)Lrows_dev + (size_t)(j * ld) * es;
-        const char* li = (const char*)linv_dev + (size_t)((j / IB) * IB * IB) * es;
-        if (dtype == 64)
-            launch_bsolve_step<double>(c, (const double*)row, ld, c0 + j, (const double*)li, (double*)z_dev, (double*)alpha_dev);
-        else
-            launch_bsolve_step<float>(c, (const float*)row, ld, c0 + j, (const float*)li, (float*)z_dev, (float*)alpha_dev);
-    }
-    return GPMI_OK;
-}
-
-int gpmi_dev_row_gemv(gpmi_ctx* c, int dtype, const void* R_dev, int64_t ldr, int64_t P, int64_t n, const void* v_dev,
-                      const void* add_dev, void* out_dev) {
-    if (!c || !R_dev || !v_dev || !add_dev || !out_dev) return earg(c, "gpmi_dev_row_gemv: bad argument");
-    GPMI_HIP(c, hipSetDevice(c->device));
-    if (dtype == 64)
-        launch_row_gemv<double>(c, (const double*)R_dev, ldr, P, n, (const double*)v_dev, (const double*)add_dev, (double*)out_dev);
-    else
-        launch_row_gemv<float>(c, (const float*)R_dev, ldr, P, n, (const float*)v_dev, (const float*)add_dev, (float*)out_dev);
-    return GPMI_OK;
-}
-
-int gpmi_dev_row_var(gpmi_ctx* c, int dtype, const void* R_dev, int64_t ldr, int64_t P, int64_t n, double kdiag, void* out_dev) {
-    if (!c || !R_dev || !out_dev) return earg(c, "gpmi_dev_row_var: bad argument");
-    GPMI_HIP(c, hipSetDevice(c->device));
-    if (dtype == 64)
-        launch_row_var<double>(c, (const double*)R_dev, ldr, P, n, kdiag, (double*)out_dev);
-    else
-        launch_row_var<float>(c, (const float*)R_dev, ldr, P, n, kdiag, (float*)out_dev);
-    return GPMI_OK;
-}
-
-int gpmi_dev_logdiag_sum(gpmi_ctx* c, int dtype, const void* A_dev, int64_t ld, int64_t nrows, int64_t col_off, double* out) {
-    if (!c || !A_dev || !out || nrows < 0) return earg(c, "gpmi_dev_logdiag_sum: bad argument");
-    GPMI_HIP(c, hipSetDevice(c->device));
-    if (dtype == 64)
-        launch_logdiag<double>(c, (const double*)A_dev, ld, nrows, col_off, c->d_scal);
-    else
-        launch_logdiag<float>(c, (const float*)A_dev, ld, nrows, col_off, c->d_scal);
-    GPMI_HIP(c, hipMemcpyAsync(c->h_scal, c->d_scal, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    GPMI_HIP(c, hipStreamSynchronize(c->stream));
-    *out = c->h_scal[0];
-    return GPMI_OK;
-}
-
-int gpmi_dev_info(gpmi_ctx* c, int reset, int64_t* info_out) {
-    if (!c) return earg(c, "gpmi_dev_info: bad argument");
-    GPMI_HIP(c, hipSetDevice(c->device));
-    if (reset) {
-        GPMI_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
-        if (!c->beside_update && !c->side_pending) la_reset(c);  // a new factorisation: the cross-stream events are free again
-    }
-    if (info_out) {
-        int h = 0;
-        GPMI_HIP(c, hipMemcpyAsync(&h, c->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        GPMI_HIP(c, hipStreamSynchronize(c->stream));
-        *info_out = h;
-    }
-    return GPMI_OK;
-}
-
-int gpmi_dev_sync(gpmi_ctx* c) {
-    if (!c) return earg(c, "gpmi_dev_sync: bad argument");
-    GPMI_HIP(c, hipSetDevice(c->device));
-    GPMI_HIP(c, hipStreamSynchronize(c->stream));
-    GPMI_HIP(c, hipGetLastError());
-    return GPMI_OK;
 }
 
 }  // extern "C"

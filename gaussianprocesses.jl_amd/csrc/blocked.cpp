@@ -283,8 +283,9 @@ int BlockedGP::fit(const gpmi_kernel* kern, const double* log_noise, int64_t n_n
         char* cr = carried_ptr(&ldc);
         dev_->copy2d(cr, ldc * es_, ymu_, npad_ * es_, npad_ * es_, 1);
     }
-    whole_now_ = G_ > 1 || npad_ - 2 * WD_ < 20480;
-    dev_->whole_cus(whole_now_);
+    // whole compute units for the chain and the exchange when collectives must find room beside the update (G > 1) or the
+    // factorisation is short enough for the chain to be exposed; free slots beside a full-width update otherwise (common.h)
+    dev_->whole_cus(G_ > 1 || npad_ < 32768);
     DevEvent e0 = dev_->record();
     for (DevStream s : {DS_SIDE, DS_COMM, DS_UPD}) {
         dev_->use(s);
@@ -302,20 +303,6 @@ int BlockedGP::fit(const gpmi_kernel* kern, const double* log_noise, int64_t n_n
     for (int64_t k = 0; k + 1 < nblk_; ++k) {
         const int64_t k0 = k * WD_, k1 = k0 + WD_;
         const int nle = n_le(rank_, k);
-        // Whole CUs for the chain and the exchange when collectives must find room beside the update (G > 1) or the update
-        // is short enough for the chain to be exposed (chol.h: cumask_below); free slots beside a full-width update otherwise.
-        // The switch happens between steps, on an event that joins the step's streams (the two modes use different streams).
-        const bool whole = G_ > 1 || npad_ - (k + 2) * WD_ < 20480;
-        if (whole != whole_now_) {
-            join_on_main();
-            DevEvent ej = dev_->record();
-            dev_->whole_cus(whole);
-            whole_now_ = whole;
-            for (DevStream s : {DS_UPD, DS_SIDE, DS_COMM}) {
-                dev_->use(s);
-                dev_->wait(ej);
-            }
-        }
         dev_->use(DS_UPD);
         dev_->wait(ev_p_);
         // U1: block column k+1 of every own row below block k

@@ -96,7 +96,6 @@ class BlockedGP {
     void update_cols(int64_t k, int64_t c_lo, int64_t c_hi);
     void join_on_main();
     int comm_rc_ = 0;
-    bool whole_now_ = true;
 };
 
 }  // namespace gpmi

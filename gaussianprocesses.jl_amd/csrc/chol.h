@@ -129,10 +129,6 @@ inline void factor_panel(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, int
 template <typename T>
 inline void factor_panel_diag(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, int64_t k0, int64_t nbk, int* d_info) {
     const int64_t kend = k0 + nbk;
-    if (c->fused_potrf) {  // one launch for the whole block (panel.hip potrf256_kernel)
-        launch_potrf256<T>(c, A + k0 * ld + k0, ld, (int)nbk, linv + (k0 / IB) * IB * IB, invdiag + k0, d_info, k0);
-        return;
-    }
     for (int64_t j0 = k0; j0 < kend; j0 += IB) {
         T* linv_j = linv + (j0 / IB) * IB * IB;
         launch_diag64<T>(c, A + j0 * ld + j0, ld, linv_j, invdiag + j0, d_info, j0);
@@ -188,9 +184,6 @@ inline void factor_panel_below(gpmi_ctx* c, T* A, int64_t ld, const T* linv, int
 // go to the CU-masked update stream — ordered after `after` (an event already recorded on the main stream) and joined back
 // into the main stream — and the grid is sized for the unreserved CUs; otherwise (round 2) they stay on the main stream and
 // leave `lookahead_slots` workgroup slots free.
-inline bool chain_masked(const gpmi_ctx* c, int64_t rows_left) {
-    return c->upd_stream && c->side_masked && c->reserved_cus > 0 && rows_left < c->cumask_below;
-}
 template <typename T, typename F>
 inline void main_update_beside_chain(gpmi_ctx* c, hipEvent_t after, F launch, bool masked = true) {
     if (masked && c->upd_stream && c->reserved_cus > 0) {
@@ -312,8 +305,11 @@ template <typename T>
 inline int cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, int64_t npad, int64_t extra, int* d_info,
                           SuperStore<T>* store = nullptr) {
     const int64_t Mtot = npad + extra;
-    const bool can_look = c->lookahead_slots > 0 && c->side_stream && npad > 4 * NB;
-    hipStream_t main_s = c->stream, side = c->side_stream;
+    // whole CUs for the chain (short factorisations: the chain would be exposed) or free slots beside a full-width update
+    const bool want_look = c->lookahead_slots > 0 && npad > 4 * NB;
+    const bool masked = want_look && set_lookahead_mode(c, npad < c->whole_cus_below) == 1;
+    hipStream_t main_s = c->stream, side = masked ? c->side_masked : c->side_stream;
+    const bool can_look = want_look && side != nullptr;
     if (store && store->parts) store->parts->clear();
 
     // the inverse path serves super-panels of NB * 2^s > NB columns; factorisations that carry the refinement step
@@ -360,8 +356,6 @@ inline int cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, in
         // The side stream's chain takes ~0.4 ms per 256 columns beside the update (contended CUs): look ahead only while
         // the update is longer.  Update length in units of a 128 x 128 x 256 tile product:
         const double ntile = 0.5 * (double)(npad - ke2) * (double)(npad - ke2) / (GEMM_BM * GEMM_BN) * (double)K / NB;
-        const bool masked = chain_masked(c, npad - ke2);  // whole CUs for the chain (short updates) or free slots (long ones)
-        side = masked ? c->side_masked : c->side_stream;
         if (!can_look || ntile < (double)(masked ? c->lookahead_min_tiles_masked : c->lookahead_min_tiles) * (double)((w2 + NB - 1) / NB)) {
             launch_gemm_nt<T>(c, A + ke * ld + ke, ld, A + ke * ld + ks, ld, A + ke * ld + ks, ld, Mtot - ke, npad - ke, K, 1, d_info);
             factor_diag_block<T>(c, A, ld, linv, invdiag, ke, w2, d_info);

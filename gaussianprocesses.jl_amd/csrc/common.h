@@ -97,19 +97,21 @@ struct gpmi_ctx {
     // look-ahead Cholesky (api.hip: cholesky_lower): the next panel's serial chain runs on side_stream under the
     // trailing update, which leaves lookahead_slots workgroup slots free (gemm_reserve is set around that launch)
     hipStream_t side_stream = nullptr;
-    // round 3: WHOLE compute units for the look-ahead chain.  side_stream is created with a CU mask of `reserved_cus` CUs
-    // (one per XCD) and upd_stream with the complementary mask; the persistent update that the chain hides under is
-    // launched on upd_stream (event hop from / to the main stream), so the chain's single-wave kernels no longer share a
-    // SIMD with GEMM waves (diag64: 26 us alone, ~130 us beside a GEMM workgroup on the same CU — profiles/r02_c2_critical_path.txt).
-    // The capacity given up is what the 16 free workgroup slots already cost (8 CU-equivalents = 3.1 %).  GPMI_CUMASK=0: round 2's slots.
-    // Measured (profiles/r03_a_cumask_ab.log): whole CUs cost the update 4.3 % (589 -> 615 ms at N = 50 000) where the free slots
-    // cost ~1.5 % (a CU with one GEMM workgroup runs it faster), and buy the chain a 5x shorter critical path (diag64 130 -> 26 us).
-    // So the choice is per look-ahead step: masked streams while fewer than cumask_below rows remain (the chain would be exposed),
-    // round 2's free slots + the unmasked high-priority side stream above that.  N = 20 000: 78.3 -> 73.0 ms per step.
+    // round 3: WHOLE compute units for the look-ahead chain.  In that mode the chain runs on side_masked (a CU mask of
+    // `reserved_cus` CUs, one per XCD) and the update it hides under on upd_stream (the complementary mask; event hop from / to
+    // the main stream), so the chain's single-wave kernels no longer share a SIMD with GEMM waves (diag64: 26 us alone, ~130 us
+    // beside a GEMM workgroup on the same CU).  Measured (profiles/r03_a_cumask_ab.log): whole CUs cost the update 4.3 % (589 ->
+    // 615 ms at N = 50 000) where round 2's free workgroup slots cost ~1.5 %, and shorten the chain 5x: N = 20 000 goes from 78.3
+    // to 73.0 ms per step, N = 50 000 from 710 to 732.  So the mode is chosen PER FACTORISATION (whole CUs below
+    // whole_cus_below rows) — and only ONE stream set exists at a time (set_lookahead_mode): HIP multiplexes streams onto few
+    // hardware queues, and with own + side_masked + upd + side streams alive the priority side stream shared a queue with the
+    // main stream: the chain serialised behind every update (940 instead of 715 ms, profiles/r03_b_hybrid_streams.log).
     hipStream_t upd_stream = nullptr;
     hipStream_t side_masked = nullptr;
     int reserved_cus = 0;
-    int64_t cumask_below = 20480;
+    int la_mode = -1;                // -1 none yet, 0 free slots (side_stream), 1 whole CUs (side_masked + upd_stream)
+    bool mask_ok = false;            // CU-masked streams are available (256 CUs, GPMI_CUMASK != 0, creation has not failed)
+    int64_t whole_cus_below = 32768; // factorisations of fewer rows reserve whole CUs for the chain
     int64_t lookahead_min_tiles_masked = 288;  // = a 3072-row trailing matrix at K = 256: the fast chain hides under shorter updates
     int lookahead_slots = 0;
     int64_t lookahead_min_tiles = 650;   // update length (in 128 x 128 x 256 tile products) below which the serial order is
@@ -126,19 +128,12 @@ struct gpmi_ctx {
     void* sup_ut = nullptr;  int64_t sup_ut_cap = 0;
     void* sup_s = nullptr;   int64_t sup_s_cap = 0;
     int64_t sup_wld = 0;
-    void* dev_noise = nullptr;  // per-point nuggets of gpmi_dev_assemble (grown once)
-    int64_t dev_noise_cap = 0;
-    int fused_potrf = 0;                 // GPMI_POTRF256=1: one launch per 256 x 256 diagonal block instead of 4 diag64 + 3 rows64
-                                         // (built and tested; measured neutral to -1 %, so off: profiles/r02_super_sweep.log)
     int64_t grad_chunk = 2048;           // K chunk of the gradient's K^-1 = L^-T L^-1 accumulation (GPMI_GRAD_CHUNK; 0 = one product)
     int super_inverse = 1;               // rows below a super-panel through its explicit inverse (GPMI_SUPER_INV=0: NB-block substitution)
     int whiten_by_super_inverse = 1;     // predict / gradient whitening through the stored super-block inverses (GPMI_WHITEN_INV=0: NB blocks)
     int64_t whiten_super = 1024;         // super-block width of whiten_rows_inv (GPMI_WHITEN_SUPER; 256 = one level)
     int gemm_reserve = 0;
-    hipStream_t own_stream = nullptr;    // the stream created with the context (stream may be switched to a caller's, gpmi_ctx_set_stream)
-    hipStream_t side_saved_stream = nullptr;  // gpmi_dev_side_begin / _end / _join (look-ahead driven by the caller's step loop)
-    hipEvent_t side_event = nullptr;
-    bool side_pending = false;
+    hipStream_t own_stream = nullptr;    // the stream created with the context
     bool beside_update = false;          // launches made now run in the reserved slots beside the persistent update: no whole-CU kernels
     std::vector<hipEvent_t> la_events;
     size_t la_next = 0;   // cross-stream dependencies, reused by every factorisation
@@ -203,6 +198,10 @@ class BlockedGP;
 BlockedGP* blocked_of(gpmi_gp* gp);
 void blocked_destroy(void* p);
 
+// the look-ahead stream set of the context: whole CUs (side_masked + upd_stream) or free slots (side_stream); switching
+// synchronises the streams that go away.  Returns the mode in effect (0 when masks are unavailable).
+int set_lookahead_mode(gpmi_ctx* c, bool whole_cus);
+
 // RAII-free helpers -------------------------------------------------------------------------
 #define GPMI_HIP(ctx, call)                                                                     \
     do {                                                                                        \
@@ -265,9 +264,6 @@ enum GemmFlags { GEMM_OVERWRITE = 1 /* C = A B' instead of C -= A B' */, GEMM_KS
 // *info = pivot_base + j + 1.
 template <typename T>
 void launch_diag64(gpmi_ctx* ctx, T* A, int64_t ld, T* linv, T* invdiag, int* info, int64_t pivot_base);
-// the whole nb x nb diagonal block (nb <= 256, multiple of 64) in one launch: L in place, its nb/64 64 x 64 inverses, 1 / L_jj
-template <typename T>
-void launch_potrf256(gpmi_ctx* ctx, T* A, int64_t ld, int nb, T* linv, T* invdiag, int* info, int64_t pivot_base);
 
 // Panel step for the rows below column block j of a panel (Xp, Lp point at the panel's first column k0):
 //   X_j <- (X_j - X[:, 0:K1] Lp[0:64, 0:K1]') Linv'   and, for the first diag_rows rows (Cholesky only),

@@ -6,7 +6,9 @@
 //            `lookahead_slots` workgroup slots left free
 //   DS_SIDE  the CU-masked chain stream (the 8 reserved CUs), else the high-priority side stream; launches are capped to the
 //            free slots (common.h side_cap)
-//   DS_COMM  the unmasked high-priority stream: RCCL's kernels and the scatter copies land on the reserved CUs
+//   DS_COMM  the main stream (idle while UPD / SIDE run a factorisation): RCCL's kernels and the scatter copies land on the
+//            reserved CUs; with free slots instead of reserved CUs, the side stream
+// Only ONE look-ahead stream set exists at a time (common.h set_lookahead_mode): HIP multiplexes streams onto few hardware queues.
 #include <dlfcn.h>
 #include <math.h>
 #include <string.h>
@@ -122,6 +124,16 @@ struct HipDev : Dev {
     void zero(void* p, int64_t bytes) override { note(hipMemsetAsync(p, 0, (size_t)bytes, c->stream), "hipMemsetAsync"); }
     void copy2d(void* dst, int64_t dp, const void* src, int64_t sp, int64_t w, int64_t rows) override {
         if (rows <= 0 || w <= 0) return;
+        if (rows == 1 || (dp == w && sp == w)) {  // contiguous: one linear copy
+            note(hipMemcpyAsync(dst, src, (size_t)(w * rows), hipMemcpyDeviceToDevice, c->stream), "hipMemcpyAsync D2D");
+            return;
+        }
+        if (w >= (64 << 10) && rows <= 256) {  // a few very long rows (whole blocks of a panel): linear copies, not a 2-D blit
+            for (int64_t r = 0; r < rows; ++r)
+                note(hipMemcpyAsync((char*)dst + r * dp, (const char*)src + r * sp, (size_t)w, hipMemcpyDeviceToDevice, c->stream),
+                     "hipMemcpyAsync D2D");
+            return;
+        }
         note(hipMemcpy2DAsync(dst, (size_t)dp, src, (size_t)sp, (size_t)w, (size_t)rows, hipMemcpyDeviceToDevice, c->stream), "hipMemcpy2DAsync");
     }
     void upload(void* dst, const void* host, int64_t bytes) override {
@@ -133,9 +145,9 @@ struct HipDev : Dev {
         note(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
     }
     // ---- streams ----
-    bool want_whole = true;
-    void whole_cus(bool on) override { want_whole = on; }
-    bool masked() const { return want_whole && c->upd_stream && c->side_masked && c->reserved_cus > 0; }
+    bool is_masked = false;
+    void whole_cus(bool on) override { is_masked = set_lookahead_mode(c, on) == 1; }
+    bool masked() const { return is_masked && c->upd_stream && c->side_masked; }
     void begin_call() override {
         (void)hipSetDevice(c->device);
         if (!main_s) main_s = c->stream;
@@ -169,7 +181,9 @@ struct HipDev : Dev {
                 c->stream = masked() ? c->side_masked : (c->side_stream ? c->side_stream : main_s);
                 c->beside_update = c->stream != main_s;
                 break;
-            case DS_COMM: c->stream = c->side_stream ? c->side_stream : main_s; break;
+            // the exchange: the main stream is idle while a factorisation runs on UPD / SIDE, so with whole CUs reserved the
+            // collectives go there (their kernels find the reserved CUs free); with free slots they follow the chain
+            case DS_COMM: c->stream = masked() ? main_s : (c->side_stream ? c->side_stream : main_s); break;
         }
     }
     DevEvent record() override {

@@ -51,6 +51,11 @@ namespace {
 // owns the index range starting at `qbase[x]`, every workgroup over-pulls exactly once, and the
 // word advances by exactly the chunk length, which is what the host adds to its copy.  Launches with no more
 // tiles than workgroups do not touch the queue at all.
+#ifdef GPMI_TOOLS
+constexpr bool kTools = true;
+#else
+constexpr bool kTools = false;  // product build: variant 0 / 64 only, no phase lock, no 4x4x4 form, no access-width override
+#endif
 struct QueueArgs {
     unsigned long long base[8];  // per-XCD value of the queue word at launch
     int64_t start[9];            // chunk x = tiles [start[x], start[x+1])
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __rest
     if (info && *info != 0) {  // an earlier pivot failed: abandon, but keep the queue arithmetic exact
         if (qa.use_queue && tid == 0 && li == 0) {
             atomicAdd(queue + 8 * xcd, (unsigned long long)(cend - cbeg));
-            if (flags & GEMM_PHASE_LOCK) atomicAdd(queue + 8 * xcd + 1, (unsigned long long)(cend - cbeg));
+            if (kTools && (flags & GEMM_PHASE_LOCK)) atomicAdd(queue + 8 * xcd + 1, (unsigned long long)(cend - cbeg));
         }
         return;
     }
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __rest
         if constexpr (VARIANT & 128) tk0 = wall_clock64();
         if (t >= cend) break;
         if constexpr (VARIANT & 128) tk_n += 1;
-        if ((flags & GEMM_PHASE_LOCK) && qa.use_queue) {
+        if (kTools && (flags & GEMM_PHASE_LOCK) && qa.use_queue) {
             // wait (bounded: ~17 ms, then go anyway) until the earlier rounds' tiles have left their K loops
             if (tid == 0) {
                 const long long r = (t - cbeg) / nloc;
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __rest
         // 16-byte C accesses (fp64, 16x16x4 accumulator layout only) need even leading dimension and 16-byte aligned rows
         constexpr bool PAIR16 = std::is_same<T, double>::value && std::is_same<MF, Mfma<double>>::value;
         using V2 = double __attribute__((ext_vector_type(2)));
-        const bool pair16 = PAIR16 && !(ldc & 1) && !(reinterpret_cast<uintptr_t>(Ct + n0) & 15) && !(flags & GEMM_NO_PAIR16);
+        const bool pair16 = PAIR16 && !(ldc & 1) && !(reinterpret_cast<uintptr_t>(Ct + n0) & 15) && !(kTools && (flags & GEMM_NO_PAIR16));
         const int lrow = wm * 64, lcol = wn * WN;  // this wave's corner inside the tile
         T* __restrict__ const Cw = Ct + (m0 + lrow) * ldc + n0 + lcol;
         auto c_index = [&](int64_t ld, int ln, int mi, int ni, int r) -> int64_t {
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __rest
             __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs above the barrier (they are what hides the DMA)
             if (last && tid == 0) {
                 s_tile = (long long)(pulled - qa.base[xcd]) + cbeg + nloc;
-                if ((flags & GEMM_PHASE_LOCK) && qa.use_queue) atomicAdd(queue + 8 * xcd + 1, 1ull);  // this tile's K loop is over
+                if (kTools && (flags & GEMM_PHASE_LOCK) && qa.use_queue) atomicAdd(queue + 8 * xcd + 1, 1ull);  // this tile's K loop is over
             }
             __syncthreads();  // (a) next slab has landed for everyone  (b) everyone is done reading `cur`  (c) s_tile
         }
@@ -493,8 +498,10 @@ static void launch_persistent_ni(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, i
         qa.done_base[x] = dbase[x];
         if (qa.use_queue && (flags & GEMM_PHASE_LOCK)) dbase[x] += (unsigned long long)(qa.start[x + 1] - qa.start[x]);
     }
+#ifdef GPMI_TOOLS
     static const bool no_pair16 = getenv("GPMI_GEMM_NO_PAIR16") != nullptr;  // tools: A/B of the C access width
     if (no_pair16) flags |= GEMM_NO_PAIR16;
+#endif
     hipLaunchKernelGGL((gemm_nt_kernel<T, V, NI>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, C, ldc, A, lda, B, ldb, M, N,
                        K, shape, side ? ctx->d_queue_side : ctx->d_queue, qa, info, flags);
 }
@@ -578,10 +585,12 @@ template <typename T, int V>
 static void launch_variant(gpmi_ctx* ctx, T* C, int64_t ld, const T* A, int64_t M, int64_t N, int64_t K, int lower) {
     const TileShape shape{0, 0, lower ? 1 : 0, 0, 1, 0};
     int flags = 0;
+#ifdef GPMI_TOOLS
     if (V & 32) {
         const char* e = getenv("GPMI_STAGGER_US");
         flags = (int)((e ? atof(e) : 80.0) * 100.0) << 16;
     }
+#endif
     launch_persistent<T, V>(ctx, C, ld, A, ld, A, ld, M, N, K, shape, nullptr, flags, nullptr, use_narrow_tiles(ctx, M, N, shape, nullptr));
 }
 
@@ -606,6 +615,7 @@ int gemm_bench(gpmi_ctx* ctx, int64_t M, int64_t N, int64_t K, int lower, int va
     auto go = [&]() {
         switch (variant) {
             case 0: launch_variant<T, 0>(ctx, C, ld, A, M, N, K, lower); break;
+#ifdef GPMI_TOOLS  // ablations of tools/gemm_ablate.py / gemm_phases.py: not instantiated in the product library
             case 1: launch_variant<T, 1>(ctx, C, ld, A, M, N, K, lower); break;
             case 2: launch_variant<T, 2>(ctx, C, ld, A, M, N, K, lower); break;
             case 4: launch_variant<T, 4>(ctx, C, ld, A, M, N, K, lower); break;
@@ -621,7 +631,7 @@ int gemm_bench(gpmi_ctx* ctx, int64_t M, int64_t N, int64_t K, int lower, int va
             case 640: launch_variant<T, 640>(ctx, C, ld, A, M, N, K, lower); break;
             case 514: launch_variant<T, 514>(ctx, C, ld, A, M, N, K, lower); break;
             case 542: launch_variant<T, 542>(ctx, C, ld, A, M, N, K, lower); break;
-
+#endif
             default: break;
         }
     };
@@ -633,7 +643,7 @@ int gemm_bench(gpmi_ctx* ctx, int64_t M, int64_t N, int64_t K, int lower, int va
     float ms = 0.f;
     GPMI_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
     *ms_out = (double)ms / iters;
-    if (variant & 128) {  // per-phase wall-clock split of the last launch (100 MHz ticks), averaged over workgroups
+    if (kTools && (variant & 128)) {  // per-phase wall-clock split of the last launch (100 MHz ticks), averaged over workgroups
         std::vector<unsigned long long> dbg(4 * 512);
         GPMI_HIP(ctx, hipMemcpy(dbg.data(), ctx->d_queue + 64, dbg.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         double pro = 0, loop = 0, epi = 0, nt = 0;

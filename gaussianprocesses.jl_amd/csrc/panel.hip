@@ -76,7 +76,7 @@ constexpr int PANEL_POOL = 2 * 64 * 65 + 64 * 16 + 16 * 17 + 64;
 
 // barrier of a phase that ONE wavefront executes (diag64): LDS operations of a wave complete in issue order, so a fence that
 // keeps the compiler from moving them (and waits for them) is all a single wave needs — and, unlike __syncthreads(), it does
-// not involve the workgroup's other waves, which wait at the phase boundary of the fused kernel (potrf256)
+// not involve the workgroup's other waves
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -399,48 +399,6 @@ __global__ __launch_bounds__(256, 2) void rows64_kernel(T* __restrict__ Xp, int6
     const int64_t nblk = (M + 63) / 64;
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x)
         rows64_block<T>(Xp, ldx, M, K1, Lp, ldl, Linv, diag_rows, refine, blk * 64, pool, pool + 64 * 65);
-}
-
-// out-of-line copies for the fused kernel: each phase keeps its own register allocation (inlined into one loop body the two
-// phases spilled 132 VGPRs)
-template <typename T>
-__device__ __noinline__ void diag64_call(T* A, int64_t ld, T* Linv, T* invdiag, int* info, int64_t pivot_base, T* pool) {
-    diag64_body<T>(A, ld, Linv, invdiag, info, pivot_base, pool);
-}
-template <typename T>
-__device__ __noinline__ void rows64_call(T* Xp, int64_t ldx, int64_t M, int K1, const T* Lp, int64_t ldl, const T* Linv, int64_t diag_rows,
-                                         int refine, int64_t row0, T* buf1, T* buf2) {
-    rows64_block<T>(Xp, ldx, M, K1, Lp, ldl, Linv, diag_rows, refine, row0, buf1, buf2);
-}
-
-// potrf256: the WHOLE factorisation of one nb x nb diagonal block (nb <= 256, a multiple of 64) in ONE launch — what was a
-// chain of 4 diag64 + 3 rows64 launches (~0.2 ms alone, ~1 ms beside the trailing update: every launch pays the contended
-// dispatch and its own load phases).  One workgroup: per 64 columns wave 0 factors and inverts the diagonal block
-// (diag64_body) while the other waves wait at the phase barrier, then all four waves run the rows64 step for the row
-// blocks below inside the block.  Results travel between the phases through global memory (the 512 KiB block is L2
-// resident): __threadfence() + barrier between phases.
-template <typename T>
-__global__ __launch_bounds__(256, 2) void potrf256_kernel(T* __restrict__ A, int64_t ld, int nb, T* __restrict__ Linv,
-                                                      T* __restrict__ invdiag, int* __restrict__ info, int64_t pivot_base, int refine) {
-    if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
-    __builtin_amdgcn_s_setprio(3);
-    __shared__ T pool[PANEL_POOL];
-    const int nsub = nb / 64;
-    for (int j = 0; j < nsub; ++j) {
-        if (threadIdx.x < 64)
-            diag64_call<T>(A + (int64_t)(64 * j) * ld + 64 * j, ld, Linv + (int64_t)j * 64 * 64, invdiag + 64 * j, info, pivot_base + 64 * j, pool);
-        __threadfence();
-        __syncthreads();
-        if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;  // uniform: read after the barrier
-        const int M = nb - 64 * (j + 1);
-        if (M > 0) {
-            T* Xp = A + (int64_t)(64 * (j + 1)) * ld;   // rows below, at the panel's first column
-            for (int r0 = 0; r0 < M; r0 += 64)
-                rows64_call<T>(Xp, ld, M, 64 * j, A + (int64_t)(64 * j) * ld, ld, Linv + (int64_t)j * 64 * 64, M, refine, r0, pool, pool + 64 * 65);
-            __threadfence();
-            __syncthreads();
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -915,13 +873,6 @@ void launch_place_inv_blocks(gpmi_ctx* ctx, const T* l256, T* LW, T* LWT, int64_
 }
 
 template <typename T>
-void launch_potrf256(gpmi_ctx* ctx, T* A, int64_t ld, int nb, T* linv, T* invdiag, int* info, int64_t pivot_base) {
-    ProfScope ps(ctx, GPMI_PROF_PANEL, 2.0 * (double)nb * nb * nb / 3.0);
-    hipLaunchKernelGGL(potrf256_kernel<T>, dim3(1), dim3(256), 0, ctx->stream, A, ld, nb, linv, invdiag, info, pivot_base,
-                       ctx->refine_solves ? 1 : 0);
-}
-
-template <typename T>
 void launch_diag64(gpmi_ctx* ctx, T* A, int64_t ld, T* linv, T* invdiag, int* info, int64_t pivot_base) {
     ProfScope ps(ctx, GPMI_PROF_PANEL, 2.0 * 64.0 * 64.0 * 64.0 / 3.0);
     hipLaunchKernelGGL(diag64_kernel<T>, dim3(1), dim3(256), 0, ctx->stream, A, ld, linv, invdiag, info, pivot_base);
@@ -986,7 +937,6 @@ void launch_logdiag(gpmi_ctx* ctx, const T* A, int64_t ld, int64_t nrows, int64_
 
 #define INST(T)                                                                                                   \
     template void launch_diag64<T>(gpmi_ctx*, T*, int64_t, T*, T*, int*, int64_t);                                \
-    template void launch_potrf256<T>(gpmi_ctx*, T*, int64_t, int, T*, T*, int*, int64_t);                         \
     template void launch_rows64<T>(gpmi_ctx*, T*, int64_t, int64_t, int, const T*, int64_t, const T*, int64_t,    \
                                    const int*);                                                                   \
     template void launch_rows256<T>(gpmi_ctx*, T*, int64_t, int64_t, int, const T*, int64_t, const T*, const int*); \

@@ -24,10 +24,6 @@ SYMBOLS = [
     "gpmi_inv_diag", "gpmi_fitc_create", "gpmi_fitc_destroy", "gpmi_fitc_fit", "gpmi_fitc_predict", "gpmi_fitc_alpha_u", "gpmi_fitc_grad",
     "gpmi_solve", "gpmi_whiten", "gpmi_logdet", "gpmi_factor_to_host", "gpmi_factor_diag",
     "gpmi_profile_enable", "gpmi_profile_get", "gpmi_profile_get_bytes", "gpmi_mfma_peak", "gpmi_bench_gemm",
-    "gpmi_dev_set_kernel", "gpmi_dev_assemble", "gpmi_dev_cov_rows",
-    "gpmi_dev_update", "gpmi_dev_bsolve_block", "gpmi_dev_row_gemv", "gpmi_dev_row_var", "gpmi_dev_logdiag_sum",
-    "gpmi_dev_info", "gpmi_dev_sync", "gpmi_dev_update_blocks", "gpmi_dev_super_factor", "gpmi_dev_super_rows",
-    "gpmi_dev_side_begin", "gpmi_dev_side_end", "gpmi_dev_side_join", "gpmi_ctx_set_stream",
     "gpmi_comm_create_callbacks", "gpmi_comm_unique_id", "gpmi_comm_create_rccl", "gpmi_comm_destroy", "gpmi_comm_selftest", "gpmi_gp_create_blocked",
     "gpmi_gp_blocked_info",
 ]
@@ -131,23 +127,6 @@ def load():
     lib.gpmi_mfma_peak.argtypes = [vp, C.c_int, C.POINTER(dbl)]
     lib.gpmi_bench_gemm.argtypes = [vp, C.c_int, i64, i64, i64, C.c_int, C.c_int, C.c_int, C.POINTER(dbl)]
     ci = C.c_int
-    lib.gpmi_dev_set_kernel.argtypes = [vp, C.POINTER(GpmiKernel), ci, C.POINTER(dbl)]
-    lib.gpmi_dev_assemble.argtypes = [vp, ci, ci, i64, vp, i64, i64, C.POINTER(dbl), i64, vp, i64, i64]
-    lib.gpmi_dev_cov_rows.argtypes = [vp, ci, ci, i64, vp, i64, vp, vp, i64, i64]
-    lib.gpmi_dev_update.argtypes = [vp, ci, vp, i64, vp, i64, vp, i64, i64, i64, i64, ci, ci, ci, ci]
-    lib.gpmi_dev_bsolve_block.argtypes = [vp, ci, vp, i64, i64, i64, vp, vp, vp]
-    lib.gpmi_dev_row_gemv.argtypes = [vp, ci, vp, i64, i64, i64, vp, vp, vp]
-    lib.gpmi_dev_row_var.argtypes = [vp, ci, vp, i64, i64, i64, dbl, vp]
-    lib.gpmi_dev_logdiag_sum.argtypes = [vp, ci, vp, i64, i64, i64, C.POINTER(dbl)]
-    lib.gpmi_dev_info.argtypes = [vp, ci, C.POINTER(i64)]
-    lib.gpmi_dev_sync.argtypes = [vp]
-    lib.gpmi_dev_update_blocks.argtypes = [vp, ci, vp, i64, vp, i64, vp, i64, i64, i64, i64, ci, ci, ci, ci, ci, ci]
-    lib.gpmi_dev_super_factor.argtypes = [vp, ci, vp, i64, i64, vp, vp, vp, i64]
-    lib.gpmi_dev_super_rows.argtypes = [vp, ci, vp, i64, i64, i64, vp]
-    lib.gpmi_dev_side_begin.argtypes = [vp]
-    lib.gpmi_dev_side_end.argtypes = [vp]
-    lib.gpmi_dev_side_join.argtypes = [vp]
-    lib.gpmi_ctx_set_stream.argtypes = [vp, vp, C.c_int]
     lib.gpmi_comm_create_callbacks.argtypes = [C.POINTER(GpmiCommCallbacks), ci, ci, C.POINTER(vp)]
     lib.gpmi_comm_unique_id.argtypes = [vp]
     lib.gpmi_comm_create_rccl.argtypes = [vp, vp, ci, ci, C.POINTER(vp)]

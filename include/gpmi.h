@@ -87,8 +87,9 @@ typedef struct gpmi_ctx gpmi_ctx; /* one per process: device(s), streams, error 
 typedef struct gpmi_gp gpmi_gp;   /* one per GPE: resident x, factor, alpha          */
 
 /* ---- context ---------------------------------------------------------- */
-/* n_devices == 1: one process drives one GPU (multi-GPU runs are one process
- * per GPU).  device_ids may be NULL (-> device 0).            */
+/* n_devices == 1: one process drives one GPU; a multi-GPU model is one process per GPU, each with
+ * its own context, joined by a communicator (gpmi_comm_*, gpmi_gp_create_blocked below).
+ * device_ids may be NULL (-> device 0).                                                        */
 int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out);
 void gpmi_ctx_destroy(gpmi_ctx*);
 const char* gpmi_last_error(gpmi_ctx*);
@@ -237,67 +238,11 @@ int gpmi_profile_get_bytes(gpmi_ctx*, int cls, double* bytes);
  * returns measured TFLOP/s with every SIMD issuing back-to-back MFMAs.      */
 int gpmi_mfma_peak(gpmi_ctx*, int dtype, double* tflops_out);
 /* Isolated timing of the trailing-update kernel  C[M x N] -= A[M x K] A[0:N, 0:K]'  on random
- * operands (lower != 0: SYRK tile set).  variant 0 is the product kernel; other values are
- * ablations used by tools/gemm_ablate.py.  Returns milliseconds per launch.                  */
+ * operands (lower != 0: SYRK tile set).  variant 0 is the product kernel; other values are the
+ * ablations of tools/gemm_ablate.py, compiled only into a GPMI_TOOLS build of the library (make
+ * TOOLS=1; GPMI_EARG otherwise).  Returns milliseconds per launch.                            */
 int gpmi_bench_gemm(gpmi_ctx*, int dtype, int64_t M, int64_t N, int64_t K, int lower, int variant, int iters,
                     double* ms_out);
-
-/* ---- device-pointer building blocks: row-block sharded factorisation, one process per GPU ---
- * The host (torch.distributed over RCCL, or MPI/RCCL from Julia) owns the buffers and moves the
- * factored panel between ranks; these calls enqueue the per-rank device work on the context's
- * stream against caller-supplied DEVICE pointers (row-major, leading dimensions in elements).
- * A failed pivot is latched in the context (gpmi_dev_info) and turns later calls into no-ops,
- * exactly like the single-GPU path.  See DESIGN.md "Row-block sharding".                       */
-int gpmi_dev_set_kernel(gpmi_ctx*, const gpmi_kernel*, int d, double* kdiag_out); /* upload the kernel program    */
-/* rows [row_off, row_off+nrows) of K + noise (lower tiles, identity padding past n): cov! + nugget
- * of update_cK! (src/GPE.jl:169-186) restricted to a shard's block-rows.  x_dev: all n points.  */
-int gpmi_dev_assemble(gpmi_ctx*, int dtype, int d, int64_t n, const void* x_dev, int64_t row_off, int64_t nrows,
-                      const double* log_noise, int64_t n_noise, void* A_dev, int64_t ld, int64_t ncols);
-/* C[i][j] = k(xa_i, xb_j), columns >= nb zero-filled up to ncols_total (K*' rows of predict, GP.jl:44) */
-int gpmi_dev_cov_rows(gpmi_ctx*, int dtype, int d, int64_t na, const void* xa_dev, int64_t nb, const void* xb_dev,
-                      void* C_dev, int64_t ldc, int64_t ncols_total);
-/* C[M x N] -= A[M x K] B[N x K]'.  mode 0: all tiles; 1: tiles with col <= row; 2: staircase of a
- * block-cyclic shard — local 256-row block i is global block g0 + i*G (relative to C's first
- * column), rows past nstair_tiles*128 are carried rows and get every column.                   */
-int gpmi_dev_update(gpmi_ctx*, int dtype, void* C_dev, int64_t ldc, const void* A_dev, int64_t lda, const void* B_dev,
-                    int64_t ldb, int64_t M, int64_t N, int64_t K, int mode, int g0, int G, int nstair_tiles);
-/* the same with distributed blocks of tiles_per_block * 128 rows (the super-panel blocks of the two-level sharded
- * factorisation: 256 * 2^s rows); flags: 1 = C = A B' instead of C -= A B'                                        */
-int gpmi_dev_update_blocks(gpmi_ctx*, int dtype, void* C_dev, int64_t ldc, const void* A_dev, int64_t lda, const void* B_dev,
-                           int64_t ldb, int64_t M, int64_t N, int64_t K, int mode, int g0, int G, int nstair_tiles,
-                           int tiles_per_block, int flags);
-/* Two-level sharded factorisation (gpmi355x/dist.py, DESIGN.md "Row-block sharding"): the w x w diagonal block at
- * blk_dev (w = 256 * 2^s) is factored in place (dpotrf semantics, pivot indices offset by pivot_base), linv_dev gets
- * its w/64 64 x 64 inverses, invdiag_dev 1 / L_ii, and lw_dev (w x w, leading dimension w) the explicit inverse of the
- * whole block — what the owner broadcasts, so that every rank solves its rows with ONE product.                       */
-int gpmi_dev_super_factor(gpmi_ctx*, int dtype, void* blk_dev, int64_t ld, int64_t w, void* linv_dev, void* invdiag_dev,
-                          void* lw_dev, int64_t pivot_base);
-/* X[M x w] <- X * LW'  (LW lower triangular: the K loop of a column tile ends at its last column), through the
- * context's scratch: the panel solve of the rows below a super-panel, and whiten! of predict rows (GP.jl:27)        */
-int gpmi_dev_super_rows(gpmi_ctx*, int dtype, void* X_dev, int64_t ldx, int64_t M, int64_t w, const void* lw_dev);
-/* Look-ahead for the caller's step loop.  Between side_begin and side_end every gpmi_dev_* launch goes to the context's
- * side stream (ordered after everything enqueued before side_begin) and is capped to the workgroup slots the next
- * gpmi_dev_update* on the main stream leaves free; side_join makes the main stream wait for that work.  Typical step:
- * update(the next diagonal block's own tiles); side_begin; super_factor(next block); side_end; update(the rest); side_join. */
-int gpmi_dev_side_begin(gpmi_ctx*);
-int gpmi_dev_side_end(gpmi_ctx*);
-int gpmi_dev_side_join(gpmi_ctx*);
-/* use_caller_stream != 0: run the context's launches on the caller's stream (a hipStream_t — NULL being the default
- * stream — e.g. torch's current stream, so that RCCL collectives and gpmi kernels are ordered without host
- * synchronisation); 0: back to the context's own stream.  Waits for the stream that is left.                       */
-int gpmi_ctx_set_stream(gpmi_ctx*, void* hip_stream, int use_caller_stream);
-/* backward substitution through ONE block-row [c0, c0+nb) of the factor held at Lrows_dev:
- * alpha[c0..) = L_cc^-T z[c0..)  (through the block's linv);  z[0..c0) -= L[c-rows, 0..c0)' alpha_c  */
-int gpmi_dev_bsolve_block(gpmi_ctx*, int dtype, const void* Lrows_dev, int64_t ld, int64_t c0, int64_t nb,
-                          const void* linv_dev, void* z_dev, void* alpha_dev);
-int gpmi_dev_row_gemv(gpmi_ctx*, int dtype, const void* R_dev, int64_t ldr, int64_t P, int64_t n, const void* v_dev,
-                      const void* add_dev, void* out_dev);                 /* out[p] = add[p] + R[p,:n] . v       */
-int gpmi_dev_row_var(gpmi_ctx*, int dtype, const void* R_dev, int64_t ldr, int64_t P, int64_t n, double kdiag,
-                     void* out_dev);                                       /* out[p] = max(kdiag - |R[p,:n]|^2, 0) */
-int gpmi_dev_logdiag_sum(gpmi_ctx*, int dtype, const void* A_dev, int64_t ld, int64_t nrows, int64_t col_off,
-                         double* out);                                     /* sum_i log A[i][col_off+i] (syncs)   */
-int gpmi_dev_info(gpmi_ctx*, int reset, int64_t* info_out);               /* reset / read the not-PD latch        */
-int gpmi_dev_sync(gpmi_ctx*);                                              /* wait for the context's stream        */
 
 #ifdef __cplusplus
 }

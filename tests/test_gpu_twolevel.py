@@ -129,19 +129,3 @@ def test_whitening_through_nb_blocks_matches_the_stored_super_inverses(monkeypat
     xs = G.synthetic_inputs(3000, 4, p=200)[2]
     np.testing.assert_allclose(gp_a.predict_f(xs)[1], gp_b.predict_f(xs)[1], rtol=1e-9, atol=1e-12)
 
-
-def test_fused_potrf256_matches_the_seven_launch_chain(monkeypatch):
-    """GPMI_POTRF256=1: every 256 x 256 diagonal block in ONE launch (panel.hip potrf256_kernel: wave 0 factors and inverts
-    each 64 x 64 block, then all four waves run the row step inside the block) — same factor, same failing pivot."""
-    a = _ctx(monkeypatch, GPMI_SUPER="512,1024,2048", GPMI_LOOKAHEAD_MIN=256, GPMI_POTRF256=1)
-    gp_a, _ = _check(a, 2900, 64)
-    b = _ctx(monkeypatch, GPMI_SUPER="512,1024,2048", GPMI_LOOKAHEAD_MIN=256, GPMI_POTRF256=0)
-    gp_b, _ = _check(b, 2900, 64)
-    assert gp_a.mll == pytest.approx(gp_b.mll, rel=1e-13)
-    n = 1500
-    x = np.arange(n, dtype=np.float64)[None, :]
-    x[0, 700] = x[0, 40]
-    y = np.random.default_rng(1).standard_normal(n)
-    with pytest.raises(g.PosDefException) as ei:
-        g.GP(x, y, g.MeanZero(), g.SEIso(-3.0, 0.0), -400.0, ctx=a)
-    assert ei.value.info == 701
