@@ -128,6 +128,23 @@ int digest_kernel(const gpmi_kernel* k, int d, DevProgram* out, std::string* err
     }
     out->kdiag = kst[0];
     out->n_hyp = hyp;
+    // multi-leaf programs of shallow depth get the specialised interior-tile kernel (cov.hip)
+    out->fast_class = -1;
+    if (k->n_ops > 1) {
+        int dep = 0, maxdep = 0, cls = 0;
+        for (int o = 0; o < k->n_ops; ++o) {
+            const int op = k->ops[o];
+            if (op == GPMI_K_SUM || op == GPMI_K_PROD) {
+                --dep;
+            } else {
+                ++dep;
+                if (op == GPMI_K_RQ_ISO || op == GPMI_K_RQ_ARD) cls |= 1;
+                if (op == GPMI_K_NOISE) cls |= 2;
+            }
+            maxdep = std::max(maxdep, dep);
+        }
+        if (maxdep <= 3) out->fast_class = cls;
+    }
     return GPMI_OK;
 }
 
@@ -180,12 +197,19 @@ static int drain_profile(gpmi_ctx* c) {
 int set_lookahead_mode(gpmi_ctx* c, bool whole) {
     const int want = (whole && c->mask_ok) ? 1 : 0;
     if (c->la_mode == want) return want;
-    for (hipStream_t* st : {&c->side_stream, &c->upd_stream, &c->side_masked})
-        if (*st) {
-            (void)hipStreamSynchronize(*st);
-            (void)hipStreamDestroy(*st);
-            *st = nullptr;
-        }
+    static const bool keep_both = getenv("GPMI_STREAM_SETS") && !strcmp(getenv("GPMI_STREAM_SETS"), "both");  // experiment (call D)
+    if (keep_both && ((want == 1 && c->side_masked && c->upd_stream) || (want == 0 && c->side_stream))) {
+        c->reserved_cus = want == 1 ? 8 : 0;
+        c->la_mode = want;
+        return want;
+    }
+    if (!keep_both)
+        for (hipStream_t* st : {&c->side_stream, &c->upd_stream, &c->side_masked})
+            if (*st) {
+                (void)hipStreamSynchronize(*st);
+                (void)hipStreamDestroy(*st);
+                *st = nullptr;
+            }
     c->reserved_cus = 0;
     if (want == 1) {
         // one CU per XCD for the chain: mask bit k * 33 (k = 0..7) lands on XCC k, one CU each (tools/cumask_probe.hip,

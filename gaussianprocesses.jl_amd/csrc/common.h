@@ -41,7 +41,8 @@ struct DevProgram {
     int32_t n_ops;
     int32_t d;
     int32_t has_noise_leaf;
-    int32_t pad_;
+    int32_t fast_class;  // >= 0: a multi-leaf program the specialised interior-tile kernel takes (cov.hip cov_multi_kernel): stationary /
+                         // Const / Noise leaves only, evaluation depth <= 3; bit 0 = an RQ leaf (pow), bit 1 = a Noise leaf.  -1 otherwise
     double kdiag;  // k(x,x): the program evaluated with every leaf at r = 0
     int32_t n_hyp;  // total number of kernel hyper-parameters (get_params order)
     int32_t pad2_;

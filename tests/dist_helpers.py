@@ -88,6 +88,7 @@ class LocalThreadComm(gd.Comm):
     def _reduce(self, user, buf, count, es, stream):
         def go():
             mine = self._t(buf, count * es).view(torch.float64 if es == 8 else torch.float32)
+            torch.cuda.synchronize(self.device)  # BEFORE the clone: libgpmi's producers run on its own (non-blocking) streams
             got = self._exchange(mine.clone())
             tot = got[0].clone()
             for g in got[1:]:
