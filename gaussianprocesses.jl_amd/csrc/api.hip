@@ -194,51 +194,41 @@ static int drain_profile(gpmi_ctx* c) {
     return GPMI_OK;
 }
 
-int set_lookahead_mode(gpmi_ctx* c, bool whole) {
-    const int want = (whole && c->mask_ok) ? 1 : 0;
-    if (c->la_mode == want) return want;
-    static const bool keep_both = getenv("GPMI_STREAM_SETS") && !strcmp(getenv("GPMI_STREAM_SETS"), "both");  // experiment (call D)
-    if (keep_both && ((want == 1 && c->side_masked && c->upd_stream) || (want == 0 && c->side_stream))) {
-        c->reserved_cus = want == 1 ? 8 : 0;
-        c->la_mode = want;
-        return want;
-    }
-    if (!keep_both)
-        for (hipStream_t* st : {&c->side_stream, &c->upd_stream, &c->side_masked})
-            if (*st) {
-                (void)hipStreamSynchronize(*st);
-                (void)hipStreamDestroy(*st);
-                *st = nullptr;
-            }
-    c->reserved_cus = 0;
-    if (want == 1) {
-        // one CU per XCD for the chain: mask bit k * 33 (k = 0..7) lands on XCC k, one CU each (tools/cumask_probe.hip,
-        // profiles/r01_coresidency_cumask_probe.log); the update stream gets the other 248
-        uint32_t side_m[8] = {0}, upd_m[8];
-        for (int k = 0; k < 8; ++k) side_m[(k * 33) / 32] |= 1u << ((k * 33) % 32);
-        for (int w = 0; w < 8; ++w) upd_m[w] = ~side_m[w];
-        if (hipExtStreamCreateWithCUMask(&c->side_masked, 8, side_m) == hipSuccess &&
-            hipExtStreamCreateWithCUMask(&c->upd_stream, 8, upd_m) == hipSuccess) {
-            c->reserved_cus = 8;
-            c->la_mode = 1;
-            return 1;
-        }
-        (void)hipGetLastError();
-        for (hipStream_t* st : {&c->upd_stream, &c->side_masked})
-            if (*st) {
-                (void)hipStreamDestroy(*st);
-                *st = nullptr;
-            }
-        c->mask_ok = false;  // not on this device / runtime: free slots from now on
-    }
+// Both look-ahead stream sets are created WITH the context, in this order: own, priority side, masked chain, masked update.
+// Measured on the MI355X pool (profiles/r03_d_stream_order.log): streams created late behave badly — CU-masked streams made
+// after a large factorisation had run cost N = 20 000 ten ms per step (83.5 instead of 73.9), and with the priority stream
+// created LAST (fourth) the chain serialised behind every update (940 instead of 711 ms at N = 50 000).  In this order the
+// last stream is the masked update stream, which never runs concurrently with the context's own stream.
+static void create_lookahead_streams(gpmi_ctx* c) {
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = greatest priority (numerically lowest)
     if (hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, hi) != hipSuccess) {
         (void)hipGetLastError();
         c->side_stream = nullptr;
     }
-    c->la_mode = 0;
-    return 0;
+    if (!c->mask_ok) return;
+    // one CU per XCD for the chain: mask bit k * 33 (k = 0..7) lands on XCC k, one CU each (tools/cumask_probe.hip,
+    // profiles/r01_coresidency_cumask_probe.log); the update stream gets the other 248
+    uint32_t side_m[8] = {0}, upd_m[8];
+    for (int k = 0; k < 8; ++k) side_m[(k * 33) / 32] |= 1u << ((k * 33) % 32);
+    for (int w = 0; w < 8; ++w) upd_m[w] = ~side_m[w];
+    if (hipExtStreamCreateWithCUMask(&c->side_masked, 8, side_m) != hipSuccess ||
+        hipExtStreamCreateWithCUMask(&c->upd_stream, 8, upd_m) != hipSuccess) {
+        (void)hipGetLastError();
+        for (hipStream_t* st : {&c->upd_stream, &c->side_masked})
+            if (*st) {
+                (void)hipStreamDestroy(*st);
+                *st = nullptr;
+            }
+        c->mask_ok = false;  // not on this device / runtime: free slots everywhere
+    }
+}
+
+int set_lookahead_mode(gpmi_ctx* c, bool whole) {
+    const int want = (whole && c->mask_ok && c->side_masked && c->upd_stream) ? 1 : 0;
+    c->reserved_cus = want == 1 ? 8 : 0;
+    c->la_mode = want;
+    return want;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -646,6 +636,7 @@ int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
         const char* cm = getenv("GPMI_CUMASK");
         c->mask_ok = !(cm && atoi(cm) == 0) && c->num_cus == 256;
         (void)hi;
+        create_lookahead_streams(c);
         c->lookahead_slots = 16;  // 8 in round 1 (a 7-launch chain per panel); the super-block factorisation has launches of up to 28 workgroups
         if (const char* e = getenv("GPMI_LOOKAHEAD")) c->lookahead_slots = atoi(e) / 8 * 8;
         if (const char* e = getenv("GPMI_LOOKAHEAD_MIN")) {  // given as a trailing size, as in round 1

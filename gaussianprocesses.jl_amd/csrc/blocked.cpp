@@ -24,7 +24,9 @@ namespace gpmi {
 
 static const double LOG2PI = 1.8378770664093453;
 
-static int64_t default_block(int64_t n) { return n >= 16384 ? 1024 : (n >= 4096 ? 512 : 256); }
+// 1024-row blocks once the K = 1024 update outlasts a 1024-block chain for most of the factorisation; narrower blocks keep the
+// chain (and the exposed tail) short below that
+static int64_t default_block(int64_t n) { return n >= 32768 ? 1024 : (n >= 4096 ? 512 : 256); }
 
 BlockedGP::BlockedGP(Dev* dev, Comm* comm, int d, int64_t n, BlockedOpts o)
     : dev_(dev), comm_(comm), rank_(comm ? comm->rank : 0), G_(comm ? comm->world : 1), d_(d), n_(n) {
@@ -386,7 +388,7 @@ int BlockedGP::fit(const gpmi_kernel* kern, const double* log_noise, int64_t n_n
                 const int li = (int)(c / G_);
                 int64_t ld, width;
                 char* blk = block_ptr(li, &ld, &width);
-                dev_->bsolve_block(blk, ld, c * WD_, WD_, linv_ + (int64_t)li * WD_ * 64 * es_, v_, alpha_);
+                dev_->bsolve_block(blk, ld, c * WD_, WD_, linv_ + (int64_t)li * WD_ * 64 * es_, LW_ + c * WD_ * WD_ * es_, v_, alpha_);
             }
         }
         if (G_ > 1) comm_rc_ |= comm_->all_reduce_sum(alpha_, npad_, es_, dev_->native_stream());  // every block of alpha was written by one rank

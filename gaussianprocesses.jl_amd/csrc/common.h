@@ -103,10 +103,8 @@ struct gpmi_ctx {
     // the main stream), so the chain's single-wave kernels no longer share a SIMD with GEMM waves (diag64: 26 us alone, ~130 us
     // beside a GEMM workgroup on the same CU).  Measured (profiles/r03_a_cumask_ab.log): whole CUs cost the update 4.3 % (589 ->
     // 615 ms at N = 50 000) where round 2's free workgroup slots cost ~1.5 %, and shorten the chain 5x: N = 20 000 goes from 78.3
-    // to 73.0 ms per step, N = 50 000 from 710 to 732.  So the mode is chosen PER FACTORISATION (whole CUs below
-    // whole_cus_below rows) — and only ONE stream set exists at a time (set_lookahead_mode): HIP multiplexes streams onto few
-    // hardware queues, and with own + side_masked + upd + side streams alive the priority side stream shared a queue with the
-    // main stream: the chain serialised behind every update (940 instead of 715 ms, profiles/r03_b_hybrid_streams.log).
+    // to 73.0 ms per step, N = 50 000 from 710 to 732.  So the mode is chosen PER FACTORISATION (whole CUs below whole_cus_below
+    // rows; set_lookahead_mode).  All streams are created with the context, in a fixed order (api.hip create_lookahead_streams).
     hipStream_t upd_stream = nullptr;
     hipStream_t side_masked = nullptr;
     int reserved_cus = 0;
@@ -199,8 +197,8 @@ class BlockedGP;
 BlockedGP* blocked_of(gpmi_gp* gp);
 void blocked_destroy(void* p);
 
-// the look-ahead stream set of the context: whole CUs (side_masked + upd_stream) or free slots (side_stream); switching
-// synchronises the streams that go away.  Returns the mode in effect (0 when masks are unavailable).
+// which look-ahead stream set the next factorisation uses: whole CUs (side_masked + upd_stream) or free slots (side_stream).
+// Returns the mode in effect (0 when masks are unavailable).
 int set_lookahead_mode(gpmi_ctx* c, bool whole_cus);
 
 // RAII-free helpers -------------------------------------------------------------------------
@@ -292,7 +290,8 @@ void launch_linv256(gpmi_ctx* ctx, const T* A, int64_t ld, const T* linv64, T* o
 template <typename T>
 void launch_place_inv_blocks(gpmi_ctx* ctx, const T* l256, T* LW, T* LWT, int64_t wld, int nblk);
 template <typename T>
-void launch_bsolve256(gpmi_ctx* ctx, const T* Arow, int64_t ld, int64_t k0, int nbk, const T* linv256, T* z, T* alpha);
+void launch_bsolve256(gpmi_ctx* ctx, const T* Arow, int64_t ld, int64_t k0, int nbk, const T* linv256, T* z, T* alpha,
+                      int64_t ldinv = NB);  // ldinv: row stride of the NB x NB inverse (a diagonal block of a wider explicit inverse)
 template <typename T>
 void launch_finalize(gpmi_ctx* ctx, const T* A, int64_t ld, int64_t n, const T* y, const T* alpha, double* out);
 

@@ -70,8 +70,9 @@ struct Dev {
     // C[M x N] (-)= A[M x K] B[N x K]'
     virtual void gemm(void* C, int64_t ldc, const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
                       DevShape shape, int flags) = 0;
-    // alpha[c0 .. c0+nb) = L_cc^-T z[c0 ..) through the block's 64 x 64 inverses; z[0 .. c0) -= L[c rows, 0 .. c0)' alpha_c
-    virtual void bsolve_block(const void* Lrows, int64_t ld, int64_t c0, int64_t nb, const void* linv, void* z, void* alpha) = 0;
+    // alpha[c0 .. c0+nb) = L_cc^-T z[c0 ..) ; z[0 .. c0) -= L[c rows, 0 .. c0)' alpha_c     (lw: the block's explicit inverse,
+    // leading dimension nb; linv: its 64 x 64 diagonal inverses)
+    virtual void bsolve_block(const void* Lrows, int64_t ld, int64_t c0, int64_t nb, const void* linv, const void* lw, void* z, void* alpha) = 0;
     virtual double logdiag_sum(const void* A, int64_t ld, int64_t nrows, int64_t col_off) = 0;  // sum log A[i][col_off + i] (synchronises)
     virtual int64_t info(bool reset) = 0;                                                        // the not-PD latch (read synchronises)
     // ---- reductions over rows ----

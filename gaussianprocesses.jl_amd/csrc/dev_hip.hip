@@ -236,9 +236,12 @@ struct HipDev : Dev {
         TileShape sh{0, 0, s.mode, s.g0, s.G, s.nstair, s.tpb > 0 ? s.tpb : 2};
         launch_gemm_shape<T>(c, (T*)C, ldc, (const T*)A, lda, (const T*)B, ldb, M, N, K, sh, c->d_info, flags);
     }
-    void bsolve_block(const void* Lrows, int64_t ld, int64_t c0, int64_t nb, const void* linv, void* z, void* alpha) override {
-        for (int64_t j = nb - IB; j >= 0; j -= IB)
-            launch_bsolve_step<T>(c, (const T*)Lrows + j * ld, ld, c0 + j, (const T*)linv + (j / IB) * IB * IB, (T*)z, (T*)alpha);
+    void bsolve_block(const void* Lrows, int64_t ld, int64_t c0, int64_t nb, const void* linv, const void* lw, void* z, void* alpha) override {
+        // 256 columns per launch through the diagonal 256 x 256 blocks of the block's explicit inverse (they ARE the inverses of
+        // the factor's diagonal 256-blocks): N / 256 launches per solve instead of N / 64 through the 64 x 64 inverses
+        (void)linv;
+        for (int64_t j = nb - NB; j >= 0; j -= NB)
+            launch_bsolve256<T>(c, (const T*)Lrows + j * ld, ld, c0 + j, (int)NB, (const T*)lw + j * nb + j, (T*)z, (T*)alpha, nb);
     }
     double logdiag_sum(const void* A, int64_t ld, int64_t nrows, int64_t col_off) override {
         launch_logdiag<T>(c, (const T*)A, ld, nrows, col_off, c->d_scal);

@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256) void place_inv_blocks_kernel(const T* __restri
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(1024) void bsolve256_kernel(const T* __restrict__ Arow, int64_t ld, int64_t k0, int nbk,
-                                                         const T* __restrict__ Linv, T* __restrict__ z, T* __restrict__ alpha) {
+                                                         const T* __restrict__ Linv, int64_t ldi, T* __restrict__ z, T* __restrict__ alpha) {
     __shared__ T sz[NB];
     __shared__ T sal[NB];
     __shared__ T part[4][NB];
@@ -719,10 +719,10 @@ __global__ __launch_bounds__(1024) void bsolve256_kernel(const T* __restrict__ A
             const T* col = Linv + c;
 #pragma unroll 4
             for (int r = r_lo; r < r_hi; r += 4) {
-                s0 += col[(int64_t)r * NB] * sz[r];
-                s1 += col[(int64_t)(r + 1) * NB] * sz[r + 1];
-                s2 += col[(int64_t)(r + 2) * NB] * sz[r + 2];
-                s3 += col[(int64_t)(r + 3) * NB] * sz[r + 3];
+                s0 += col[(int64_t)r * ldi] * sz[r];
+                s1 += col[(int64_t)(r + 1) * ldi] * sz[r + 1];
+                s2 += col[(int64_t)(r + 2) * ldi] * sz[r + 2];
+                s3 += col[(int64_t)(r + 3) * ldi] * sz[r + 3];
             }
         }
         part[q][c] = (s0 + s1) + (s2 + s3);
@@ -904,9 +904,9 @@ void launch_linv256(gpmi_ctx* ctx, const T* A, int64_t ld, const T* linv64, T* o
     hipLaunchKernelGGL(linv256_kernel<T>, dim3((unsigned)side_cap(ctx, 4 * nblk)), dim3(256), 0, ctx->stream, A, ld, linv64, out, npad, info);
 }
 template <typename T>
-void launch_bsolve256(gpmi_ctx* ctx, const T* Arow, int64_t ld, int64_t k0, int nbk, const T* linv256, T* z, T* alpha) {
+void launch_bsolve256(gpmi_ctx* ctx, const T* Arow, int64_t ld, int64_t k0, int nbk, const T* linv256, T* z, T* alpha, int64_t ldinv) {
     const unsigned blocks = (unsigned)(k0 > 0 ? (k0 + 255) / 256 : 1);
-    hipLaunchKernelGGL(bsolve256_kernel<T>, dim3(blocks), dim3(1024), 0, ctx->stream, Arow, ld, k0, nbk, linv256, z, alpha);
+    hipLaunchKernelGGL(bsolve256_kernel<T>, dim3(blocks), dim3(1024), 0, ctx->stream, Arow, ld, k0, nbk, linv256, ldinv, z, alpha);
 }
 template <typename T>
 void launch_finalize(gpmi_ctx* ctx, const T* A, int64_t ld, int64_t n, const T* y, const T* alpha, double* out) {
@@ -943,7 +943,7 @@ void launch_logdiag(gpmi_ctx* ctx, const T* A, int64_t ld, int64_t nrows, int64_
     template void launch_bsolve_step<T>(gpmi_ctx*, const T*, int64_t, int64_t, const T*, T*, T*);                 \
     template void launch_linv256<T>(gpmi_ctx*, const T*, int64_t, const T*, T*, int64_t, const int*);             \
     template void launch_place_inv_blocks<T>(gpmi_ctx*, const T*, T*, T*, int64_t, int);             \
-    template void launch_bsolve256<T>(gpmi_ctx*, const T*, int64_t, int64_t, int, const T*, T*, T*);              \
+    template void launch_bsolve256<T>(gpmi_ctx*, const T*, int64_t, int64_t, int, const T*, T*, T*, int64_t);     \
     template void launch_finalize<T>(gpmi_ctx*, const T*, int64_t, int64_t, const T*, const T*, double*);         \
     template void launch_row_gemv<T>(gpmi_ctx*, const T*, int64_t, int64_t, int64_t, const T*, const T*, T*);     \
     template void launch_row_var<T>(gpmi_ctx*, const T*, int64_t, int64_t, int64_t, double, T*);                  \

@@ -25,7 +25,7 @@ from .gpe import GPE
 
 
 def default_block(n):
-    """Rows per distributed block (0 lets the library choose: 1024 from 16 384 points, 512 from 4096, else 256)."""
+    """Rows per distributed block (0 lets the library choose: 1024 from 32 768 points, 512 from 4096, else 256)."""
     e = os.environ.get("GPMI_DIST_WD")
     return int(e) if e else 0
 

@@ -96,7 +96,7 @@ withkernel(f, kd::KernelDesc) = GC.@preserve kd f(Ref(CKernel(length(kd.ops), po
 # Matrix(cK) are dense-only (libgpmi returns GPMI_EARG -> ArgumentError on a blocked handle).
 struct HIPCovariance <: CovarianceStrategy
     packed::Bool
-    block::Int            # rows per block (0: library default — 1024 from 16 384 points)
+    block::Int            # rows per block (0: library default — 1024 from 32 768 points)
     stripe_blocks::Int    # local blocks per storage stripe (packed)
     comm::Ptr{Cvoid}      # gpmi_comm* or C_NULL
 end

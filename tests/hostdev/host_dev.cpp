@@ -72,7 +72,7 @@ struct HostDev : Dev {
         if (info_ || M <= 0 || N <= 0 || K <= 0) return;
         ops.gemm((double*)C, ldc, (const double*)A, lda, (const double*)B, ldb, M, N, K, s.mode, s.g0, s.G, s.nstair, s.tpb, flags);
     }
-    void bsolve_block(const void* Lrows, int64_t ld, int64_t c0, int64_t nb, const void* linv, void* z, void* alpha) override {
+    void bsolve_block(const void* Lrows, int64_t ld, int64_t c0, int64_t nb, const void* linv, const void*, void* z, void* alpha) override {
         if (info_) return;
         ops.bsolve_block((const double*)Lrows, ld, c0, nb, (const double*)linv, (double*)z, (double*)alpha);
     }
