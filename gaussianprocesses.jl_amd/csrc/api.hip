@@ -194,18 +194,9 @@ static int drain_profile(gpmi_ctx* c) {
     return GPMI_OK;
 }
 
-// Both look-ahead stream sets are created WITH the context, in this order: own, priority side, masked chain, masked update.
-// Measured on the MI355X pool (profiles/r03_d_stream_order.log): streams created late behave badly — CU-masked streams made
-// after a large factorisation had run cost N = 20 000 ten ms per step (83.5 instead of 73.9), and with the priority stream
-// created LAST (fourth) the chain serialised behind every update (940 instead of 711 ms at N = 50 000).  In this order the
-// last stream is the masked update stream, which never runs concurrently with the context's own stream.
+// Both look-ahead stream sets are created WITH the context: the CU-masked pair here, right after the context's own stream (the
+// priority side stream comes before it: gpmi_ctx_create).
 static void create_lookahead_streams(gpmi_ctx* c) {
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = greatest priority (numerically lowest)
-    if (hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, hi) != hipSuccess) {
-        (void)hipGetLastError();
-        c->side_stream = nullptr;
-    }
     if (!c->mask_ok) return;
     // one CU per XCD for the chain: mask bit k * 33 (k = 0..7) lands on XCC k, one CU each (tools/cumask_probe.hip,
     // profiles/r01_coresidency_cumask_probe.log); the update stream gets the other 248
@@ -612,6 +603,18 @@ int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
     if (dev < 0 || dev >= count) return GPMI_EARG;
     gpmi_ctx* c = new gpmi_ctx();
     c->device = dev;
+    // Stream creation ORDER matters on this runtime (profiles/r03_d_stream_order.log, r03_e_*): priority side stream, the
+    // context's own stream, then the two CU-masked streams.  The masked streams must directly follow the own stream (created
+    // after the priority stream, or lazily after a large factorisation, they cost N = 20 000 ten ms per step), and the priority
+    // stream must not be the fourth (as the fourth it serialised behind the own stream: 940 instead of 711 ms at N = 50 000).
+    if (hipSetDevice(dev) == hipSuccess) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = greatest priority (numerically lowest)
+        if (hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, hi) != hipSuccess) {
+            (void)hipGetLastError();
+            c->side_stream = nullptr;
+        }
+    }
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc(&c->d_prog, sizeof(DevProgram)) != hipSuccess ||
         hipHostMalloc(&c->h_prog, sizeof(DevProgram)) != hipSuccess || hipMalloc(&c->d_info, sizeof(int)) != hipSuccess ||

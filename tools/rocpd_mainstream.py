@@ -12,10 +12,13 @@ qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols
 gcol = "grid_x" if "grid_x" in cols else ("grid_size_x" if "grid_size_x" in cols else ("grid_size" if "grid_size" in cols else "0"))
 wcol = "workgroup_x" if "workgroup_x" in cols else ("workgroup_size_x" if "workgroup_size_x" in cols else ("workgroup_size" if "workgroup_size" in cols else "1"))
 rows = db.execute(f"select name, start, end, {qcol}, {gcol}, {wcol} from kernels order by start").fetchall()
-covs = [i for i, r in enumerate(rows) if "cov_" in r[0] and (r[2] - r[1]) > 300000]
-i0 = covs[-1]
-# the fit ends at the finalize kernel after it
-i1 = next((i for i in range(i0, len(rows)) if "finalize" in rows[i][0]), len(rows) - 1)
+# the last fit: it ends at the last finalize kernel (dense path) / dot kernel (blocked path) and starts at the first covariance
+# launch after the end marker before that (the blocked path assembles block-row by block-row: many launches)
+ends = [i for i, r in enumerate(rows) if "finalize" in r[0] or "dot_kernel" in r[0]]
+i1 = ends[-1]
+prev_end = ends[-2] if len(ends) > 1 else -1
+i0 = next(i for i in range(prev_end + 1, i1) if "cov_" in rows[i][0] and (rows[i][2] - rows[i][1]) > 20000 and not any(
+    "row_gemv" in rows[j][0] or "row_sumsq" in rows[j][0] for j in range(i, min(i + 400, i1)) if rows[j][1] < rows[i][2] + 2_000_000))
 sel = rows[i0:i1 + 1]
 short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").replace("gpmi::", "").split("(")[0]
 busy = defaultdict(int)
