@@ -23,15 +23,19 @@
 namespace gpmi {
 
 static const double LOG2PI = 1.8378770664093453;
+static const int64_t kWholeCusBelow = 20480;  // rows left below which a step reserves whole CUs for the chain (common.h whole_cus_below)
 
 // 1024-row blocks once the K = 1024 update outlasts a 1024-block chain for most of the factorisation; narrower blocks keep the
 // chain (and the exposed tail) short below that
-static int64_t default_block(int64_t n) { return n >= 32768 ? 1024 : (n >= 4096 ? 512 : 256); }
+static int64_t default_block(int64_t n, int world) {
+    if (world == 1 && n >= 40960) return 2048;  // one rank: the dense path's widest super-panel (K = 2048 updates: 0.85 instead of 0.81 of peak)
+    return n >= 32768 ? 1024 : (n >= 4096 ? 512 : 256);
+}
 
 BlockedGP::BlockedGP(Dev* dev, Comm* comm, int d, int64_t n, BlockedOpts o)
     : dev_(dev), comm_(comm), rank_(comm ? comm->rank : 0), G_(comm ? comm->world : 1), d_(d), n_(n) {
     es_ = dev->es;
-    WD_ = o.block > 0 ? o.block : default_block(n);
+    WD_ = o.block > 0 ? o.block : default_block(n, G_);
     nblk_ = (n + WD_ - 1) / WD_;
     npad_ = nblk_ * WD_;
     tpb_ = (int)(WD_ / 128);
@@ -231,9 +235,9 @@ void BlockedGP::join_on_main() {
 
 // own rows (and the carried row) x block columns [c_lo, c_hi) -= X_k P_k' : the staircase of a block-cyclic shard, one launch
 // per stripe.  Only rows whose diagonal lies at or right of c_lo have entries there.
-void BlockedGP::update_cols(int64_t k, int64_t c_lo, int64_t c_hi) {
+void BlockedGP::update_cols(int64_t k, int64_t c_lo, int64_t c_hi, int64_t min_block) {
     if (c_lo >= c_hi) return;
-    const int first = n_le(rank_, c_lo - 1);
+    const int first = n_le(rank_, std::max(c_lo, min_block) - 1);
     for (const Piece& pc : pieces(first, true)) {
         const int64_t M = (int64_t)pc.nb * WD_ + (pc.carried ? 1 : 0);
         const int64_t ncols = std::min<int64_t>(c_hi * WD_, pc.width) - c_lo * WD_;
@@ -286,8 +290,10 @@ int BlockedGP::fit(const gpmi_kernel* kern, const double* log_noise, int64_t n_n
         dev_->copy2d(cr, ldc * es_, ymu_, npad_ * es_, npad_ * es_, 1);
     }
     // whole compute units for the chain and the exchange when collectives must find room beside the update (G > 1) or the
-    // factorisation is short enough for the chain to be exposed; free slots beside a full-width update otherwise (common.h)
-    dev_->whole_cus(G_ > 1 || npad_ < 32768);
+    // update is short enough for the chain to be exposed; free slots beside a full-width update otherwise (common.h).  Chosen
+    // per step below: a factorisation starts with free slots and ends on whole CUs.
+    bool whole_now = G_ > 1 || npad_ - 2 * WD_ < kWholeCusBelow;
+    dev_->whole_cus(whole_now);
     DevEvent e0 = dev_->record();
     for (DevStream s : {DS_SIDE, DS_COMM, DS_UPD}) {
         dev_->use(s);
@@ -305,10 +311,24 @@ int BlockedGP::fit(const gpmi_kernel* kern, const double* log_noise, int64_t n_n
     for (int64_t k = 0; k + 1 < nblk_; ++k) {
         const int64_t k0 = k * WD_, k1 = k0 + WD_;
         const int nle = n_le(rank_, k);
+        const bool whole = G_ > 1 || npad_ - (k + 2) * WD_ < kWholeCusBelow;
+        if (whole != whole_now) {  // the two modes use different streams: join the step's streams, switch, fan out again
+            join_on_main();
+            DevEvent ej = dev_->record();
+            dev_->whole_cus(whole);
+            whole_now = whole;
+            for (DevStream st : {DS_UPD, DS_SIDE, DS_COMM}) {
+                dev_->use(st);
+                dev_->wait(ej);
+            }
+        }
         dev_->use(DS_UPD);
         dev_->wait(ev_p_);
         // U1: block column k+1 of every own row below block k
         const bool mine_next = (k + 1) % G_ == rank_;
+        // (one rank: only the next diagonal block goes first — the chain needs nothing else — and the rest of block column k+1
+        //  is part of the one big update below, as in chol.h; with an exchange to hide, the whole column goes first so that the
+        //  next panel can be solved and sent early)
         DevShape rect, lower;
         lower.mode = 1;
         bool first_piece = true;
@@ -321,7 +341,7 @@ int BlockedGP::fit(const gpmi_kernel* kern, const double* log_noise, int64_t n_n
                 M -= WD_;
             }
             first_piece = false;
-            if (M > 0) dev_->gemm(rows + k1 * es_, pc.ld, rows + k0 * es_, pc.ld, panel_rows(k, k + 1), ldP_, M, WD_, WD_, rect, 0);
+            if (G_ > 1 && M > 0) dev_->gemm(rows + k1 * es_, pc.ld, rows + k0 * es_, pc.ld, panel_rows(k, k + 1), ldP_, M, WD_, WD_, rect, 0);
         }
         DevEvent ev_u1 = dev_->record();
         DevEvent chain = ev_u1;
@@ -337,13 +357,17 @@ int BlockedGP::fit(const gpmi_kernel* kern, const double* log_noise, int64_t n_n
         }
         bcast_lw(k + 1, chain);
         // U2a: enough block columns to cover the chain and the broadcast, then the next panel, then the rest under the exchange
+        // (one rank: nothing to exchange — the whole update hides the chain, the next panel is solved after it, as chol.h does)
         const int64_t rest = nblk_ - (k + 2);
-        const int64_t m = std::min<int64_t>(nblk_, k + 2 + std::max<int64_t>(rest > 0 ? 1 : 0, (rest + 3) / 4));
+        const int64_t m = G_ == 1 ? nblk_ : std::min<int64_t>(nblk_, k + 2 + std::max<int64_t>(rest > 0 ? 1 : 0, (rest + 3) / 4));
         dev_->use(DS_UPD);
-        update_cols(k, k + 2, m);
+        if (G_ == 1)
+            update_cols(k, k + 1, nblk_, k + 2);  // everything but the next diagonal block, in one launch per stripe
+        else
+            update_cols(k, k + 2, m, 0);
         solve_and_gather(k + 1, nullptr);
         dev_->use(DS_UPD);
-        update_cols(k, m, nblk_);
+        if (G_ > 1) update_cols(k, m, nblk_, 0);
     }
     // join the streams on the main one
     join_on_main();

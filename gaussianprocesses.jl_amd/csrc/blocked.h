@@ -14,7 +14,7 @@
 namespace gpmi {
 
 struct BlockedOpts {
-    int64_t block = 0;      // rows per distributed block (0: 1024 from 32 768 points, 512 from 4096, else 256)
+    int64_t block = 0;      // rows per distributed block (0: 2048 from 40 960 points on one rank, else 1024 from 32 768, 512 from 4096, 256 below)
     int stripe_blocks = 0;  // local blocks per storage stripe (0: one stripe = the plain rows x npad matrix)
 };
 
@@ -93,7 +93,7 @@ class BlockedGP {
     DevEvent ev_lw_ = nullptr, ev_p_ = nullptr;
     void bcast_lw(int64_t k, DevEvent after);
     void solve_and_gather(int64_t k, const char* from_A_only);
-    void update_cols(int64_t k, int64_t c_lo, int64_t c_hi);
+    void update_cols(int64_t k, int64_t c_lo, int64_t c_hi, int64_t min_block);
     void join_on_main();
     int comm_rc_ = 0;
 };

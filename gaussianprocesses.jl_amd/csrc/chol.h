@@ -306,8 +306,11 @@ inline int cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, in
                           SuperStore<T>* store = nullptr) {
     const int64_t Mtot = npad + extra;
     const bool want_look = c->lookahead_slots > 0 && npad > 4 * NB;
-    hipStream_t main_s = c->stream, side = c->side_stream;
-    const bool can_look = want_look && (c->side_stream != nullptr || c->side_masked != nullptr);
+    // whole CUs for the chain in short factorisations (the chain would be exposed), free slots beside a full-width update in long
+    // ones: chosen per factorisation (switching inside one measured WORSE at N = 50 000: 718 against 711 ms, profiles/r03_f_*)
+    const bool masked = want_look && set_lookahead_mode(c, npad < c->whole_cus_below) == 1;
+    hipStream_t main_s = c->stream, side = masked ? c->side_masked : c->side_stream;
+    const bool can_look = want_look && side != nullptr;
     if (store && store->parts) store->parts->clear();
 
     // the inverse path serves super-panels of NB * 2^s > NB columns; factorisations that carry the refinement step
@@ -354,10 +357,6 @@ inline int cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, in
         // The side stream's chain takes ~0.4 ms per 256 columns beside the update (contended CUs): look ahead only while
         // the update is longer.  Update length in units of a 128 x 128 x 256 tile product:
         const double ntile = 0.5 * (double)(npad - ke2) * (double)(npad - ke2) / (GEMM_BM * GEMM_BN) * (double)K / NB;
-        // per step: whole CUs for the chain once fewer than whole_cus_below rows remain (the update is then short enough for
-        // the chain to be exposed), free slots beside a full-width update before that (common.h)
-        const bool masked = want_look && set_lookahead_mode(c, npad - ke2 < c->whole_cus_below) == 1;
-        side = masked ? c->side_masked : c->side_stream;
         if (!can_look || ntile < (double)(masked ? c->lookahead_min_tiles_masked : c->lookahead_min_tiles) * (double)((w2 + NB - 1) / NB)) {
             launch_gemm_nt<T>(c, A + ke * ld + ke, ld, A + ke * ld + ks, ld, A + ke * ld + ks, ld, Mtot - ke, npad - ke, K, 1, d_info);
             factor_diag_block<T>(c, A, ld, linv, invdiag, ke, w2, d_info);

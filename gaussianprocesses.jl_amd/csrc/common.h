@@ -103,15 +103,15 @@ struct gpmi_ctx {
     // the main stream), so the chain's single-wave kernels no longer share a SIMD with GEMM waves (diag64: 26 us alone, ~130 us
     // beside a GEMM workgroup on the same CU).  Measured (profiles/r03_a_cumask_ab.log): whole CUs cost the update 4.3 % (589 ->
     // 615 ms at N = 50 000) where round 2's free workgroup slots cost ~1.5 %, and shorten the chain 5x: N = 20 000 goes from 78.3
-    // to 73.0 ms per step, N = 50 000 from 710 to 732.  So the mode is chosen PER LOOK-AHEAD STEP (whole CUs once fewer than
-    // whole_cus_below rows remain; set_lookahead_mode).  All streams are created with the context, in a fixed order (api.hip create_lookahead_streams).
+    // to 73.0 ms per step, N = 50 000 from 710 to 732.  So the mode is chosen PER FACTORISATION (whole CUs below whole_cus_below
+    // rows; set_lookahead_mode).  All streams are created with the context, in a fixed order (api.hip create_lookahead_streams).
     hipStream_t upd_stream = nullptr;
     hipStream_t side_masked = nullptr;
     int reserved_cus = 0;
     int la_mode = -1;                // -1 none yet, 0 free slots (side_stream), 1 whole CUs (side_masked + upd_stream)
     bool mask_ok = false;            // CU-masked streams are available (256 CUs, GPMI_CUMASK != 0, creation has not failed)
-    int64_t whole_cus_below = 20480; // look-ahead steps with fewer rows left reserve whole CUs for the chain (dense path: per step;
-                                     // blocked path: per factorisation, blocked.cpp)
+    int64_t whole_cus_below = 32768; // factorisations of fewer rows reserve whole CUs for the chain (the blocked path decides per
+                                     // step: its fixed-width blocks leave a long chain-bound tail, blocked.cpp)
     int64_t lookahead_min_tiles_masked = 288;  // = a 3072-row trailing matrix at K = 256: the fast chain hides under shorter updates
     int lookahead_slots = 0;
     int64_t lookahead_min_tiles = 650;   // update length (in 128 x 128 x 256 tile products) below which the serial order is
