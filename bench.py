@@ -44,7 +44,7 @@ for p in (ROOT, os.path.join(ROOT, "gaussianprocesses.jl_amd")):
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (v_mfma_f64_16x16x4_f64): 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: Peak FP32 (matrix)
-PMC_RECORD = os.path.join("profiles", "r02_bench_pmc_hbm.json")
+PMC_RECORD = os.path.join("profiles", "r03_bench_pmc_hbm.json")
 
 
 def _pmc_traffic(args, n, d, p):

@@ -352,7 +352,7 @@ static int grad_t(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, do
     if (rc != GPMI_OK) return rc;
     const int n_hyp = c->h_prog->n_hyp;
     if (c->h_prog->n_ops > GRAD_MAX_NODES || n_hyp > GRAD_MAX_HYP || gp->d > GRAD_MAX_D) {
-        c->err = "gpmi_grad: kernel outside the device gradient path (<= 48 hyper-parameters, d <= 16)";
+        c->err = "gpmi_grad: kernel outside the device gradient path (<= 64 hyper-parameters, d <= 32)";
         return GPMI_EARG;
     }
     const size_t bytes = (size_t)(npad * ld) * sizeof(T);

@@ -28,7 +28,7 @@ static const int64_t kWholeCusBelow = 20480;  // rows left below which a step re
 // 1024-row blocks once the K = 1024 update outlasts a 1024-block chain for most of the factorisation; narrower blocks keep the
 // chain (and the exposed tail) short below that
 static int64_t default_block(int64_t n, int world) {
-    if (world == 1 && n >= 40960) return 2048;  // one rank: the dense path's widest super-panel (K = 2048 updates: 0.85 instead of 0.81 of peak)
+    if (world == 1 && n >= 131072) return 2048;  // one rank, very large n: K = 2048 updates (N = 200 000 fp32: 20.9 instead of 22.0 s); below that the 2048-block chain outlasts the shrinking updates (N = 50 000: 790 instead of 760 ms, profiles/r03_h_*)
     return n >= 32768 ? 1024 : (n >= 4096 ? 512 : 256);
 }
 

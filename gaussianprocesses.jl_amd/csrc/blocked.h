@@ -14,7 +14,7 @@
 namespace gpmi {
 
 struct BlockedOpts {
-    int64_t block = 0;      // rows per distributed block (0: 2048 from 40 960 points on one rank, else 1024 from 32 768, 512 from 4096, 256 below)
+    int64_t block = 0;      // rows per distributed block (0: 1024 from 32 768 points — 2048 from 131 072 on one rank —, 512 from 4096, 256 below)
     int stripe_blocks = 0;  // local blocks per storage stripe (0: one stripe = the plain rows x npad matrix)
 };
 

@@ -313,8 +313,8 @@ void launch_logdiag(gpmi_ctx* ctx, const T* A, int64_t ld, int64_t nrows, int64_
 
 // gradient path -------------------------------------------------------------------------------------------
 constexpr int GRAD_MAX_NODES = 32;  // kernel-tree size the device gradient handles (cost grows with leaves^2)
-constexpr int GRAD_MAX_HYP = 48;    // hyper-parameters
-constexpr int GRAD_MAX_D = 16;      // input dimension
+constexpr int GRAD_MAX_HYP = 64;    // hyper-parameters: (n_hyp + 1) x 256 double accumulators + the 64 x d row points share the 160 KB of LDS
+constexpr int GRAD_MAX_D = 32;      // input dimension (the pair's d squared differences live in registers)
 // A[i][i] = 1, everything else 0 (n x n, row-major)
 template <typename T>
 void launch_set_identity(gpmi_ctx* ctx, T* A, int64_t ld, int64_t n);

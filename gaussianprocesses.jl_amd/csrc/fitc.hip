@@ -522,7 +522,7 @@ int fitc_grad_t(gpmi_fitc* f, const gpmi_kernel* k, double log_noise, double* dk
         }
     }
     if (n_hyp > GRAD_MAX_HYP || f->d > GRAD_MAX_D || c->h_prog->n_ops > GRAD_MAX_NODES) {
-        c->err = "gpmi_fitc_grad: the device gradient covers kernels with <= 48 hyper-parameters, <= 32 nodes, d <= 16";
+        c->err = "gpmi_fitc_grad: the device gradient covers kernels with <= 64 hyper-parameters, <= 32 nodes, d <= 32";
         return GPMI_EARG;
     }
     const size_t es = sizeof(T);

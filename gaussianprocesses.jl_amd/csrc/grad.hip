@@ -297,8 +297,10 @@ static int64_t launch_dmll_any(gpmi_ctx* ctx, const T* x, int64_t n, int d, cons
         go(dmll_kernel<T, 4, RECT>);
     else if (d <= 8)
         go(dmll_kernel<T, 8, RECT>);
-    else
+    else if (d <= 16)
         go(dmll_kernel<T, 16, RECT>);
+    else
+        go(dmll_kernel<T, 32, RECT>);
     return (int64_t)ntr * ntc;
 }
 template <typename T>

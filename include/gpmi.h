@@ -127,7 +127,7 @@ int gpmi_predict(gpmi_gp*, const gpmi_kernel*, int64_t p, const void* xpred, con
  *   dnoise_out   = exp(2 logNoise) tr(alpha alpha' - K^-1)             (dmll_noise, GPE.jl:273-275; may be NULL)
  * The mean part, dot(grad_mean, alpha) (GPE.jl:282-288), is O(N d) host work on alpha.
  * n_kern must equal the kernel's parameter count.  Allocates two more n x n device buffers on
- * first use.  Kernels beyond 48 parameters / d > 16 return GPMI_EARG.          */
+ * first use.  Kernels beyond 64 parameters / d > 32 return GPMI_EARG (cov! itself: d <= 64).          */
 int gpmi_grad(gpmi_gp*, const gpmi_kernel*, const double* log_noise, int64_t n_noise, double* dkern_out, int32_t n_kern,
               double* dnoise_out);
 
@@ -162,7 +162,7 @@ int gpmi_fitc_grad(gpmi_fitc*, const gpmi_kernel*, double log_noise, double* dke
 
 /* ---- blocked model object: packed storage on one device, row-block sharding over several ---------
  * The same gpmi_gp handle type and the same gpmi_fit / gpmi_predict / gpmi_grad / gpmi_logdet / gpmi_factor_diag, with the
- * factor of K + noise held as block-rows of block_rows = 256 * 2^s rows (0: 2048 from 40 960 points on one rank, else 1024 from 32 768, 512 from 4096, 256 below)
+ * factor of K + noise held as block-rows of block_rows = 256 * 2^s rows (0: 1024 from 32 768 points — 2048 from 131 072 on one rank —, 512 from 4096, 256 below)
  *   - dealt round-robin over the ranks of `comm` (one process per GPU; every rank makes the same calls with the same
  *     arguments and receives the same results: mll, alpha, mu, var, gradient are replicated), and
  *   - per rank, in stripes of stripe_blocks local blocks that stop at their own diagonal (0: one stripe = full rows), so the
