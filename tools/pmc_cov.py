@@ -10,7 +10,7 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             name = row.get("Kernel_Name", "")
             if "cov_" not in name or row.get("Counter_Name") != counter:
                 continue
-            k = name.split("(")[0].replace("void gpmi::(anonymous namespace)::", "")
+            k = name.replace("void gpmi::(anonymous namespace)::", "").split("(")[0]
             e = out.setdefault(k, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "ns": 0.0, "launches": 0})
             e[counter] += float(row["Counter_Value"]) * 1024.0
             if counter == "WRITE_SIZE":
