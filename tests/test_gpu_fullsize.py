@@ -1,10 +1,10 @@
 """Parity at BASELINE.json's full sizes.
 
-C2 (N=20000, d=8, SEArd, fp64) is compared DIRECTLY with the CPU oracle (about a minute of host
-LAPACK).  C3 (N=50000, d=8, (SEArd+Mat52Iso)+Noise, fp64) is too large for a host factorisation
-in the test budget, so it is checked through size-independent properties of the result:
-    residual      (K + s2 I) alpha = y - mu           (K rebuilt by the ORACLE in row chunks)
-    factor        |L^-1 (K v)|^2 = v' K v             for a random v  (pins the whole factor)
+C2 (N=20000, d=8, SEArd, fp64) and, since round 3, C3 (N=50000, d=8, (SEArd+Mat52Iso)+Noise, fp64) are compared DIRECTLY with
+the CPU oracle (host LAPACK: about a minute resp. two).  C3 is additionally — and C4 (N=200000, fp32), which has no fp64
+counterpart that fits anywhere, exclusively — checked through size-independent properties of the result on sparse probes:
+    residual      (K + s2 I) alpha = y - mu           (K rows rebuilt by the ORACLE for ~1000 random rows)
+    factor        |L^-1 (K v)|^2 = v' K v             for a v supported on ~100 points  (pins the whole factor)
     mll           -(y'alpha + logdet + n log 2pi)/2   recomputed from the parts
     predict       sigma2 in [0, k(x,x)], mu finite; at training inputs mu ~ y (test/gp.jl:47-50)
 """
@@ -46,6 +46,8 @@ def test_c2_n20000_direct_vs_oracle():
 
 
 def test_c3_n50000_composite_properties():
+    """Size-independent properties on sparse probes the oracle can rebuild in seconds (the DIRECT comparison against the oracle's
+    full factorisation is test_c3_n50000_composite_direct_vs_oracle below)."""
     n = 50000
     x, y, xs = G.synthetic_inputs(n, 8, p=512)
     spec = ("sum", ("sum", ("se_ard", LL8, 0.0), ("mat52_iso", math.log(0.7), math.log(0.5))), ("noise", math.log(0.05)))
@@ -53,13 +55,17 @@ def test_c3_n50000_composite_properties():
     gp = g.GP(x, y, g.MeanZero(), g.from_spec(spec), log_noise)
     nv = math.exp(2 * log_noise)
     rng = np.random.default_rng(0)
-    v = rng.standard_normal(n)
-    KV = _Kv_chunked(spec, x, nv, np.stack([gp.alpha, v], axis=1))
-    # residual of the solve
-    assert np.abs(KV[:, 0] - y).max() <= 1e-8 * max(1.0, np.abs(y).max())
-    # the factor: |L^-1 K v|^2 == v'Kv
-    w = gp.cK.whiten(KV[:, 1])
-    assert float(w @ w) == pytest.approx(float(v @ KV[:, 1]), rel=1e-10)
+    # residual of the solve on 1024 random rows (K rows rebuilt by the oracle)
+    rows = np.sort(rng.choice(n, 1024, replace=False))
+    r = G.cov(spec, x[:, rows], x) @ gp.alpha + nv * gp.alpha[rows] - y[rows]
+    assert np.abs(r).max() <= 1e-8 * max(1.0, np.abs(y).max())
+    # the factor: |L^-1 K v|^2 == v'Kv for a v supported on 96 points (K v needs 96 columns of K only)
+    S = np.sort(rng.choice(n, 96, replace=False))
+    vS = rng.standard_normal(96)
+    Kv = G.cov(spec, x, x[:, S]) @ vS
+    Kv[S] += nv * vS
+    w = gp.cK.whiten(Kv)
+    assert float(w @ w) == pytest.approx(float(vS @ Kv[S]), rel=1e-10)
     # logdet, independently of the device's reduction: 2 Σ log U_ii summed on the host from the factor's diagonal ...
     dg = np.asarray(gp.cK.factor_diag(), dtype=np.float64)
     assert np.all(dg > 0)
