@@ -183,7 +183,7 @@ void BlockedGP::bcast_lw(int64_t k, DevEvent after) {
 // Rows below block k (own blocks with global index > k, plus the carried row): X <- X LW_k' out of place into S (which is the
 // send buffer of the exchange and, on one rank, the panel itself), copied back into the factor; then the all-gather into P_k
 // in global row order.  from_factor: the rows are already solved (gradient: the panel is re-gathered from the stored factor).
-void BlockedGP::solve_and_gather(int64_t k, const char* from_factor) {
+void BlockedGP::solve_and_gather(int64_t k, bool from_factor) {
     const int64_t k0 = k * WD_;
     const int nle = n_le(rank_, k);
     char* S = S_[G_ == 1 ? (k & 1) : 0];
@@ -307,7 +307,7 @@ int BlockedGP::fit(const gpmi_kernel* kern, const double* log_noise, int64_t n_n
         after = dev_->record();
     }
     bcast_lw(0, after);
-    solve_and_gather(0, nullptr);
+    solve_and_gather(0, false);
     for (int64_t k = 0; k + 1 < nblk_; ++k) {
         const int64_t k0 = k * WD_, k1 = k0 + WD_;
         const int nle = n_le(rank_, k);
@@ -365,7 +365,7 @@ int BlockedGP::fit(const gpmi_kernel* kern, const double* log_noise, int64_t n_n
             update_cols(k, k + 1, nblk_, k + 2);  // everything but the next diagonal block, in one launch per stripe
         else
             update_cols(k, k + 2, m, 0);
-        solve_and_gather(k + 1, nullptr);
+        solve_and_gather(k + 1, false);
         dev_->use(DS_UPD);
         if (G_ > 1) update_cols(k, m, nblk_, 0);
     }
@@ -467,13 +467,11 @@ int BlockedGP::predict(const gpmi_kernel* kern, int64_t P, const void* xpred_hos
     if ((rc = grow(&xp_, &xp_cap_, P * d_ * es_))) return rc;
     if ((rc = grow(&Rloc_, &Rloc_cap_, Ppad * ldR * es_))) return rc;
     if ((rc = grow(&Vk_, &Vk_cap_, Ppad * ldP_ * es_))) return rc;
-    if ((rc = grow(&small_, &small_cap_, (4 * Ppad + (int64_t)maxown_ * WD_) * es_ + 2 * Ppad * 8))) return rc;
+    if ((rc = grow(&small_, &small_cap_, (2 * Ppad + (int64_t)maxown_ * WD_) * es_ + 2 * Ppad * 8))) return rc;
     if (full_cov && (rc = grow(&Kpp_, &Kpp_cap_, Ppad * ldK * es_))) return rc;
     char* mean_d = small_;
     char* mu_d = small_ + Ppad * es_;
-    char* var_d = small_ + 2 * Ppad * es_;
-    char* zero_d = small_ + 3 * Ppad * es_;
-    char* aloc = small_ + 4 * Ppad * es_;
+    char* aloc = small_ + 2 * Ppad * es_;
     double* s2acc = (double*)(aloc + (int64_t)maxown_ * WD_ * es_);
     dev_->upload(xp_, xpred_host, P * d_ * es_);
     dev_->zero(small_, small_cap_);
@@ -521,8 +519,6 @@ int BlockedGP::predict(const gpmi_kernel* kern, int64_t P, const void* xpred_hos
             else
                 ((float*)var_out)[p] = (float)v;
         }
-        (void)var_d;
-        (void)zero_d;
         return GPMI_OK;
     }
     std::vector<char> tmp((size_t)(P * ldK * es_));
@@ -582,7 +578,7 @@ int BlockedGP::grad(const gpmi_kernel* kern, const double* log_noise, int64_t n_
     for (int64_t k = 0; k < nblk_; ++k) {
         const int nrows_blk = n_le(rank_, k);  // own blocks <= k
         const int64_t M = (int64_t)nrows_blk * WD_;
-        if (k + 1 < nblk_) solve_and_gather(k, "factor");  // P_k from the stored factor (UPD packs, SIDE gathers)
+        if (k + 1 < nblk_) solve_and_gather(k, true);  // P_k from the stored factor (UPD packs, SIDE gathers)
         dev_->use(DS_UPD);
         if (M > 0) {
             dev_->gemm(S2, ldP_, G1_ + k * WD_ * es_, ldG, LW_ + k * WD_ * WD_ * es_, WD_, M, WD_, WD_, rect, DG_OVERWRITE | DG_KEND_COL);

@@ -77,7 +77,6 @@ class BlockedGP {
     int n_le(int q, int64_t k) const { return k >= q ? (int)((k - q) / G_ + 1) : 0; }  // blocks of rank q with global index <= k
     int n_below(int q, int64_t k) const { return n_own_of(q) - n_le(q, k); }
     int n_own_of(int q) const { return q < nblk_ ? (int)((nblk_ - 1 - q) / G_ + 1) : 0; }
-    char* at(char* base, int64_t row, int64_t ld, int64_t col) const { return base + (row * ld + col) * es_; }
     const Stripe& stripe_of(int i) const;
     char* block_ptr(int i, int64_t* ld, int64_t* width) const;
     char* carried_ptr(int64_t* ld) const;
@@ -92,7 +91,7 @@ class BlockedGP {
     // factorisation pieces
     DevEvent ev_lw_ = nullptr, ev_p_ = nullptr;
     void bcast_lw(int64_t k, DevEvent after);
-    void solve_and_gather(int64_t k, const char* from_A_only);
+    void solve_and_gather(int64_t k, bool from_factor);  // from_factor: the rows are already solved (gradient: re-gather a stored panel)
     void update_cols(int64_t k, int64_t c_lo, int64_t c_hi, int64_t min_block);
     void join_on_main();
     int comm_rc_ = 0;
