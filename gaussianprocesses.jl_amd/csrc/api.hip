@@ -593,14 +593,31 @@ extern "C" {
 
 const char* gpmi_version(void) { return "gpmi 0.3 (gfx950)"; }
 
+static int create_one_context(int dev, gpmi_ctx** out);
+
 int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
     if (!out) return GPMI_EARG;
     *out = nullptr;
-    if (n_devices != 1) return GPMI_EARG;
+    if (n_devices < 1 || n_devices > 64 || (n_devices > 1 && !device_ids)) return GPMI_EARG;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return GPMI_EDEVICE;  // no GPU: no fallback
-    const int dev = device_ids ? device_ids[0] : 0;
-    if (dev < 0 || dev >= count) return GPMI_EARG;
+    for (int i = 0; i < n_devices; ++i) {
+        const int dev = device_ids ? device_ids[i] : 0;
+        if (dev < 0 || dev >= count) return GPMI_EARG;
+    }
+    gpmi_ctx* c = nullptr;
+    int rc = create_one_context(device_ids ? device_ids[0] : 0, &c);
+    if (rc != GPMI_OK) return rc;
+    if (n_devices > 1 && (rc = group_create(c, n_devices, device_ids)) != GPMI_OK) {
+        gpmi_ctx_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return GPMI_OK;
+}
+
+static int create_one_context(int dev, gpmi_ctx** out) {
+    *out = nullptr;
     gpmi_ctx* c = new gpmi_ctx();
     c->device = dev;
     // Stream creation ORDER matters on this runtime (profiles/r03_d_stream_order.log, r03_e_*): priority side stream, the
@@ -683,6 +700,7 @@ int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
 
 void gpmi_ctx_destroy(gpmi_ctx* c) {
     if (!c) return;
+    if (c->group && c->group_rank == 0) group_destroy(c);  // the other members of a device group go with their primary
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& r : c->prof) {
@@ -753,6 +771,11 @@ void gpmi_gp_destroy(gpmi_gp* gp) {
         hipSetDevice(gp->ctx->device);
         hipStreamSynchronize(gp->ctx->stream);
     }
+    if (gp->group) {
+        group_gp_destroy(gp);
+        delete gp;
+        return;
+    }
     if (gp->blocked) {
         blocked_destroy(gp->blocked);
         delete gp;
@@ -775,6 +798,7 @@ int gpmi_fit(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int64_t
         return GPMI_EARG;
     }
     GPMI_HIP(c, hipSetDevice(c->device));
+    if (gp->group) return group_fit(gp, k, log_noise, n_noise, y_minus_mu, mll_out, alpha_out, info_out);
     if (BlockedGP* b = blocked_of(gp)) {
         const int rc = b->fit(k, log_noise, n_noise, y_minus_mu, mll_out, alpha_out, info_out);
         if (rc != GPMI_OK) c->err = b->error();
@@ -792,6 +816,7 @@ int gpmi_predict(gpmi_gp* gp, const gpmi_kernel* k, int64_t p, const void* xpred
         c->err = "gpmi_predict: bad argument";
         return GPMI_EARG;
     }
+    if (gp->group) return group_predict(gp, k, p, xpred, mean_pred, full_cov, mu_out, var_out);
     if (BlockedGP* b = blocked_of(gp)) {
         GPMI_HIP(c, hipSetDevice(c->device));
         const int rc = b->predict(k, p, xpred, mean_pred, full_cov, mu_out, var_out);
@@ -819,6 +844,7 @@ int gpmi_grad(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int64_
         c->err = "gpmi_grad: the noise gradient is defined for scalar logNoise only (GPE.jl:313)";
         return GPMI_EARG;
     }
+    if (gp->group) return group_grad(gp, k, log_noise, n_noise, dkern_out, n_kern, dnoise_out);
     if (BlockedGP* b = blocked_of(gp)) {
         GPMI_HIP(c, hipSetDevice(c->device));
         const int rc = b->grad(k, log_noise, n_noise, dkern_out, n_kern, dnoise_out);
@@ -933,6 +959,7 @@ int gpmi_factor_diag(gpmi_gp* gp, void* diag_out) {
         return GPMI_EARG;
     }
     GPMI_HIP(c, hipSetDevice(c->device));
+    if (gp->group) return group_factor_diag(gp, diag_out);
     if (BlockedGP* b = blocked_of(gp)) {
         rc = b->factor_diag(diag_out);
         if (rc != GPMI_OK) c->err = b->error();
@@ -1001,3 +1028,6 @@ int gpmi_mfma_peak(gpmi_ctx* c, int dtype, double* tflops_out) {
 }
 
 }  // extern "C"
+
+// one context on one device (a member of a device group is one of these too: group_create, dev_hip.hip)
+int gpmi::create_member_context(int dev, gpmi_ctx** out) { return create_one_context(dev, out); }

@@ -74,6 +74,8 @@ struct SuperPart {
 
 struct gpmi_ctx {
     int device = 0;
+    void* group = nullptr;  // non-null: member of an in-process device group (gpmi_ctx_create with n_devices > 1; dev_hip.hip)
+    int group_rank = 0;     // 0 = the primary (the handle the caller holds)
     hipStream_t stream = nullptr;
     std::string err;
     gpmi::DevProgram* d_prog = nullptr;  // device copy of the current kernel program
@@ -158,6 +160,7 @@ inline int64_t side_cap(const gpmi_ctx* c, int64_t nwg) {
 
 struct gpmi_gp {
     gpmi_ctx* ctx = nullptr;
+    void* group = nullptr;    // non-null: a blocked model sharded over the devices of the context's group, one BlockedGP per member
     void* blocked = nullptr;  // non-null: a BLOCKED handle (gpmi_gp_create_blocked; dev_hip.hip / blocked.cpp) — the dense fields below are unused
     int dtype = 64;
     int d = 0;
@@ -195,8 +198,20 @@ namespace gpmi {
 
 // blocked handles (dev_hip.hip)
 class BlockedGP;
-BlockedGP* blocked_of(gpmi_gp* gp);
+BlockedGP* blocked_of(gpmi_gp* gp);  // the (rank-0) driver of a blocked handle, or nullptr
 void blocked_destroy(void* p);
+// in-process device groups: gpmi_ctx_create(n_devices > 1) — one context per device id, an in-process communicator (peer copies
+// ordered by events), one worker thread per member for the duration of a call (dev_hip.hip)
+int create_member_context(int dev, gpmi_ctx** out);
+int group_create(gpmi_ctx* primary, int n, const int* device_ids);
+void group_destroy(gpmi_ctx* primary);
+int group_gp_create(gpmi_ctx* primary, int dtype, int d, int64_t n, const void* x, int64_t block_rows, int stripe_blocks, gpmi_gp** out);
+void group_gp_destroy(gpmi_gp* gp);
+int group_fit(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int64_t n_noise, const void* ymu, double* mll_out, void* alpha_out,
+              int64_t* info_out);
+int group_predict(gpmi_gp* gp, const gpmi_kernel* k, int64_t p, const void* xpred, const void* mean_pred, int full_cov, void* mu_out, void* var_out);
+int group_grad(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int64_t n_noise, double* dkern_out, int n_kern, double* dnoise_out);
+int group_factor_diag(gpmi_gp* gp, void* out);
 
 // which look-ahead stream set the next factorisation uses: whole CUs (side_masked + upd_stream) or free slots (side_stream).
 // Returns the mode in effect (0 when masks are unavailable).

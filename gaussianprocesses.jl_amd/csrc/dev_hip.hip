@@ -13,7 +13,10 @@
 #include <math.h>
 #include <string.h>
 
+#include <condition_variable>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "blocked.h"
@@ -390,7 +393,324 @@ struct BlockedHandle {
     std::unique_ptr<BlockedGP> gp;
 };
 void blocked_destroy(void* p) { delete (BlockedHandle*)p; }
-BlockedGP* blocked_of(gpmi_gp* gp) { return gp && gp->blocked ? ((BlockedHandle*)gp->blocked)->gp.get() : nullptr; }
+
+// ---- in-process device group -------------------------------------------------------------------------------------------
+// gpmi_ctx_create(n_devices > 1): SURVEY 8(b)'s single-process multi-GPU form.  One context per device id (the same id may
+// repeat: that is how the single-GPU test box runs it), one BlockedGP per member, one worker thread per member for the
+// duration of an API call, and a communicator that needs no library: collectives are PEER COPIES ordered by events — a rank
+// publishes its buffer and a "ready" event, the readers make their stream wait for it and copy straight from the owner's
+// memory (hipMemcpyAsync device-to-device: one xGMI hop per pair, all pairs at once), then publish "done" events the owner's
+// stream waits for before it may touch the buffer again.  The host threads only rendezvous to exchange the handles.
+struct LocalGroup {
+    int n = 0;
+    std::vector<gpmi_ctx*> members;  // [0] = the primary
+    std::mutex mu;
+    std::condition_variable cv;
+    int waiting = 0;
+    uint64_t gen = 0;
+    bool aborted = false;
+    // slots published by the ranks, two sets used alternately (collective parity) so that a rank still reading the slots of
+    // collective i cannot race a fast rank publishing collective i + 1
+    std::vector<const void*> ptr[2];
+    std::vector<hipEvent_t> ready[2], done[2];
+    std::vector<double> hv[2];
+    bool barrier() {  // false: the group was aborted (a member failed outside a collective)
+        std::unique_lock<std::mutex> lk(mu);
+        if (aborted) return false;
+        const uint64_t g0 = gen;
+        if (++waiting == n) {
+            waiting = 0;
+            ++gen;
+            cv.notify_all();
+            return true;
+        }
+        cv.wait(lk, [&] { return gen != g0 || aborted; });
+        return !aborted;
+    }
+    void abort() {
+        std::lock_guard<std::mutex> lk(mu);
+        aborted = true;
+        cv.notify_all();
+    }
+    void reset() {
+        std::lock_guard<std::mutex> lk(mu);
+        aborted = false;
+        waiting = 0;
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void sum_ranks_kernel(T* __restrict__ out, const T* __restrict__ parts, int64_t count, int world) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    T s = parts[i];
+    for (int q = 1; q < world; ++q) s += parts[(int64_t)q * count + i];  // fixed order: bit-identical on every rank
+    out[i] = s;
+}
+
+struct LocalComm : Comm {
+    LocalGroup* g;
+    gpmi_ctx* c;
+    std::vector<hipEvent_t> pool;
+    size_t next = 0;
+    uint64_t seq = 0;  // collectives issued so far (parity selects the slot set; every rank issues the same sequence)
+    void* red = nullptr;
+    int64_t red_cap = 0;
+    LocalComm(LocalGroup* grp, gpmi_ctx* ctx, int r) : g(grp), c(ctx) {
+        rank = r;
+        world = grp->n;
+    }
+    ~LocalComm() override {
+        (void)hipSetDevice(c->device);
+        for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+        if (red) (void)hipFree(red);
+    }
+    hipEvent_t event() {
+        if (pool.size() < 64) {
+            hipEvent_t e;
+            (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            pool.push_back(e);
+            return e;
+        }
+        return pool[next++ % pool.size()];
+    }
+    // every rank reads `bytes` from each published pointer in `from` (rank index -> destination), then the owners wait for the readers
+    int exchange(const void* mine, void* stream, int64_t bytes, int root /* -1: all-gather */, void* dst_base) {
+        hipStream_t s = (hipStream_t)stream;
+        const int par = (int)(seq++ & 1);
+        hipEvent_t rdy = event();
+        if (hipEventRecord(rdy, s) != hipSuccess) return 1;
+        g->ptr[par][rank] = mine;
+        g->ready[par][rank] = rdy;
+        if (!g->barrier()) return 2;
+        for (int q = 0; q < world; ++q) {
+            if (root >= 0 && q != root) continue;
+            char* dst = (char*)dst_base + (root >= 0 ? 0 : (int64_t)q * bytes);
+            if (q == rank) {
+                if (root < 0 && dst != mine && hipMemcpyAsync(dst, mine, (size_t)bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
+                continue;
+            }
+            if (hipStreamWaitEvent(s, g->ready[par][q], 0) != hipSuccess) return 1;
+            if (hipMemcpyAsync(dst, g->ptr[par][q], (size_t)bytes, hipMemcpyDefault, s) != hipSuccess) return 1;
+        }
+        hipEvent_t dn = event();
+        if (hipEventRecord(dn, s) != hipSuccess) return 1;
+        g->done[par][rank] = dn;
+        if (!g->barrier()) return 2;
+        for (int q = 0; q < world; ++q)  // my buffer may change only after everyone who reads it has
+            if (q != rank && (root < 0 || rank == root))
+                if (hipStreamWaitEvent(s, g->done[par][q], 0) != hipSuccess) return 1;
+        return 0;
+    }
+    int broadcast(void* buf, int64_t bytes, int root, void* stream) override { return exchange(buf, stream, bytes, root, buf); }
+    int all_gather(const void* send, void* recv, int64_t bytes_each, void* stream) override { return exchange(send, stream, bytes_each, -1, recv); }
+    int all_reduce_sum(void* buf, int64_t count, int es, void* stream) override {
+        const int64_t need = (int64_t)world * count * es;
+        if (red_cap < need) {
+            (void)hipStreamSynchronize((hipStream_t)stream);
+            if (red) (void)hipFree(red);
+            red = nullptr;
+            red_cap = 0;
+            if (hipMalloc(&red, (size_t)need) != hipSuccess) return 1;
+            red_cap = need;
+        }
+        const int rc = exchange(buf, stream, count * es, -1, red);
+        if (rc) return rc;
+        const unsigned blocks = (unsigned)((count + 255) / 256);
+        if (es == 8)
+            hipLaunchKernelGGL(sum_ranks_kernel<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (double*)buf, (const double*)red, count, world);
+        else
+            hipLaunchKernelGGL(sum_ranks_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)buf, (const float*)red, count, world);
+        return 0;
+    }
+    int host_allreduce(double* vals, int n, int op) override {
+        if (n > 64) return 1;
+        const int par = (int)(seq++ & 1);
+        for (int i = 0; i < n; ++i) g->hv[par][(size_t)rank * 64 + i] = vals[i];
+        if (!g->barrier()) return 2;
+        for (int i = 0; i < n; ++i) {
+            double a = g->hv[par][i];
+            for (int q = 1; q < world; ++q) {
+                const double b = g->hv[par][(size_t)q * 64 + i];
+                a = op == 0 ? a + b : (op == 1 ? (b < a ? b : a) : (b > a ? b : a));
+            }
+            vals[i] = a;
+        }
+        return g->barrier() ? 0 : 2;
+    }
+};
+
+struct GroupHandle {
+    LocalGroup* g = nullptr;
+    std::vector<std::unique_ptr<LocalComm>> comms;
+    std::vector<std::unique_ptr<BlockedHandle>> ranks;
+};
+
+BlockedGP* blocked_of(gpmi_gp* gp) {
+    if (gp && gp->group) return ((GroupHandle*)gp->group)->ranks[0]->gp.get();
+    return gp && gp->blocked ? ((BlockedHandle*)gp->blocked)->gp.get() : nullptr;
+}
+
+int group_create(gpmi_ctx* primary, int n, const int* ids) {
+    LocalGroup* g = new LocalGroup();
+    g->n = n;
+    g->members.assign((size_t)n, nullptr);
+    g->members[0] = primary;
+    primary->group = g;
+    primary->group_rank = 0;
+    for (int r = 1; r < n; ++r) {
+        gpmi_ctx* m = nullptr;
+        const int rc = create_member_context(ids[r], &m);
+        if (rc != GPMI_OK) {
+            primary->err = "gpmi_ctx_create: could not create the context of device " + std::to_string(ids[r]);
+            return rc;  // the caller destroys the primary, which takes the members made so far with it
+        }
+        m->group = g;
+        m->group_rank = r;
+        g->members[(size_t)r] = m;
+    }
+    for (int par = 0; par < 2; ++par) {
+        g->ptr[par].assign((size_t)n, nullptr);
+        g->ready[par].assign((size_t)n, nullptr);
+        g->done[par].assign((size_t)n, nullptr);
+        g->hv[par].assign((size_t)n * 64, 0.0);
+    }
+    // direct peer copies between distinct devices (errors are not fatal: the runtime then stages through the host)
+    for (int a = 0; a < n; ++a)
+        for (int b = 0; b < n; ++b)
+            if (ids[a] != ids[b]) {
+                (void)hipSetDevice(ids[a]);
+                if (hipDeviceEnablePeerAccess(ids[b], 0) != hipSuccess) (void)hipGetLastError();
+            }
+    (void)hipSetDevice(primary->device);
+    return GPMI_OK;
+}
+
+void group_destroy(gpmi_ctx* primary) {
+    LocalGroup* g = (LocalGroup*)primary->group;
+    if (!g) return;
+    for (size_t r = 1; r < g->members.size(); ++r)
+        if (g->members[r]) {
+            g->members[r]->group = nullptr;
+            gpmi_ctx_destroy(g->members[r]);
+        }
+    primary->group = nullptr;
+    delete g;
+}
+
+// run f(rank) on one thread per member (rank 0 on the caller's); a member that fails outside a collective aborts the group's
+// rendezvous so that nobody waits for it.  Returns rank 0's status unless another member failed harder.
+template <typename F>
+static int group_run(GroupHandle* h, F f) {
+    LocalGroup* g = h->g;
+    g->reset();
+    std::vector<int> rc((size_t)g->n, GPMI_OK);
+    auto body = [&](int r) {
+        (void)hipSetDevice(g->members[(size_t)r]->device);
+        rc[(size_t)r] = f(r);
+        if (rc[(size_t)r] == GPMI_EDEVICE || rc[(size_t)r] == GPMI_EARG) g->abort();
+    };
+    std::vector<std::thread> th;
+    for (int r = 1; r < g->n; ++r) th.emplace_back(body, r);
+    body(0);
+    for (auto& t : th) t.join();
+    (void)hipSetDevice(g->members[0]->device);
+    int out = rc[0];
+    for (int r = 1; r < g->n; ++r)
+        if (rc[(size_t)r] > out || (out == GPMI_OK && rc[(size_t)r] != GPMI_OK)) {
+            out = rc[(size_t)r];
+            g->members[0]->err = h->ranks[(size_t)r]->gp->error();
+        }
+    if (rc[0] != GPMI_OK && out == rc[0]) g->members[0]->err = h->ranks[0]->gp->error();
+    return out;
+}
+
+int group_gp_create(gpmi_ctx* primary, int dtype, int d, int64_t n, const void* x, int64_t block_rows, int stripe_blocks, gpmi_gp** out) {
+    LocalGroup* g = (LocalGroup*)primary->group;
+    std::unique_ptr<GroupHandle> h(new GroupHandle());
+    h->g = g;
+    BlockedOpts o;
+    o.block = block_rows;
+    o.stripe_blocks = stripe_blocks;
+    for (int r = 0; r < g->n; ++r) {
+        gpmi_ctx* m = g->members[(size_t)r];
+        h->comms.emplace_back(new LocalComm(g, m, r));
+        std::unique_ptr<BlockedHandle> b(new BlockedHandle());
+        if (dtype == 64)
+            b->dev.reset(new HipDev<double>(m));
+        else
+            b->dev.reset(new HipDev<float>(m));
+        b->gp.reset(new BlockedGP(b->dev.get(), h->comms.back().get(), d, n, o));
+        h->ranks.push_back(std::move(b));
+    }
+    const int rc = group_run(h.get(), [&](int r) { return h->ranks[(size_t)r]->gp->init(x); });
+    if (rc != GPMI_OK) return rc;
+    gpmi_gp* gp = new gpmi_gp();
+    gp->ctx = primary;
+    gp->dtype = dtype;
+    gp->d = d;
+    gp->n = n;
+    gp->group = h.release();
+    *out = gp;
+    return GPMI_OK;
+}
+
+void group_gp_destroy(gpmi_gp* gp) {
+    GroupHandle* h = (GroupHandle*)gp->group;
+    if (!h) return;
+    for (size_t r = 0; r < h->ranks.size(); ++r) {
+        (void)hipSetDevice(h->g->members[r]->device);
+        h->ranks[r].reset();
+    }
+    h->comms.clear();
+    (void)hipSetDevice(h->g->members[0]->device);
+    delete h;
+    gp->group = nullptr;
+}
+
+int group_fit(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int64_t n_noise, const void* ymu, double* mll_out, void* alpha_out,
+              int64_t* info_out) {
+    GroupHandle* h = (GroupHandle*)gp->group;
+    std::vector<int64_t> info((size_t)h->g->n, 0);
+    std::vector<double> mll((size_t)h->g->n, 0.0);
+    const int rc = group_run(h, [&](int r) {
+        return h->ranks[(size_t)r]->gp->fit(k, log_noise, n_noise, ymu, &mll[(size_t)r], r == 0 ? alpha_out : nullptr, &info[(size_t)r]);
+    });
+    if (info_out) *info_out = info[0];
+    if (rc == GPMI_OK && mll_out) *mll_out = mll[0];
+    return rc;
+}
+int group_predict(gpmi_gp* gp, const gpmi_kernel* k, int64_t p, const void* xpred, const void* mean_pred, int full_cov, void* mu_out, void* var_out) {
+    GroupHandle* h = (GroupHandle*)gp->group;
+    const size_t es = gp->dtype == 64 ? 8 : 4;
+    // every rank produces the (replicated) results; the members other than rank 0 write into scratch
+    std::vector<std::vector<char>> mu((size_t)h->g->n), var((size_t)h->g->n);
+    for (int r = 1; r < h->g->n; ++r) {
+        mu[(size_t)r].resize((size_t)p * es);
+        var[(size_t)r].resize((size_t)(full_cov ? p * p : p) * es);
+    }
+    return group_run(h, [&](int r) {
+        return h->ranks[(size_t)r]->gp->predict(k, p, xpred, mean_pred, full_cov, r == 0 ? mu_out : (void*)mu[(size_t)r].data(),
+                                                r == 0 ? var_out : (void*)var[(size_t)r].data());
+    });
+}
+int group_grad(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int64_t n_noise, double* dkern_out, int n_kern, double* dnoise_out) {
+    GroupHandle* h = (GroupHandle*)gp->group;
+    std::vector<std::vector<double>> dk((size_t)h->g->n, std::vector<double>((size_t)std::max(n_kern, 1)));
+    std::vector<double> dn((size_t)h->g->n, 0.0);
+    const int rc = group_run(h, [&](int r) {
+        return h->ranks[(size_t)r]->gp->grad(k, log_noise, n_noise, r == 0 ? dkern_out : dk[(size_t)r].data(), n_kern,
+                                             dnoise_out ? (r == 0 ? dnoise_out : &dn[(size_t)r]) : nullptr);
+    });
+    return rc;
+}
+int group_factor_diag(gpmi_gp* gp, void* out) {
+    GroupHandle* h = (GroupHandle*)gp->group;
+    const size_t es = gp->dtype == 64 ? 8 : 4;
+    std::vector<std::vector<char>> tmp((size_t)h->g->n);
+    for (int r = 1; r < h->g->n; ++r) tmp[(size_t)r].resize((size_t)gp->n * es);
+    return group_run(h, [&](int r) { return h->ranks[(size_t)r]->gp->factor_diag(r == 0 ? out : (void*)tmp[(size_t)r].data()); });
+}
 
 }  // namespace gpmi
 
@@ -535,6 +855,13 @@ int gpmi_gp_create_blocked(gpmi_ctx* c, gpmi_comm* comm, int dtype, int d, int64
     }
     *out = nullptr;
     GPMI_HIP(c, hipSetDevice(c->device));
+    if (c->group && !comm) {  // a device group: one BlockedGP per member, joined by the in-process communicator
+        if (c->group_rank != 0) {
+            c->err = "gpmi_gp_create_blocked: pass the group's primary context";
+            return GPMI_EARG;
+        }
+        return group_gp_create(c, dtype, d, n, x, block_rows, stripe_blocks, out);
+    }
     std::unique_ptr<BlockedHandle> h(new BlockedHandle());
     if (dtype == 64)
         h->dev.reset(new HipDev<double>(c));

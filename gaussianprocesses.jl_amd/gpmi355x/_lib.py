@@ -144,17 +144,22 @@ class Context:
 
     _default = {}
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, devices=None):
+        """devices=[i, j, ...]: an in-process DEVICE GROUP (gpmi_ctx_create with n_devices > 1): blocked models created on it
+        (gpmi355x.dist.ShardedGPE(..., ctx=ctx) / GP(..., packed=True, ctx=ctx)) are row-block sharded over those devices by
+        one worker thread each, joined by peer copies — no launcher, no process group.  Everything else runs on devices[0]."""
         lib = load()
         h = C.c_void_p()
-        ids = (C.c_int * 1)(int(device))
-        rc = lib.gpmi_ctx_create(1, ids, C.byref(h))
+        devs = [int(device)] if devices is None else [int(v) for v in devices]
+        ids = (C.c_int * len(devs))(*devs)
+        rc = lib.gpmi_ctx_create(len(devs), ids, C.byref(h))
         if rc != GPMI_OK:
             raise DeviceError(
-                f"gpmi_ctx_create failed (rc={rc}): no usable gfx950 device {device}. "
+                f"gpmi_ctx_create failed (rc={rc}): no usable gfx950 device(s) {devs}. "
                 "libgpmi has no CPU backend by design.")
         self.h = h
-        self.device = int(device)
+        self.device = devs[0]
+        self.devices = devs
 
     @classmethod
     def default(cls, device=None):

@@ -11,7 +11,9 @@ What this module supplies is the communicator (one process per GPU, every rank m
                             whatever group the launcher already has (torch.distributed here: any backend)
     TorchDistComm(group)    collectives delegated to torch.distributed through gpmi_comm_callbacks: backend "nccl" is RCCL,
                             "gloo" works on device buffers too (two processes on one GPU in tests/test_gpu_dist.py)
-and `comm=None` = one rank (packed storage on a single device: SURVEY §8f-3).
+and `comm=None` = one rank (packed storage on a single device: SURVEY §8f-3) — or, on a context made with
+`Context(devices=[...])`, one rank per device of that in-process group (worker threads + peer copies inside libgpmi: the
+single-process multi-GPU form of SURVEY §8(b)'s `gpmi_ctx_create(n_devices 1..8)`).
 """
 from __future__ import annotations
 
@@ -241,8 +243,9 @@ class ShardedGPE(GPE):
 
     @property
     def nown(self):
+        """blocks this rank owns (an in-process device group reports its rank 0)"""
         c = self._blocked["comm"]
-        r, g = (c.rank, c.world) if c is not None else (0, 1)
+        r, g = (c.rank, c.world) if c is not None else (0, len(getattr(self.ctx, "devices", [0])))
         return len(range(r, self.nblk, g))
 
     @property

@@ -32,12 +32,17 @@ function check(ctx::Ptr{Cvoid}, rc::Cint, info::Integer=0)
     error("libgpmi: $msg")
 end
 
+# ENV["GPMI_DEVICE"] = "3"           one GPU (default 0)
+# ENV["GPMI_DEVICES"] = "0,1,2,3"      an in-process DEVICE GROUP (gpmi_ctx_create with n_devices > 1): blocked models —
+#                                      HIPCovariance(sharded=true) / (packed=true) — are row-block sharded over these GPUs by
+#                                      worker threads inside libgpmi; this one Julia session drives them all, no MPI
 const CTX = Ref{Ptr{Cvoid}}(C_NULL)
 function context()
     if CTX[] == C_NULL
         h = Ref{Ptr{Cvoid}}(C_NULL)
-        dev = Ref{Cint}(parse(Cint, get(ENV, "GPMI_DEVICE", "0")))
-        rc = ccall((:gpmi_ctx_create, libgpmi), Cint, (Cint, Ptr{Cint}, Ptr{Ptr{Cvoid}}), 1, dev, h)
+        devs = haskey(ENV, "GPMI_DEVICES") ? Cint[parse(Cint, v) for v in split(ENV["GPMI_DEVICES"], ",")] :
+                                             Cint[parse(Cint, get(ENV, "GPMI_DEVICE", "0"))]
+        rc = ccall((:gpmi_ctx_create, libgpmi), Cint, (Cint, Ptr{Cint}, Ptr{Ptr{Cvoid}}), length(devs), devs, h)
         rc == 0 || error("libgpmi: no usable MI355X (gpmi_ctx_create rc=$rc); there is no CPU backend")
         CTX[] = h[]
     end
@@ -89,6 +94,8 @@ withkernel(f, kd::KernelDesc) = GC.@preserve kd f(Ref(CKernel(length(kd.ops), po
 # HIPCovariance()                      the dense device path: ONE n x n factor buffer (gpmi_gp_create)
 # HIPCovariance(packed=true)           a BLOCKED handle on one device (gpmi_gp_create_blocked): block-rows in stripes that stop
 #                                      at their own diagonal — no upper triangle, N = 250 000 in fp64 on 288 GB
+# HIPCovariance(sharded=true)          with ENV["GPMI_DEVICES"] = "0,1,...": the factor row-block sharded over the GPUs of an in-process
+#                                      device group — one Julia session, worker threads and peer copies inside libgpmi
 # HIPCovariance(comm=rccl_comm(...))   the factor row-block sharded over the ranks of a communicator: one Julia process per GPU
 #                                      (MPI.jl / Distributed launch), every rank runs the same script on the same data and gets the
 #                                      same mll / alpha / predictions / gradient back
@@ -96,13 +103,14 @@ withkernel(f, kd::KernelDesc) = GC.@preserve kd f(Ref(CKernel(length(kd.ops), po
 # Matrix(cK) are dense-only (libgpmi returns GPMI_EARG -> ArgumentError on a blocked handle).
 struct HIPCovariance <: CovarianceStrategy
     packed::Bool
+    sharded::Bool         # a blocked handle without packing: on a device-group context (GPMI_DEVICES) one rank per GPU
     block::Int            # rows per block (0: library default — 1024 from 32 768 points)
     stripe_blocks::Int    # local blocks per storage stripe (packed)
     comm::Ptr{Cvoid}      # gpmi_comm* or C_NULL
 end
-HIPCovariance(; packed::Bool=false, block::Integer=0, stripe_blocks::Integer=8, comm::Ptr{Cvoid}=C_NULL) =
-    HIPCovariance(packed, block, packed ? stripe_blocks : 0, comm)
-blocked(s::HIPCovariance) = s.packed || s.comm != C_NULL
+HIPCovariance(; packed::Bool=false, sharded::Bool=false, block::Integer=0, stripe_blocks::Integer=8, comm::Ptr{Cvoid}=C_NULL) =
+    HIPCovariance(packed, sharded, block, packed ? stripe_blocks : 0, comm)
+blocked(s::HIPCovariance) = s.packed || s.sharded || s.comm != C_NULL
 
 # libgpmi's own RCCL communicator (librccl opened at run time).  `exchange(id::Union{Vector{UInt8},Nothing}) -> Vector{UInt8}` moves the
 # 128-byte unique id from rank 0 to every rank (MPI.bcast, a shared file, Distributed.remotecall_fetch ...).

@@ -87,9 +87,13 @@ typedef struct gpmi_ctx gpmi_ctx; /* one per process: device(s), streams, error 
 typedef struct gpmi_gp gpmi_gp;   /* one per GPE: resident x, factor, alpha          */
 
 /* ---- context ---------------------------------------------------------- */
-/* n_devices == 1: one process drives one GPU; a multi-GPU model is one process per GPU, each with
- * its own context, joined by a communicator (gpmi_comm_*, gpmi_gp_create_blocked below).
- * device_ids may be NULL (-> device 0).                                                        */
+/* n_devices == 1: one GPU (device_ids may be NULL -> device 0).
+ * n_devices  > 1: an in-process DEVICE GROUP — one context per entry of device_ids (an id may repeat), joined by an
+ * in-process communicator (peer copies ordered by events: no library, no launcher).  gpmi_gp_create_blocked(ctx, NULL, ...)
+ * on such a context shards the model row-block-wise over the group's devices and runs one worker thread per member inside
+ * every gpmi_fit / gpmi_predict / gpmi_grad on it; every other entry point runs on device_ids[0].  This is the
+ * single-process multi-GPU form (a Julia session driving all the GPUs of a node); the one-process-per-GPU form is a
+ * communicator (gpmi_comm_*) on single-device contexts.                                                              */
 int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out);
 void gpmi_ctx_destroy(gpmi_ctx*);
 const char* gpmi_last_error(gpmi_ctx*);
@@ -167,7 +171,8 @@ int gpmi_fitc_grad(gpmi_fitc*, const gpmi_kernel*, double log_noise, double* dke
  *     arguments and receives the same results: mll, alpha, mu, var, gradient are replicated), and
  *   - per rank, in stripes of stripe_blocks local blocks that stop at their own diagonal (0: one stripe = full rows), so the
  *     upper triangle is never allocated: N^2 (1 + 1/S) / 2 elements instead of alloc_cK's two N x N (src/GP.jl:14-20).
- * comm == NULL: one rank (a single device past the N x N ceiling: N = 250 000 fp64 on 288 GB).  gpmi_grad on a blocked
+ * comm == NULL: one rank (a single device past the N x N ceiling: N = 250 000 fp64 on 288 GB) — or, when ctx is a device
+ * group (gpmi_ctx_create with n_devices > 1), one rank per device of the group.  gpmi_grad on a blocked
  * handle needs ONE more own-rows x N matrix (N^2 / world) instead of two N x N.  gpmi_solve / gpmi_whiten / gpmi_inv_diag /
  * gpmi_factor_to_host are not provided on a blocked handle (GPMI_EARG).                                                  */
 typedef struct gpmi_comm gpmi_comm;

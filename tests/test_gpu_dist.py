@@ -136,6 +136,43 @@ def test_virtual_ranks_on_one_gpu(world, n, block, per):
     assert all(logs[r] == logs[0] for r in range(1, world))
 
 
+@pytest.mark.parametrize("devs,n,block,per", [([0, 0], 1000, None, 0), ([0, 0, 0], 1793, None, 0), ([0, 0], 3000, 256, 2), ([0, 0, 0, 0], 5200, 512, 0)])
+def test_in_process_device_group(devs, n, block, per):
+    """gpmi_ctx_create(n_devices > 1): the single-process multi-GPU form.  On the one GPU of the test box the group's
+    members all sit on device 0: worker threads, the in-process communicator (peer copies ordered by events) and the sharded
+    driver are exercised end to end through the plain GPE verbs, gradient and full_cov included."""
+    x, y, xs = _problem(n)
+    ln = math.log(0.1)
+    ctx = g.Context(devices=devs)
+    gp = gd.ShardedGPE(x, y, g.MeanConst(0.1), g.from_spec(SPEC), ln, ctx=ctx, block=block, stripe_blocks=per)
+    assert gp.nown == len(range(0, gp.nblk, len(devs)))
+    _check(gp, x, y, xs, ln, ("const", 0.1), grad=True)
+    hyp = gp.get_params()
+    gp.set_params([h + 0.03 for h in hyp])
+    gp.update_mll()
+    dense = g.GP(x, y, g.MeanConst(0.1), g.from_spec(SPEC), ln)
+    dense.set_params([h + 0.03 for h in hyp])
+    dense.update_mll()
+    assert gp.mll == pytest.approx(dense.mll, rel=1e-10)
+    del gp
+    ctx.close()
+
+
+def test_in_process_device_group_not_posdef_and_reuse():
+    n = 700
+    x = np.zeros((4, n))
+    x[0] = np.arange(n)
+    x[:, 300] = x[:, 5]
+    ctx = g.Context(devices=[0, 0])
+    with pytest.raises(g.PosDefException) as ei:
+        gd.ShardedGPE(x, np.ones(n), g.MeanZero(), g.SEIso(-3.0, 0.0), -400.0, ctx=ctx)
+    assert ei.value.info == 301
+    # the group stays usable
+    x2, y2, xs2 = _problem(900)
+    gp = gd.ShardedGPE(x2, y2, g.MeanZero(), g.from_spec(SPEC), math.log(0.1), ctx=ctx)
+    _check(gp, x2, y2, xs2, math.log(0.1), ("zero",))
+
+
 def test_virtual_ranks_not_posdef():
     n = 700
     x = np.zeros((4, n))
