@@ -182,10 +182,9 @@ def run_workload(g, ctx, n, d, p, dtype, steps, warmup, barrier, comm=None, shar
     blocked code path on one rank)."""
     import gc
 
-    import torch
-
     gc.collect()
-    torch.cuda.empty_cache()
+    if "torch" in sys.modules:
+        sys.modules["torch"].cuda.empty_cache()
     np_dt = np.float64 if dtype == "f64" else np.float32
     x, y, xpred = synthetic_inputs(n, d, p)
     ll = _ll(d)
@@ -209,9 +208,25 @@ def run_workload(g, ctx, n, d, p, dtype, steps, warmup, barrier, comm=None, shar
         gp.update_mll()
         return gp.predict_f(xpred)
 
+    # Instrumentation inside the timed region (profiles/r03_n_instrumentation.log).  The roofline kernel's launches always carry HIP
+    # events (attached to the dispatch: hipExtLaunchKernelGGL start / stop events).  Marker events around EVERY other profiled launch —
+    # thousands per fit for the chain kernels — cost 4 ms of a 69 ms step at N = 20 000, so the stage times are taken over the warm-up
+    # steps and the timed steps bracket the roofline kernel only.  One measured exception: in the free-slot look-ahead mode (factorisations
+    # of >= 32 768 rows) events on the update alone cost MORE than events everywhere (N = 50 000 fit: none 652, everywhere 657, update
+    # only 665 ms — the markers on the side stream's chain kernels evidently help the chain along once the update's dispatch carries a
+    # completion signal), so those workloads keep every class bracketed, as in rounds 1 and 2.
+    syrk_only = (not sharded) and n < 32768
+    stage = None
+    if warmup > 0:
+        ctx.profile_enable(True)
     for i in range(warmup):
         step(i)
-    ctx.profile_enable(True)
+    if warmup > 0:
+        stage = {name: ctx.profile_get(getattr(g._lib, "PROF_" + name)) for name in ("SYRK", "COV", "PANEL", "SOLVE", "PREDICT")}
+    if syrk_only:
+        ctx.profile_enable(True, only=g._lib.PROF_SYRK)
+    else:
+        ctx.profile_enable(True)
     barrier()
     t0 = time.perf_counter()
     for i in range(steps):
@@ -219,8 +234,10 @@ def run_workload(g, ctx, n, d, p, dtype, steps, warmup, barrier, comm=None, shar
     barrier()
     elapsed = time.perf_counter() - t0
     syrk_bytes = ctx.profile_get_bytes(g._lib.PROF_SYRK)
-    prof = {name: ctx.profile_get(getattr(g._lib, "PROF_" + name)) for name in ("SYRK", "COV", "PANEL", "SOLVE", "PREDICT")}
+    prof = {"SYRK": ctx.profile_get(g._lib.PROF_SYRK)}
     ctx.profile_enable(False)
+    prof["stage"] = stage
+    prof["stage_steps"] = warmup
     assert np.all(np.isfinite(mu)) and np.all(np.isfinite(s2)) and math.isfinite(gp.mll)
     return {"elapsed": elapsed, "prof": prof, "syrk_bytes": syrk_bytes, "t_build": t_build, "mll": gp.mll, "ll": ll,
             "base_mll": base_mll, "base_mu": np.asarray(base_mu, dtype=np.float64), "base_s2": np.asarray(base_s2, dtype=np.float64)}
@@ -248,7 +265,10 @@ def roofline_object(args, res, n, d, p, dtype, steps):
 
 
 def stage_object(res, steps):
-    pr = res["prof"]
+    pr = res["prof"].get("stage")
+    steps = res["prof"].get("stage_steps", 0)
+    if not pr or steps <= 0:
+        return {"note": "no warm-up steps: stage times not taken"}
     return {
         "cov": pr["COV"][1] / steps,
         "cov_GBps": (pr["COV"][2] / max(pr["COV"][1], 1e-9)) * 1e-6,
@@ -256,8 +276,8 @@ def stage_object(res, steps):
         "panel_potf2_trsm_update": pr["PANEL"][1] / steps,
         "alpha_solve_mll": pr["SOLVE"][1] / steps,
         "predict": pr["PREDICT"][1] / steps,
-        "note": "per-class sums of HIP-event intervals; the panel chain runs on a side stream UNDER the trailing update "
-                "(look-ahead), so the classes overlap and do not add up to ms_per_step",
+        "note": "per-class sums of HIP-event intervals over the WARM-UP steps; the panel chain runs on a side stream UNDER the trailing "
+                "update (look-ahead), so the classes overlap and do not add up to ms_per_step",
     }
 
 
@@ -304,7 +324,7 @@ def run_c3(g, ctx, steps=3):
     gp = g.GP(x, y, g.MeanZero(), g.from_spec(spec), math.log(0.1), ctx=ctx)
     base = np.asarray(gp.get_params())
     mll0 = gp.mll
-    ctx.profile_enable(True)
+    ctx.profile_enable(True, only=g._lib.PROF_COV)
     t0 = time.perf_counter()
     for i in range(steps):
         gp.set_params(base + 1e-3 * (i + 1) * np.where(np.arange(len(base)) == 0, 0.0, 1.0))
@@ -429,19 +449,23 @@ def main():
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         raise SystemExit(subprocess.call(cmd, env=env))
 
-    import torch
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(world_env or "1")
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a MI355X: no GPU visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dist = None
+    dist = torch = None
     if world > 1:
+        # one rank per GPU: torch.distributed is the launcher's rendezvous, barrier and max-over-ranks (imported BEFORE libgpmi so that
+        # the two share one HIP runtime).  The single-GPU process does not load torch at all: libgpmi then runs on ROCm's own HIP
+        # runtime instead of the older one bundled in the torch wheel (measured: N = 20 000 68.5 instead of 73.4 ms per step), and the
+        # bracket around the timed region is gpmi_ctx_synchronize (hipDeviceSynchronize) in place of torch.cuda.synchronize().
+        import torch
         import torch.distributed as dist
+
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a MI355X: no GPU visible (there is no CPU fallback)")
+        torch.cuda.set_device(local_rank)
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
@@ -454,12 +478,16 @@ def main():
     mode = args.mode or ("sharded" if world > 1 else "single")
     sharded = mode == "sharded"
     n, d, p = args.n, args.d, args.p
-    ctx = g.Context.default(local_rank)
+    try:
+        ctx = g.Context.default(local_rank)
+    except g._lib.DeviceError as e:
+        raise SystemExit(f"bench.py needs a MI355X: {e} (there is no CPU fallback)")
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
+        ctx.synchronize()
 
     _comm = []
 

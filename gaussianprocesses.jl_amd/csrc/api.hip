@@ -161,20 +161,34 @@ static hipEvent_t take_event(gpmi_ctx* c) {
     hipEventCreate(&e);
     return e;
 }
-ProfScope::ProfScope(gpmi_ctx* ctx, int cls, double work, double bytes) : c(ctx) {
-    if (!c->prof_on) return;
+ProfScope::ProfScope(gpmi_ctx* ctx, int cls, double work, double bytes, bool attach_to_launch, bool chain_kernel) : c(ctx), attach(attach_to_launch) {
+    if (!c->prof_on || (c->prof_only >= 0 && cls != c->prof_only) || (chain_kernel && c->prof_skip_chain)) return;
     ProfRec r;
     r.a = take_event(c);
     r.b = take_event(c);
     r.cls = cls;
     r.work = work;
     r.bytes = bytes;
-    hipEventRecord(r.a, c->stream);
+    if (attach) {  // the launch itself carries the two events (start / stop of the dispatch): nothing else enters the queue
+        c->attach_a = r.a;
+        c->attach_b = r.b;
+    } else {
+        hipEventRecord(r.a, c->stream);
+    }
     idx = (int)c->prof.size();
     c->prof.push_back(r);
 }
 ProfScope::~ProfScope() {
-    if (idx >= 0) hipEventRecord(c->prof[idx].b, c->stream);
+    if (idx < 0) return;
+    if (attach) {
+        if (c->attach_a) {  // nothing was launched (empty product): give the pair a zero-length interval
+            hipEventRecord(c->prof[idx].a, c->stream);
+            hipEventRecord(c->prof[idx].b, c->stream);
+            c->attach_a = c->attach_b = nullptr;
+        }
+        return;
+    }
+    hipEventRecord(c->prof[idx].b, c->stream);
 }
 
 static int drain_profile(gpmi_ctx* c) {
@@ -729,6 +743,16 @@ void gpmi_ctx_destroy(gpmi_ctx* c) {
 
 const char* gpmi_last_error(gpmi_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
+int gpmi_ctx_synchronize(gpmi_ctx* c) {
+    if (!c) return GPMI_EARG;
+    for (gpmi_ctx* m : group_members(c)) {
+        GPMI_HIP(c, hipSetDevice(m->device));
+        GPMI_HIP(c, hipDeviceSynchronize());
+    }
+    GPMI_HIP(c, hipSetDevice(c->device));
+    return GPMI_OK;
+}
+
 int gpmi_gp_create(gpmi_ctx* c, int dtype, int d, int64_t n, const void* x, gpmi_gp** out) {
     if (!c) return earg(c, "gpmi_gp_create: bad argument");
     if (!out || !x || (dtype != 64 && dtype != 32) || d <= 0 || d > MAX_D || n <= 0) {
@@ -975,6 +999,8 @@ int gpmi_profile_enable(gpmi_ctx* c, int on) {
     if (!c) return earg(c, "gpmi_profile_enable: bad argument");
     int rc = drain_profile(c);
     c->prof_on = on != 0;
+    c->prof_only = (on >= 2 && on < 64) ? on - 2 : -1;
+    c->prof_skip_chain = on == 64;
     for (int i = 0; i < GPMI_PROF_NCLASS; ++i) {
         c->prof_n[i] = 0;
         c->prof_ms[i] = 0;

@@ -140,6 +140,10 @@ struct gpmi_ctx {
     std::vector<hipEvent_t> la_events;
     size_t la_next = 0;   // cross-stream dependencies, reused by every factorisation
     bool prof_on = false;
+    int prof_only = -1;  // >= 0: bracket the launches of THIS class only (gpmi_profile_enable(ctx, 2 + cls))
+    bool prof_skip_chain = false;  // gpmi_profile_enable(ctx, 64): every class, but not the thousands of tiny chain kernels (diag64 / rows64 / rows256)
+    hipEvent_t attach_a = nullptr, attach_b = nullptr;  // events the NEXT update-kernel launch carries itself (hipExtLaunchKernelGGL): no
+                                                         // marker packets around the persistent kernel (gemm.hip, ProfScope attach mode)
     std::vector<gpmi::ProfRec> prof;
     std::vector<hipEvent_t> ev_pool;
     int64_t prof_n[GPMI_PROF_NCLASS] = {0};
@@ -204,6 +208,7 @@ void blocked_destroy(void* p);
 // ordered by events), one worker thread per member for the duration of a call (dev_hip.hip)
 int create_member_context(int dev, gpmi_ctx** out);
 int group_create(gpmi_ctx* primary, int n, const int* device_ids);
+std::vector<gpmi_ctx*> group_members(gpmi_ctx* c);  // the members of c's device group, or {c}
 void group_destroy(gpmi_ctx* primary);
 int group_gp_create(gpmi_ctx* primary, int dtype, int d, int64_t n, const void* x, int64_t block_rows, int stripe_blocks, gpmi_gp** out);
 void group_gp_destroy(gpmi_gp* gp);
@@ -230,7 +235,8 @@ int set_lookahead_mode(gpmi_ctx* c, bool whole_cus);
 struct ProfScope {
     gpmi_ctx* c;
     int idx = -1;
-    ProfScope(gpmi_ctx* ctx, int cls, double work, double bytes = 0.0);
+    bool attach = false;  // the events ride on the kernel dispatch itself (ctx->attach_a / _b) instead of marker packets around it
+    ProfScope(gpmi_ctx* ctx, int cls, double work, double bytes = 0.0, bool attach_to_launch = false, bool chain_kernel = false);
     ~ProfScope();
 };
 

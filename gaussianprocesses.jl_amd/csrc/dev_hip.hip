@@ -586,6 +586,11 @@ int group_create(gpmi_ctx* primary, int n, const int* ids) {
     return GPMI_OK;
 }
 
+std::vector<gpmi_ctx*> group_members(gpmi_ctx* c) {
+    if (c->group) return ((LocalGroup*)c->group)->members;
+    return {c};
+}
+
 void group_destroy(gpmi_ctx* primary) {
     LocalGroup* g = (LocalGroup*)primary->group;
     if (!g) return;

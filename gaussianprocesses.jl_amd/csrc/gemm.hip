@@ -28,6 +28,8 @@
 #include <type_traits>
 #include <vector>
 
+#include <hip/hip_ext.h>
+
 #include "common.h"
 #include "mfma.h"
 #include "tile_order.h"
@@ -502,6 +504,13 @@ static void launch_persistent_ni(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, i
     static const bool no_pair16 = getenv("GPMI_GEMM_NO_PAIR16") != nullptr;  // tools: A/B of the C access width
     if (no_pair16) flags |= GEMM_NO_PAIR16;
 #endif
+    if (ctx->attach_a) {  // profiled launch: the dispatch carries its own start / stop events (ProfScope attach mode)
+        hipEvent_t ea = ctx->attach_a, eb = ctx->attach_b;
+        ctx->attach_a = ctx->attach_b = nullptr;
+        hipExtLaunchKernelGGL((gemm_nt_kernel<T, V, NI>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, ea, eb, 0, C, ldc, A, lda, B, ldb, M, N, K,
+                              shape, side ? ctx->d_queue_side : ctx->d_queue, qa, info, flags);
+        return;
+    }
     hipLaunchKernelGGL((gemm_nt_kernel<T, V, NI>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, C, ldc, A, lda, B, ldb, M, N,
                        K, shape, side ? ctx->d_queue_side : ctx->d_queue, qa, info, flags);
 }
@@ -557,7 +566,7 @@ void launch_gemm_shape(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda
     const bool b_in_a = B >= A && B < A + M * lda;
     const double abytes = sizeof(T) * ((flags & GEMM_OVERWRITE ? 1.0 : 2.0) * entries +
                                        ((double)M + (b_in_a ? 0.0 : (double)N)) * (double)K * (batch ? batch->count : 1));
-    ProfScope ps(ctx, trailing ? GPMI_PROF_SYRK : GPMI_PROF_PANEL, 2.0 * entries * (double)K, abytes);
+    ProfScope ps(ctx, trailing ? GPMI_PROF_SYRK : GPMI_PROF_PANEL, 2.0 * entries * (double)K, abytes, /*attach_to_launch=*/true);
     if (trailing)
         launch_persistent<T, 0>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags, batch, false);
     else

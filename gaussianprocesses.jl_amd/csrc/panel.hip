@@ -874,14 +874,14 @@ void launch_place_inv_blocks(gpmi_ctx* ctx, const T* l256, T* LW, T* LWT, int64_
 
 template <typename T>
 void launch_diag64(gpmi_ctx* ctx, T* A, int64_t ld, T* linv, T* invdiag, int* info, int64_t pivot_base) {
-    ProfScope ps(ctx, GPMI_PROF_PANEL, 2.0 * 64.0 * 64.0 * 64.0 / 3.0);
+    ProfScope ps(ctx, GPMI_PROF_PANEL, 2.0 * 64.0 * 64.0 * 64.0 / 3.0, 0.0, false, /*chain_kernel=*/true);
     hipLaunchKernelGGL(diag64_kernel<T>, dim3(1), dim3(256), 0, ctx->stream, A, ld, linv, invdiag, info, pivot_base);
 }
 template <typename T>
 void launch_rows64(gpmi_ctx* ctx, T* Xp, int64_t ldx, int64_t M, int K1, const T* Lp, int64_t ldl, const T* linv,
                    int64_t diag_rows, const int* info) {
     if (M <= 0) return;
-    ProfScope ps(ctx, GPMI_PROF_PANEL, 2.0 * (double)M * 64.0 * (double)(K1 + 64));
+    ProfScope ps(ctx, GPMI_PROF_PANEL, 2.0 * (double)M * 64.0 * (double)(K1 + 64), 0.0, false, /*chain_kernel=*/true);
     hipLaunchKernelGGL(rows64_kernel<T>, dim3((unsigned)side_cap(ctx, (M + 63) / 64)), dim3(256), 0, ctx->stream, Xp, ldx, M, K1, Lp, ldl,
                        linv, diag_rows, info, ctx->refine_solves ? 1 : 0);
 }
@@ -889,7 +889,7 @@ template <typename T>
 void launch_rows256(gpmi_ctx* ctx, T* Xp, int64_t ldx, int64_t M, int nsub, const T* Lp, int64_t ldl, const T* linv,
                     const int* info) {
     if (M <= 0) return;
-    ProfScope ps(ctx, GPMI_PROF_PANEL, 2.0 * (double)M * 64.0 * 64.0 * (double)(nsub * (nsub + 1) / 2));
+    ProfScope ps(ctx, GPMI_PROF_PANEL, 2.0 * (double)M * 64.0 * 64.0 * (double)(nsub * (nsub + 1) / 2), 0.0, false, /*chain_kernel=*/true);
     hipLaunchKernelGGL(rows256_kernel<T>, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, ctx->stream, Xp, ldx, M, nsub, Lp, ldl,
                        linv, info);
 }

@@ -19,7 +19,7 @@ PROF_SYRK, PROF_COV, PROF_PANEL, PROF_SOLVE, PROF_PREDICT = range(5)
 
 # every symbol include/gpmi.h declares (tests/test_abi.py checks header == this list == library)
 SYMBOLS = [
-    "gpmi_ctx_create", "gpmi_ctx_destroy", "gpmi_last_error", "gpmi_version",
+    "gpmi_ctx_create", "gpmi_ctx_destroy", "gpmi_ctx_synchronize", "gpmi_last_error", "gpmi_version",
     "gpmi_gp_create", "gpmi_gp_destroy", "gpmi_fit", "gpmi_predict", "gpmi_grad", "gpmi_cov",
     "gpmi_inv_diag", "gpmi_fitc_create", "gpmi_fitc_destroy", "gpmi_fitc_fit", "gpmi_fitc_predict", "gpmi_fitc_alpha_u", "gpmi_fitc_grad",
     "gpmi_solve", "gpmi_whiten", "gpmi_logdet", "gpmi_factor_to_host", "gpmi_factor_diag",
@@ -79,20 +79,20 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
-    # torch's wheel bundles its own libamdhip64: whichever HIP runtime is loaded SECOND in a process finds no GPU
-    # ("No HIP GPUs are available" from torch when libgpmi came first).  Importing torch first makes libgpmi.so resolve
-    # libamdhip64 to the one already loaded, so the sharded / packed paths (torch tensors, torch.distributed) can be used
-    # at any later point.  GPMI_NO_TORCH_PRELOAD=1 skips it for processes that never touch torch.
-    if not os.environ.get("GPMI_NO_TORCH_PRELOAD"):
+    # libgpmi needs no torch (round 3: the sharded / packed orchestration and the RCCL communicator live below the C ABI).  One
+    # thing to know when a host program uses BOTH: torch's wheel bundles its own libamdhip64, and whichever HIP runtime is loaded
+    # SECOND in a process finds no GPU.  If torch is already imported, libgpmi.so resolves libamdhip64 to the copy torch loaded and
+    # the two share one runtime; a program that imports gpmi355x first and torch later must import torch first instead
+    # (bench.py, tests/conftest.py and the communicators of gpmi355x.dist that wrap torch.distributed do).
+    import sys
+
+    if "torch" in sys.modules:
         try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
-        except Exception as e:  # noqa: BLE001  (a torch install that fails to load must not take libgpmi down with it)
+            import torch  # noqa: F401  (make sure its shared libraries are mapped before dlopen)
+        except Exception as e:  # noqa: BLE001
             import warnings
 
-            warnings.warn(f"gpmi355x: importing torch failed ({e!r}); libgpmi is loaded without it — the torch-hosted "
-                          "communicators of gpmi355x.dist will not be usable in this process")
+            warnings.warn(f"gpmi355x: torch is half-imported ({e!r}); loading libgpmi without sharing its HIP runtime")
     lib = C.CDLL(LIB_PATH)
     vp, i64, dbl = C.c_void_p, C.c_int64, C.c_double
     lib.gpmi_version.restype = C.c_char_p
@@ -101,6 +101,7 @@ def load():
     lib.gpmi_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
     lib.gpmi_ctx_destroy.argtypes = [vp]
     lib.gpmi_ctx_destroy.restype = None
+    lib.gpmi_ctx_synchronize.argtypes = [vp]
     lib.gpmi_gp_create.argtypes = [vp, C.c_int, C.c_int, i64, vp, C.POINTER(vp)]
     lib.gpmi_gp_destroy.argtypes = [vp]
     lib.gpmi_gp_destroy.restype = None
@@ -179,8 +180,15 @@ class Context:
             raise ArgumentError(msg)
         raise DeviceError(msg)
 
-    def profile_enable(self, on=True):
-        self.check(load().gpmi_profile_enable(self.h, 1 if on else 0))
+    def synchronize(self):
+        """waits for all work on the context's device(s): the bracket around a timed region"""
+        self.check(load().gpmi_ctx_synchronize(self.h))
+
+    def profile_enable(self, on=True, only=None, skip_chain=False):
+        """HIP-event brackets around the profiled launches: every class, one class (only=PROF_SYRK ...), or every class but the
+        thousands of tiny chain kernels (skip_chain)"""
+        code = 0 if not on else ((2 + int(only)) if only is not None else (64 if skip_chain else 1))
+        self.check(load().gpmi_profile_enable(self.h, code))
 
     def profile_get(self, cls_id):
         n, ms, work = C.c_int64(), C.c_double(), C.c_double()

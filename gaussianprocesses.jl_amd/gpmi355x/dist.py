@@ -69,6 +69,9 @@ class TorchDistComm(Comm):
         import torch
         import torch.distributed as dist
 
+        if not torch.cuda.is_available():
+            raise _lib.DeviceError("TorchDistComm: torch sees no GPU — import torch BEFORE gpmi355x so that the two share one HIP runtime")
+
         self.torch, self.dist, self.group = torch, dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.backend = dist.get_backend(group)

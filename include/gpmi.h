@@ -96,6 +96,9 @@ typedef struct gpmi_gp gpmi_gp;   /* one per GPE: resident x, factor, alpha     
  * communicator (gpmi_comm_*) on single-device contexts.                                                              */
 int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out);
 void gpmi_ctx_destroy(gpmi_ctx*);
+/* waits for ALL work on the context's device(s) (every entry point already returns with its results on the host; this is the
+ * explicit bracket a timing harness puts around a measured region: hipDeviceSynchronize)                                  */
+int gpmi_ctx_synchronize(gpmi_ctx*);
 const char* gpmi_last_error(gpmi_ctx*);
 const char* gpmi_version(void);
 
@@ -232,6 +235,8 @@ enum gpmi_prof_class {
     GPMI_PROF_PREDICT = 4,
     GPMI_PROF_NCLASS = 5
 };
+/* on = 0: off; 1: every class; 2 + cls: the launches of class cls ONLY (a few dozen event pairs per fit for GPMI_PROF_SYRK,
+ * against thousands for the panel kernels: what a timing harness leaves on inside its timed region).                       */
 int gpmi_profile_enable(gpmi_ctx*, int on);
 /* launches, total milliseconds and algorithmic work (flops for SYRK/PANEL/
  * PREDICT, bytes for COV/SOLVE) accumulated since the last call for `cls`.  */

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # torch FIRST: its wheel bundles a HIP runtime, and the second runtime loaded in a process sees no GPU (gpmi355x/_lib.py);
+    import torch  # noqa: F401  the GPU suites use torch for the test-side communicators and independent reference products
+except Exception:  # noqa: BLE001
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "gaussianprocesses.jl_amd")
 for p in (ROOT, PKG):
