@@ -203,10 +203,17 @@ def run_workload(g, ctx, n, d, p, dtype, steps, warmup, barrier, comm=None, shar
     base_mll = gp.mll
     base_mu, base_s2 = gp.predict_f(xpred)
 
+    wall = {"fit": 0.0, "predict": 0.0}
+
     def step(i):
         gp.set_params(base + 1e-3 * ((i % 7) + 1) * np.where(np.arange(len(base)) == 0, 0.0, 1.0))
+        t_a = time.perf_counter()
         gp.update_mll()
-        return gp.predict_f(xpred)
+        t_b = time.perf_counter()
+        out = gp.predict_f(xpred)
+        wall["fit"] += t_b - t_a
+        wall["predict"] += time.perf_counter() - t_b
+        return out
 
     # Instrumentation inside the timed region (profiles/r03_n_instrumentation.log).  The roofline kernel's launches always carry HIP
     # events (attached to the dispatch: hipExtLaunchKernelGGL start / stop events).  Marker events around EVERY other profiled launch —
@@ -228,6 +235,7 @@ def run_workload(g, ctx, n, d, p, dtype, steps, warmup, barrier, comm=None, shar
     else:
         ctx.profile_enable(True)
     barrier()
+    wall["fit"] = wall["predict"] = 0.0
     t0 = time.perf_counter()
     for i in range(steps):
         mu, s2 = step(warmup + i)
@@ -240,6 +248,7 @@ def run_workload(g, ctx, n, d, p, dtype, steps, warmup, barrier, comm=None, shar
     prof["stage_steps"] = warmup
     assert np.all(np.isfinite(mu)) and np.all(np.isfinite(s2)) and math.isfinite(gp.mll)
     return {"elapsed": elapsed, "prof": prof, "syrk_bytes": syrk_bytes, "t_build": t_build, "mll": gp.mll, "ll": ll,
+            "fit_ms": 1e3 * wall["fit"] / steps, "predict_ms": 1e3 * wall["predict"] / steps,
             "base_mll": base_mll, "base_mu": np.asarray(base_mu, dtype=np.float64), "base_s2": np.asarray(base_s2, dtype=np.float64)}
 
 
@@ -535,6 +544,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            "fit_only_ms_per_step": res["fit_ms"],          # update_mll! alone (SURVEY 8d asks for fit-only and fit+predict), host wall clock
+            "predict_only_ms_per_step": res["predict_ms"],
             "higher_is_better": True,
             "scaling": "weak" if (world > 1 and not sharded) else "strong",
             "vs_baseline": None,
@@ -563,6 +574,8 @@ def main():
             sec["c2"] = {
                 "workload": "N=20000, d=8, SEArd + MeanZero, f64, P=1024 (BASELINE.json configs[1]), 5 steps after 2 warm-ups",
                 "ms_per_step": 1e3 * c2_el / 5,
+                "fit_only_ms_per_step": c2["fit_ms"],
+                "predict_only_ms_per_step": c2["predict_ms"],
                 "fits_per_sec": 5 / c2_el,
                 "roofline_frac": roofline_object(args, c2, 20000, 8, 1024, "f64", 5)["frac"],
                 "stage_ms_per_step": {k: v for k, v in stage_object(c2, 5).items() if k != "note"},

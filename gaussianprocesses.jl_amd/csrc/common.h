@@ -62,6 +62,7 @@ struct ProfRec {
     int cls;
     double work;
     double bytes;
+    bool attached;  // start / stop events of a dispatch (hipExtLaunchKernelGGL): they pin the kernel command, see drain_profile
 };
 
 }  // namespace gpmi

@@ -502,3 +502,34 @@ def test_tiny_noise_keeps_lapack_accuracy():
     spec = ("se_ard", [math.log(0.3), math.log(0.4)], 0.0)
     gp, ref = _fit_both(spec, x, y, -8.0)
     assert abs(gp.mll - ref["mll"]) <= 2e-8 * abs(ref["mll"])
+
+
+def test_destroyed_model_returns_its_device_memory_after_a_profiled_fit():
+    """gpmi_gp_destroy gives the factor's memory back even after fits bracketed by gpmi_profile_enable: the start / stop events
+    attached to the trailing-update dispatches pin the kernel command (and with it the factor) for as long as they exist."""
+    import gc
+
+    import torch
+
+    ctx = g.Context.default(0)
+    rng = np.random.default_rng(3)
+    n = 12000  # fp64 factor: 1.15 GB
+    x = rng.uniform(size=(4, n))
+    y = np.sin(x.sum(axis=0))
+
+    def run(profile):
+        gp = g.GP(x, y, g.MeanZero(), g.SEArd([0.0] * 4, 0.0), -1.0, ctx=ctx)
+        if profile:
+            ctx.profile_enable(True)
+        gp.update_mll()
+        if profile:
+            ctx.profile_get(g._lib.PROF_SYRK)
+            ctx.profile_enable(False)
+
+    run(False)  # context scratch reaches its size for this n
+    gc.collect()
+    free0 = torch.cuda.mem_get_info()[0]
+    run(True)
+    gc.collect()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 << 20, f"{(free0 - free1) / 1e9:.2f} GB still held after the model was destroyed"
