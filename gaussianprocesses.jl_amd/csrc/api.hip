@@ -688,14 +688,15 @@ static int create_one_context(int dev, gpmi_ctx** out) {
             c->lookahead_min_tiles = c->lookahead_min_tiles_masked = (int64_t)(0.5 * t * t / (GEMM_BM * GEMM_BN));
         }
     }
-    // ---- environment, read once per context.  Four knobs steer the factorisation (defaults are the measured optimum):
+    // ---- environment, read once per context.  Five knobs steer the factorisation (defaults are the measured optimum):
     //   GPMI_SUPER=a,b,c       rows remaining from which super-panels of 512 / 1024 / 2048 columns are used
     //   GPMI_LOOKAHEAD=slots   workgroup slots left free beside the update (0 = serial factorisation)
     //   GPMI_LOOKAHEAD_MIN=n   smallest trailing size whose update still hides a 256-block chain
     //   GPMI_CUMASK=0          never reserve whole compute units for the chain (round 2's free slots everywhere)
-    // and four TEST HOOKS select the alternative code paths (NB-block substitution instead of the stored super-block inverses,
-    // the one-product K^-1) at sizes a test can afford — tests/test_gpu_twolevel.py:
-    //   GPMI_SUPER_INV=0  GPMI_WHITEN_INV=0  GPMI_WHITEN_SUPER=w  GPMI_GRAD_CHUNK=k
+    //   GPMI_UPDATE256=0       the 128 x 128 update kernel everywhere (update256.hip off)
+    // and five TEST HOOKS select the alternative code paths (NB-block substitution instead of the stored super-block inverses,
+    // the one-product K^-1, the 256 x 128 update for small launches) at sizes a test can afford — tests/test_gpu_twolevel.py:
+    //   GPMI_SUPER_INV=0  GPMI_WHITEN_INV=0  GPMI_WHITEN_SUPER=w  GPMI_GRAD_CHUNK=k  GPMI_UPDATE256_MIN=tiles
     // Everything else (tile-shape overrides, the phase lock, refinement everywhere, C access width) is bring-up tooling and only
     // exists in a GPMI_TOOLS build (make TOOLS=1).
     if (const char* e = getenv("GPMI_SUPER")) {  // "min512,min1024,min2048" (remaining rows from which each width is used)
@@ -703,6 +704,8 @@ static int create_one_context(int dev, gpmi_ctx** out) {
         sscanf(e, "%lld,%lld,%lld", &a, &b, &d);
         c->super_min[0] = a; c->super_min[1] = b; c->super_min[2] = d;
     }
+    if (const char* e = getenv("GPMI_UPDATE256")) c->update256 = atoi(e) != 0;
+    if (const char* e = getenv("GPMI_UPDATE256_MIN")) c->update256_min_tiles = std::max<long long>(1, atoll(e));
     if (const char* e = getenv("GPMI_GRAD_CHUNK")) c->grad_chunk = std::max<long long>(0, atoll(e) / NB * NB);
     if (const char* e = getenv("GPMI_SUPER_INV")) c->super_inverse = atoi(e) != 0;
     if (const char* e = getenv("GPMI_WHITEN_INV")) c->whiten_by_super_inverse = atoi(e) != 0;
@@ -1050,7 +1053,7 @@ int gpmi_bench_gemm(gpmi_ctx* c, int dtype, int64_t M, int64_t N, int64_t K, int
     if (!c || !ms_out || (dtype != 64 && dtype != 32) || M <= 0 || N <= 0 || K <= 0 || iters <= 0 || N > M) return earg(c, "gpmi_bench_gemm: bad argument");
     if (K % 64 != 0) return earg(c, "gpmi_bench_gemm: bad argument");
 #ifndef GPMI_TOOLS
-    if (variant != 0) return earg(c, "gpmi_bench_gemm: ablation variants exist in a GPMI_TOOLS build only (make TOOLS=1)");
+    if (variant != 0 && variant != 256) return earg(c, "gpmi_bench_gemm: ablation variants exist in a GPMI_TOOLS build only (make TOOLS=1)");
 #endif
     GPMI_HIP(c, hipSetDevice(c->device));
     return dtype == 64 ? gemm_bench<double>(c, M, N, K, lower, variant, iters, ms_out)

@@ -31,6 +31,7 @@
 #include <hip/hip_ext.h>
 
 #include "common.h"
+#include "gemm_queue.h"
 #include "mfma.h"
 #include "tile_order.h"
 
@@ -58,19 +59,6 @@ constexpr bool kTools = true;
 #else
 constexpr bool kTools = false;  // product build: variant 0 / 64 only, no phase lock, no 4x4x4 form, no access-width override
 #endif
-struct QueueArgs {
-    unsigned long long base[8];  // per-XCD value of the queue word at launch
-    int64_t start[9];            // chunk x = tiles [start[x], start[x+1])
-    int use_queue;
-    // GEMM_PHASE_LOCK: value of the XCD's "tiles finished" word (queue word + 1) at launch; a tile of round r = (t - start) /
-    // nloc starts once every tile of the earlier rounds has finished its K loop, so the ~64 tiles in flight on an XCD step
-    // through K together and share their 16 operand panels in L2 slab by slab
-    unsigned long long done_base[8];
-    // batched launch (split-K with separate outputs): work item t is tile t % tiles_per of batch t / tiles_per,
-    // whose operands and output start strideA / strideB / strideC elements further on
-    int64_t tiles_per;
-    int64_t strideA, strideB, strideC;
-};
 
 template <typename T, int VARIANT, int NI>
 __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __restrict__ C, int64_t ldc, const T* __restrict__ A,
@@ -480,7 +468,7 @@ static void launch_persistent_ni(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, i
     const int per_cu = NI == 2 ? (ctx->gemm_wgs_per_cu == 1 ? 1 : 3) : ctx->gemm_wgs_per_cu;
     // beside the persistent update (side stream): no more workgroups than the slots it leaves free, and a queue of its own
     const bool side = ctx->beside_update;
-    const int slots = side ? ctx->lookahead_slots : per_cu * ctx->num_cus - ctx->gemm_reserve;  // multiples of 8
+    const int slots = side ? side_slots(ctx) : per_cu * ctx->num_cus - ctx->gemm_reserve;  // multiples of 8
     // small launches: one workgroup per tile (rounded up to a multiple of 8 so XCD chunks stay contiguous)
     const int grid = (int)std::min<int64_t>(slots, (ntiles + 7) / 8 * 8);
     unsigned long long* const qbase = side ? ctx->queue_base_side : ctx->queue_base;
@@ -567,9 +555,11 @@ void launch_gemm_shape(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda
     const double abytes = sizeof(T) * ((flags & GEMM_OVERWRITE ? 1.0 : 2.0) * entries +
                                        ((double)M + (b_in_a ? 0.0 : (double)N)) * (double)K * (batch ? batch->count : 1));
     ProfScope ps(ctx, trailing ? GPMI_PROF_SYRK : GPMI_PROF_PANEL, 2.0 * entries * (double)K, abytes, /*attach_to_launch=*/true);
-    if (trailing)
+    if (trailing) {
+        // the big updates of the dense path go in 256 x 128 tiles (update256.hip); everything else in 128 x 128 / 128 x 64
+        if (!batch && !flags && launch_update256<T>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info)) return;
         launch_persistent<T, 0>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags, batch, false);
-    else
+    } else
         launch_persistent<T, 64>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags, batch, narrow);
 }
 
@@ -624,6 +614,11 @@ int gemm_bench(gpmi_ctx* ctx, int64_t M, int64_t N, int64_t K, int lower, int va
     auto go = [&]() {
         switch (variant) {
             case 0: launch_variant<T, 0>(ctx, C, ld, A, M, N, K, lower); break;
+            case 256: case 257: case 259: case 261: case 263: case 271:  // the 256 x 128 form of the trailing update (update256.hip; + ablation bits in tools builds)
+                ctx->update256_ablation = variant - 256;
+                if (!lower || !launch_update256<T>(ctx, C, ld, A, ld, A, ld, M, N, K, TileShape{0, 0, 1, 0, 1, 0}, nullptr))
+                    launch_variant<T, 0>(ctx, C, ld, A, M, N, K, lower);
+                break;
 #ifdef GPMI_TOOLS  // ablations of tools/gemm_ablate.py / gemm_phases.py: not instantiated in the product library
             case 1: launch_variant<T, 1>(ctx, C, ld, A, M, N, K, lower); break;
             case 2: launch_variant<T, 2>(ctx, C, ld, A, M, N, K, lower); break;

@@ -129,3 +129,59 @@ def test_whitening_through_nb_blocks_matches_the_stored_super_inverses(monkeypat
     xs = G.synthetic_inputs(3000, 4, p=200)[2]
     np.testing.assert_allclose(gp_a.predict_f(xs)[1], gp_b.predict_f(xs)[1], rtol=1e-9, atol=1e-12)
 
+
+
+@pytest.mark.parametrize("n,dtype,cumask", [(2500, np.float64, 0), (4100, np.float64, 0), (6000, np.float64, 0), (6000, np.float64, 1),
+                                            (5000, np.float32, 0)])
+def test_update_in_256x128_tiles_small(monkeypatch, n, dtype, cumask):
+    """The trailing update in 256 x 128 tiles (csrc/update256.hip) at sizes the oracle factors in seconds: GPMI_UPDATE256_MIN=1
+    sends EVERY eligible update of the dense factorisation through it (by default only launches of >= 1024 tiles take it), so edge
+    tiles in both directions, the carried right-hand-side row, launches smaller than the grid and the queue all run; K = 256 in
+    fp32 is 8 slabs (not eligible) and stays on the 128 x 128 kernel.  The kernel is not used on the CU-masked update stream, which
+    is where look-ahead updates of factorisations under 32 768 rows go: GPMI_CUMASK=0 (free slots everywhere) puts the look-ahead
+    updates — the lower region with a row offset, grid of 248 workgroups — through it as well; cumask = 1 keeps the default (only
+    the serial-order updates take it).  mll / alpha / predictions against the oracle."""
+    monkeypatch.setenv("GPMI_UPDATE256_MIN", "1")
+    if not cumask:
+        monkeypatch.setenv("GPMI_CUMASK", "0")
+    monkeypatch.setenv("GPMI_SUPER", "1024,2048,100000")  # super-panels of 512 from 1024 rows on, 1024 from 2048: K = 512 / 1024 updates at these sizes
+    ctx = g.Context(0)
+    d = 5
+    x, y, xs = G.synthetic_inputs(n, d, p=64)
+    ll = [math.log(0.6)] * d
+    spec = ("se_ard", ll, 0.0)
+    gp = g.GP(x.astype(dtype), y, g.MeanZero(), g.from_spec(spec), math.log(0.1), dtype=dtype, ctx=ctx)
+    ref = G.update_mll(spec, x, y, math.log(0.1))
+    tol = 1e-9 if dtype == np.float64 else 2e-3
+    assert abs(gp.mll - ref["mll"]) <= tol * abs(ref["mll"]), (gp.mll, ref["mll"])
+    np.testing.assert_allclose(gp.alpha, ref["alpha"], rtol=0, atol=(1e-7 if dtype == np.float64 else 5e-2) * np.abs(ref["alpha"]).max())
+    mu, var = gp.predict_f(xs.astype(dtype))
+    rmu, rvar = G.predict_f(spec, x, ref, xs)
+    np.testing.assert_allclose(mu, rmu, rtol=0, atol=(1e-8 if dtype == np.float64 else 2e-3) * np.abs(rmu).max())
+    np.testing.assert_allclose(var, rvar, rtol=0, atol=(1e-8 if dtype == np.float64 else 2e-3))
+
+
+def test_update_in_256x128_tiles_matches_the_128_kernel_n12000(monkeypatch):
+    """Same factorisation through both update kernels at a size where the look-ahead is active: the factor's
+    diagonal, alpha and mll agree to rounding; a failing pivot is reported identically."""
+    x, y, _ = G.synthetic_inputs(12000, 6, p=4)
+    kern = lambda: g.SEArd([math.log(0.5)] * 6, 0.0)
+    monkeypatch.setenv("GPMI_UPDATE256_MIN", "1")
+    monkeypatch.setenv("GPMI_CUMASK", "0")  # free slots: the look-ahead updates go through the 256 x 128 kernel too
+    a = g.GP(x, y, g.MeanZero(), kern(), math.log(0.05), ctx=g.Context(0))
+    monkeypatch.setenv("GPMI_UPDATE256", "0")
+    b = g.GP(x, y, g.MeanZero(), kern(), math.log(0.05), ctx=g.Context(0))
+    assert abs(a.mll - b.mll) <= 1e-11 * abs(b.mll)
+    np.testing.assert_allclose(a.alpha, b.alpha, rtol=0, atol=1e-9 * np.abs(b.alpha).max())
+    np.testing.assert_allclose(a.cK.factor_diag(), b.cK.factor_diag(), rtol=1e-11)
+    # a matrix that stops being positive definite late: both report the same pivot
+    xd = x.copy()
+    xd[:, 11000] = xd[:, 3]
+    monkeypatch.delenv("GPMI_UPDATE256")
+    errs = []
+    for env in ("1", "0"):
+        monkeypatch.setenv("GPMI_UPDATE256", env)
+        with pytest.raises(g.PosDefException) as ei:
+            g.GP(xd, y, g.MeanZero(), g.SEArd([math.log(0.5)] * 6, 0.0), -40.0, ctx=g.Context(0))
+        errs.append(ei.value.info)
+    assert errs[0] == errs[1] and errs[0] > 0

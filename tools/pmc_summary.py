@@ -8,14 +8,15 @@ import os
 import sys
 
 root = sys.argv[1]
-KERNEL = "gemm_nt_kernel<double, 0, 4>"
+KERNELS = ("gemm_nt_kernel<double, 0, 4>", "update256_kernel<double")  # the trailing update: 128 x 128 and 256 x 128 forms (one roofline class)
+KERNEL = " + ".join(KERNELS)
 out = {"kernel": KERNEL, "command": "python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary", "units": "bytes per launch"}
 for counter, folder in (("FETCH_SIZE", "FETCH_SIZE"), ("WRITE_SIZE", "WRITE_SIZE"), ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES"),
                         ("SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES"), ("GRBM_GUI_ACTIVE", "GRBM_GUI_ACTIVE")):
     vals = {}
     for f in glob.glob(os.path.join(root, folder, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            if KERNEL in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+            if any(k in row.get("Kernel_Name", "") for k in KERNELS) and row.get("Counter_Name") == counter:
                 key = row.get("Dispatch_Id")
                 vals[key] = vals.get(key, 0.0) + float(row["Counter_Value"])
     n = len(vals)

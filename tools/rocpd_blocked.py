@@ -30,7 +30,7 @@ def summarize(part, title, top=12):
 summarize(pred, "predict kernels", 6)
 summarize(fit, "fit kernels", 16)
 # queues that carry the trailing update are the critical path: merge them, list their idle time
-upd_q = {r[3] for r in fit if "gemm_nt_kernel" in r[0] and ", 0, 4>" in r[0]}
+upd_q = {r[3] for r in fit if ("gemm_nt_kernel" in r[0] and ", 0, 4>" in r[0]) or "update256_kernel" in r[0]}
 iv = sorted((r[1], r[2], short(r[0])) for r in fit if r[3] in upd_q)
 t0 = fit[0][1]
 ce, idle, gaps, prev = iv[0][1], 0, [], iv[0][2]

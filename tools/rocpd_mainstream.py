@@ -29,7 +29,7 @@ for name, st, en, q, gx, wx in sel:
 # time; every other queue is a side queue
 upd_busy = defaultdict(int)
 for name, st, en, q, gx, wx in sel:
-    if "gemm_nt_kernel<" in name and ", 0, 4>" in name:
+    if ("gemm_nt_kernel<" in name and ", 0, 4>" in name) or "update256_kernel" in name:
         upd_busy[q] += en - st
 mains = {sel[0][3], sel[-1][3]}
 if upd_busy:
@@ -81,7 +81,7 @@ for q in busy:
 # [update start, update end + 5 ms], offsets in us relative to the update's start
 if len(sys.argv) > 2:
     k = int(sys.argv[2])
-    upd = [r for r in sel if "gemm_nt_kernel<double, 0, 4>" in r[0] or "gemm_nt_kernel<float, 0, 4>" in r[0]]
+    upd = [r for r in sel if "gemm_nt_kernel<double, 0, 4>" in r[0] or "gemm_nt_kernel<float, 0, 4>" in r[0] or "update256_kernel" in r[0]]
     u = upd[k]
     w0, w1 = u[1], u[2] + 5_000_000
     print(f"# window: update #{k} lasts {(u[2] - u[1]) / 1e3:.0f} us; kernels overlapping [0, {(w1 - w0) / 1e3:.0f}] us")
