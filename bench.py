@@ -258,7 +258,8 @@ def roofline_object(args, res, n, d, p, dtype, steps):
     achieved = (fl_syrk / max(ms_syrk, 1e-9)) * 1e-9  # flop/ms -> TFLOP/s
     es = 8 if dtype == "f64" else 4
     return {
-        "kernel": "gemm_nt_kernel<T, 0, 4> (Cholesky trailing update, 128x128 tiles, K = super-panel width, v_mfma_f64_16x16x4)",
+        "kernel": "Cholesky trailing update, K = super-panel width, v_mfma_f64_16x16x4: update256_kernel<T> (256x128 tiles, the big launches of "
+                  "factorisations of >= 32768 rows) + gemm_nt_kernel<T, 0, 4> (128x128 tiles, the others); all launches of the class are averaged",
         "bound": "mfma",
         "achieved": achieved,
         "peak": peak,

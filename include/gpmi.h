@@ -248,9 +248,11 @@ int gpmi_profile_get_bytes(gpmi_ctx*, int cls, double* bytes);
  * returns measured TFLOP/s with every SIMD issuing back-to-back MFMAs.      */
 int gpmi_mfma_peak(gpmi_ctx*, int dtype, double* tflops_out);
 /* Isolated timing of the trailing-update kernel  C[M x N] -= A[M x K] A[0:N, 0:K]'  on random
- * operands (lower != 0: SYRK tile set).  variant 0 is the product kernel; other values are the
- * ablations of tools/gemm_ablate.py, compiled only into a GPMI_TOOLS build of the library (make
- * TOOLS=1; GPMI_EARG otherwise).  Returns milliseconds per launch.                            */
+ * operands (lower != 0: SYRK tile set).  variant 0 is the 128 x 128 product kernel, 256 the
+ * 256 x 128 one (csrc/update256.hip; needs lower != 0, falls back to 0 where it does not apply);
+ * other values are the ablations of tools/gemm_ablate.py / tools/update256_ablate.py, compiled
+ * only into a GPMI_TOOLS build of the library (make TOOLS=1; GPMI_EARG otherwise).  Returns
+ * milliseconds per launch.                                                                     */
 int gpmi_bench_gemm(gpmi_ctx*, int dtype, int64_t M, int64_t N, int64_t K, int lower, int variant, int iters,
                     double* ms_out);
 

@@ -15,9 +15,4 @@ head -8 $O/r_kernel_stats.csv | cut -c1-200; head -5 $O/r_mainstream.txt
 rm -rf $O/prof_end
 bash tools/gpu_pmc_bench.sh > $O/r_pmc_bench.log 2>&1; tail -2 $O/r_pmc_bench.log | cut -c1-1200
 rm -rf $O/pmc_bench
-cd /tmp
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$GRAFT_REPO_ROOT/$O/pmc_c3/$c" -- python "$GRAFT_REPO_ROOT/tools/c3_cov_only.py" > "$GRAFT_REPO_ROOT/$O/pmc_c3_$c.log" 2>&1
-done
-cd "$GRAFT_REPO_ROOT"; python tools/pmc_cov.py $O/pmc_c3 > $O/r_c3_cov_pmc.json; cat $O/r_c3_cov_pmc.json
-find $O/pmc_c3 -name "*.csv" -size +20M -delete; rm -rf $O/pmc_c3
+# (the C3 covariance PMC record, profiles/r03_c3_cov_pmc.json, is from the previous records run: cov.hip has not changed since)
