@@ -372,6 +372,11 @@ inline int cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, in
             hipEvent_t eb = la_event(c);  // columns [ks, ke) complete and their inverse consumed
             (void)hipEventRecord(eb, main_s);
             (void)hipStreamWaitEvent(side, eb, 0);
+            // the update below in 256 x 128 tiles leaves eight whole CUs (one per XCD) instead of sixteen half-CU slots: one workgroup
+            // per XCD and chain launch then (common.h side_slots)
+            const TileShape upd_shape{0, 0, 1, (int)((w2 + GEMM_BM - 1) / GEMM_BM), 1, 0};
+            c->side_one_per_xcd = !masked && update256_applies<T>(c, A + ke2 * ld + ke, ld, A + ke2 * ld + ks, ld, A + ke * ld + ks, ld, Mtot - ke2,
+                                                                 npad - ke, K, upd_shape);
             {
                 StreamScope sc(c, side, c->num_cus);  // the block's factorisation and its inverse: small launches
                 c->beside_update = true;  // no launch larger than the reserved slots, no whole-CU kernels (common.h side_cap)
@@ -382,13 +387,14 @@ inline int cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, in
                 if (inv2) build_super_inverse<T>(c, A, ld, linv, ke, w2, LW2, wld2, d_info);
                 c->beside_update = false;
             }
+            c->side_one_per_xcd = false;
             hipEvent_t ec = la_event(c);
             (void)hipEventRecord(ec, side);
             // everything below the next diagonal block: rows ke2.., columns ke.. up to each row tile's diagonal tile
             // (lower mode with offset: row tile ti keeps column tiles <= ti + g0)
             main_update_beside_chain<T>(c, eb, [&]() {
-                launch_gemm_shape<T>(c, A + ke2 * ld + ke, ld, A + ke2 * ld + ks, ld, A + ke * ld + ks, ld, Mtot - ke2, npad - ke, K,
-                                     TileShape{0, 0, 1, (int)((w2 + GEMM_BM - 1) / GEMM_BM), 1, 0}, d_info, 0);
+                launch_gemm_shape<T>(c, A + ke2 * ld + ke, ld, A + ke2 * ld + ks, ld, A + ke * ld + ks, ld, Mtot - ke2, npad - ke, K, upd_shape,
+                                     d_info, 0);
             }, masked);
             (void)hipStreamWaitEvent(main_s, ec, 0);
         }

@@ -138,6 +138,7 @@ struct gpmi_ctx {
     int gemm_reserve = 0;
     int update256 = 1;                   // big trailing updates in 256 x 128 tiles, one 512-thread workgroup per CU (update256.hip;
                                          // GPMI_UPDATE256=0: round 2's 128 x 128 kernel everywhere)
+    bool side_one_per_xcd = false;       // set around a look-ahead chain whose update will run as update256_kernel (chol.h, side_slots)
     int update256_ablation = 0;         // tools builds: ABL bits of update256_kernel for gpmi_bench_gemm (variant 256 + bits)
     int64_t update256_min_tiles = 1024;  // ... from this many 256 x 128 tiles on (GPMI_UPDATE256_MIN: test hook)
     hipStream_t own_stream = nullptr;    // the stream created with the context
@@ -165,7 +166,7 @@ namespace gpmi {
 // Beside the 256 x 128 update on an unmasked stream the free room is eight WHOLE CUs, one per XCD, instead of sixteen half-CU slots:
 // a side launch of more than one workgroup per XCD ends with the update (the dispatcher queues workgroups on shader engines that
 // have no free CU — measured on rows64 and on the 128 x 64 products alike, profiles/r03_r_update256.log), so the cap is 8 there.
-inline int side_slots(const gpmi_ctx* c) { return (c->update256 && c->la_mode == 0 && c->lookahead_slots > 8) ? 8 : c->lookahead_slots; }
+inline int side_slots(const gpmi_ctx* c) { return (c->side_one_per_xcd && c->lookahead_slots > 8) ? 8 : c->lookahead_slots; }
 inline int64_t side_cap(const gpmi_ctx* c, int64_t nwg) {
     const int64_t cap = side_slots(c);
     return c->beside_update && nwg > cap ? cap : nwg;
@@ -287,6 +288,10 @@ void launch_gemm_shape(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda
 template <typename T>
 bool launch_update256(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
                       TileShape shape, const int* info);
+// ... and whether it WOULD take it (no launch): the look-ahead sizes the chain's launches by it (chol.h)
+template <typename T>
+bool update256_applies(const gpmi_ctx* ctx, const T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
+                       TileShape shape);
 enum GemmFlags { GEMM_OVERWRITE = 1 /* C = A B' instead of C -= A B' */, GEMM_KSTART_ROW = 2 /* A[i][k] = 0 for k < i: start K at the tile's first row */,
                  GEMM_KEND_COL = 8 /* B[j][k] = 0 for k > j: end K at the tile's last column */,
                  GEMM_PHASE_LOCK = 64 /* tiles of an XCD start round by round (gemm.hip QueueArgs::done_base) */,

@@ -394,15 +394,19 @@ bool prepare(gpmi_ctx* ctx) {
 // tiles) whose row offset is a multiple of 256, K in whole slabs and at least 16 of them (the C fragments arrive during the
 // first 16), not beside another persistent launch, and enough tiles to fill the chip for several rounds.  Returns false
 // without launching anything otherwise.
-template <typename T, int ABL>
-static bool launch_update256_abl(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
-                                 TileShape shape, const int* info) {
+// Does the 256 x 128 kernel take this update?  (a lower-mode region whose row offset is a multiple of 256, K in whole slabs and at least
+// 16 of them, a plain stream, operands aligned for 16-byte accesses, enough tiles to fill the chip for several rounds)
+template <typename T>
+static bool update256_plan(const gpmi_ctx* ctx, const T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M, int64_t N,
+                           int64_t K, TileShape shape, TileShape* out, int64_t* ntiles_out) {
     constexpr int BK = Mfma<T>::BK;
     if (!ctx->update256 || shape.mode != 1 || (shape.g0 & 1) || ctx->beside_update) return false;
-    if (ctx->stream == ctx->upd_stream && ctx->upd_stream) return false;  // on the CU-masked update stream the kernel measured 10 % slower (profiles/r03_r_update256.log)
+    // on the CU-masked update stream the kernel measured 10 % slower than the 128 x 128 one (profiles/r03_r_update256.log)
+    if (ctx->upd_stream && ctx->stream == ctx->upd_stream) return false;
     if (K % BK != 0 || K / BK < 16 || (lda % (16 / (int)sizeof(T))) || (ldb % (16 / (int)sizeof(T)))) return false;
     if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) return false;
     if (sizeof(T) == 8 && ((ldc & 1) || (reinterpret_cast<uintptr_t>(C) & 15))) return false;  // fp64: 16-byte accesses to the C tile
+    if (lda * (int64_t)sizeof(T) >= (1 << 24) || ldb * (int64_t)sizeof(T) >= (1 << 24)) return false;  // 32-bit staging offsets: 256 rows x stride
     TileShape s = shape;
     s.mode = 3;
     s.g0 = shape.g0 / 2;
@@ -410,6 +414,17 @@ static bool launch_update256_abl(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, i
     s.ntn = (int)((N + U_BN - 1) / U_BN);
     const int64_t ntiles = tile_count(s);
     if (ntiles < ctx->update256_min_tiles) return false;
+    *out = s;
+    *ntiles_out = ntiles;
+    return true;
+}
+
+template <typename T, int ABL>
+static bool launch_update256_abl(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
+                                 TileShape shape, const int* info) {
+    TileShape s;
+    int64_t ntiles;
+    if (!update256_plan<T>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, &s, &ntiles)) return false;
     if (!prepare<T, ABL>(ctx)) return false;
     // one workgroup per CU; the look-ahead's free slots (two per CU in the 128 x 128 kernel's terms) become whole free CUs
     const int cus = (ctx->num_cus - (ctx->gemm_reserve + 1) / 2) / 8 * 8;
@@ -452,6 +467,17 @@ bool launch_update256(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda,
 #endif
     return launch_update256_abl<T, 0>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info);
 }
+template <typename T>
+bool update256_applies(const gpmi_ctx* ctx, const T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
+                       TileShape shape) {
+    TileShape s;
+    int64_t n;
+    return update256_plan<T>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, &s, &n);
+}
+template bool update256_applies<double>(const gpmi_ctx*, const double*, int64_t, const double*, int64_t, const double*, int64_t, int64_t, int64_t,
+                                        int64_t, TileShape);
+template bool update256_applies<float>(const gpmi_ctx*, const float*, int64_t, const float*, int64_t, const float*, int64_t, int64_t, int64_t, int64_t,
+                                       TileShape);
 template bool launch_update256<double>(gpmi_ctx*, double*, int64_t, const double*, int64_t, const double*, int64_t, int64_t, int64_t, int64_t,
                                        TileShape, const int*);
 template bool launch_update256<float>(gpmi_ctx*, float*, int64_t, const float*, int64_t, const float*, int64_t, int64_t, int64_t, int64_t,

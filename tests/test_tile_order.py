@@ -41,6 +41,15 @@ int main() {
     for (int off = 0; off <= 2; ++off)
         for (int ntm = 1; ntm <= 30; ++ntm)
             for (int ntn = 1; ntn <= 2 * (ntm + off); ++ntn) { ++cases; bad += check(TileShape{ntm, ntn, 3, off, 1, 0}); }
+    // the same enumeration at twice the scale is the 256 x 128 tiling of update256.hip: the look-ahead updates of an N = 50 000
+    // factorisation (row offset = next super-panel width / 256: 8, 4, 2; the last tile-row holds the carried right-hand side and
+    // is capped by ntn), and the serial-order update (offset 0)
+    for (int off : {0, 2, 4, 8})
+        for (int rows : {24576, 47360, 50048 - 2048})
+            for (int extra : {0, 8}) {
+                const int M = rows + extra, N = rows + 256 * off;  // M rows below the next diagonal block, N columns from its first column
+                ++cases; bad += check(TileShape{(M + 255) / 256, (N + 127) / 128, 3, off, 1, 0});
+            }
     // staircase (row-block-cyclic shards): G ranks, first owned block g0, carried rows past the staircase
     for (int G = 1; G <= 4; ++G)
         for (int g0 = 0; g0 < G + 2; ++g0)
