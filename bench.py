@@ -501,19 +501,38 @@ def main():
 
     _comm = []
 
+    _comm_kind = []
+
     def make_comm():
         """ONE communicator per process, verified before the first fit: libgpmi's own RCCL communicator (the unique id travels
-        through the launcher's torch.distributed group), or — GPMI_DIST_COMM=torch — torch.distributed behind the callbacks."""
+        through the launcher's torch.distributed group), or — GPMI_DIST_COMM=torch, and as the fallback when every rank agrees that
+        the native one could not be opened or failed its self-test — torch.distributed (backend nccl = RCCL) behind the callbacks."""
         if dist is None:
             return None
         if not _comm:
             from gpmi355x import dist as gd
 
-            if os.environ.get("GPMI_DIST_COMM", "rccl") == "torch":
+            c = None
+            if os.environ.get("GPMI_DIST_COMM", "rccl") != "torch":
+                ok = 1
+                try:
+                    c = gd.rccl_comm(ctx)
+                    c.selftest(ctx)
+                except Exception as e:  # noqa: BLE001
+                    ok = 0
+                    sys.stderr.write(f"bench.py rank {rank}: native RCCL communicator unavailable ({e!r}); asking the other ranks\n")
+                t = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                if int(t.item()) == 0:  # somebody failed: everybody falls back (the collectives must match on every rank)
+                    if c is not None:
+                        c.close()
+                    c = None
+                else:
+                    _comm_kind.append("libgpmi RCCL (gpmi_comm_create_rccl)")
+            if c is None:
                 c = gd.TorchDistComm(device=local_rank)
-            else:
-                c = gd.rccl_comm(ctx)
-            c.selftest(ctx)
+                c.selftest(ctx)
+                _comm_kind.append("torch.distributed nccl behind gpmi_comm_callbacks")
             _comm.append(c)
         return _comm[0]
 
@@ -557,6 +576,7 @@ def main():
                             "(the configuration BASELINE.json's north-star target is quoted on)",
                 "parallelism": par,
                 "mll": res["mll"],
+                **({"communicator": _comm_kind[0]} if _comm_kind else {}),
             },
             "roofline": roofline_object(args, res, n, d, p, args.dtype, args.steps),
             "stage_ms_per_step": stage_object(res, args.steps),
