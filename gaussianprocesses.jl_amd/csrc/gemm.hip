@@ -611,6 +611,20 @@ int gemm_bench(gpmi_ctx* ctx, int64_t M, int64_t N, int64_t K, int lower, int va
     hipEvent_t e0, e1;
     GPMI_HIP(ctx, hipEventCreate(&e0));
     GPMI_HIP(ctx, hipEventCreate(&e1));
+#ifdef GPMI_TOOLS
+    // tools: the same launch as the look-ahead makes it — GPMI_BENCH_STREAM=reserve: plain stream, 16 slots (8 CUs) left free;
+    // =masked: the CU-masked update stream (248 CUs)
+    const char* bs = getenv("GPMI_BENCH_STREAM");
+    const bool on_masked = bs && bs[0] == 'm' && ctx->upd_stream;
+    hipStream_t s_keep = ctx->stream;
+    const int cus_keep = ctx->num_cus;
+    if (on_masked) {
+        ctx->stream = ctx->upd_stream;
+        ctx->num_cus = cus_keep - 8;
+    } else if (bs && bs[0] == 'r') {
+        ctx->gemm_reserve = 16;
+    }
+#endif
     auto go = [&]() {
         switch (variant) {
             case 0: launch_variant<T, 0>(ctx, C, ld, A, M, N, K, lower); break;
@@ -647,6 +661,11 @@ int gemm_bench(gpmi_ctx* ctx, int64_t M, int64_t N, int64_t K, int lower, int va
     float ms = 0.f;
     GPMI_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
     *ms_out = (double)ms / iters;
+#ifdef GPMI_TOOLS
+    ctx->stream = s_keep;
+    ctx->num_cus = cus_keep;
+    ctx->gemm_reserve = 0;
+#endif
     if (kTools && (variant & 128)) {  // per-phase wall-clock split of the last launch (100 MHz ticks), averaged over workgroups
         std::vector<unsigned long long> dbg(4 * 512);
         GPMI_HIP(ctx, hipMemcpy(dbg.data(), ctx->d_queue + 64, dbg.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));

@@ -402,7 +402,12 @@ static bool update256_plan(const gpmi_ctx* ctx, const T* C, int64_t ldc, const T
     constexpr int BK = Mfma<T>::BK;
     if (!ctx->update256 || shape.mode != 1 || (shape.g0 & 1) || ctx->beside_update) return false;
     // on the CU-masked update stream the kernel measured 10 % slower than the 128 x 128 one (profiles/r03_r_update256.log)
-    if (ctx->upd_stream && ctx->stream == ctx->upd_stream) return false;
+#ifdef GPMI_TOOLS
+    static const bool on_masked_too = getenv("GPMI_UPDATE256_ON_MASKED") != nullptr;  // tools: measure it there (tools/update256_streams.py)
+#else
+    constexpr bool on_masked_too = false;
+#endif
+    if (ctx->upd_stream && ctx->stream == ctx->upd_stream && !on_masked_too) return false;
     if (K % BK != 0 || K / BK < 16 || (lda % (16 / (int)sizeof(T))) || (ldb % (16 / (int)sizeof(T)))) return false;
     if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) return false;
     if (sizeof(T) == 8 && ((ldc & 1) || (reinterpret_cast<uintptr_t>(C) & 15))) return false;  // fp64: 16-byte accesses to the C tile
