@@ -14,13 +14,17 @@
 //     the barrier: while the 32 MFMAs of (slab k, k-half 0) issue, the fragments of (k, half 1) are in flight; while those
 //     multiply, the fragments of (k + 1, half 0).  A wave arrives at every barrier with the operands of its next 32 MFMAs in
 //     registers — the matrix pipe is never drained by an LDS latency;
-//   * the fragment reads are inline-asm ds_read_b128: hipcc cannot tell the LDS writes of global_load_lds from LDS reads and
-//     puts s_waitcnt vmcnt(0) in front of every LDS read it sees after a DMA (gemm.hip, K loop comment), which would
-//     serialise exactly this pipeline; the waits are written by hand (lgkmcnt before use, vmcnt(0) before the barrier);
-//   * the C tile does not pass through a prologue: the accumulators start at zero and C arrives INSIDE the K loop, one
-//     16 x 16 fragment per wave and slab during the first 16 slabs (loads issued at the top of a slab, added at its end), so
-//     the 256 KiB of C per tile ride under ~55 us of MFMA issue; the tile leaves with plain stores.  (Round 1 tried C in the K
-//     loop at K = 256 and only moved the cost — there C was a quarter of all bytes; at K >= 1024 it is 3 - 6 %.)
+//   * everything that is not an MFMA is issued INSIDE the MFMA stream, after groups of four: one LDS-DMA piece after each of the
+//     first half's groups 1 - 6, the eight ds_read_b128 of the other half after group 0 (both waves of a SIMD stand at the same
+//     place in the code: six pieces issued in a row after the barrier were ~600 cycles without an MFMA);
+//   * the fragment reads and the LDS-DMA are inline assembly: hipcc cannot tell the LDS writes of global_load_lds from LDS reads
+//     and puts s_waitcnt vmcnt(0) in front of every LDS read it sees after a DMA (gemm.hip, K loop comment), and it waits for the
+//     DMA before it overwrites a register the DMA used as its address — either would serialise exactly this pipeline; the waits
+//     are written by hand (lgkmcnt before use, vmcnt(0) before the barrier);
+//   * the C tile is read in the EPILOGUE, into the then-free fragment registers (four batches of four fragments, two in flight),
+//     while the next tile's first two slabs are already on their way (its index comes from the queue pull issued under the last
+//     slab), and the tile's 32 stores per lane drain under the next tile's first slab.  (C inside the K loop — one fragment per
+//     slab during the first 16 — was built first; hipcc's register allocation does not survive it: DESIGN.md 3.2b.)
 // Tile order: tile_order.h mode 3 (the lower region in tiles twice as tall as wide), per-XCD persistent queues as in gemm.hip.
 // Used for the dense path's big updates only (launch_update256 says when); everything else stays on gemm_nt_kernel.
 #include <algorithm>
@@ -96,8 +100,8 @@ __global__ __launch_bounds__(512, 2) void update256_kernel(T* __restrict__ C, in
         return;
     }
     // Everything a lane keeps across the K loop besides accumulators and fragments is 32-bit: ONE LDS offset (the other three
-    // fragment addresses differ from it by wave-uniform amounts and one XOR), six staging offsets, one C offset.  The pointers
-    // they are added to are wave-uniform (scalar registers).
+    // fragment addresses differ from it by wave-uniform amounts and one XOR) and six staging offsets.  The pointers they are added
+    // to are wave-uniform (scalar registers).
     const int lane = tid & 63;
     const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform
     const int wm = wvu >> 1, wn = wvu & 1;
