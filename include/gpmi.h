@@ -33,6 +33,9 @@
 
 #include <stdint.h>
 
+/* libgpmi.so is built with -fvisibility=hidden: the entry points below are its ONLY dynamic symbols */
+#define GPMI_API __attribute__((visibility("default")))
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -94,19 +97,19 @@ typedef struct gpmi_gp gpmi_gp;   /* one per GPE: resident x, factor, alpha     
  * every gpmi_fit / gpmi_predict / gpmi_grad on it; every other entry point runs on device_ids[0].  This is the
  * single-process multi-GPU form (a Julia session driving all the GPUs of a node); the one-process-per-GPU form is a
  * communicator (gpmi_comm_*) on single-device contexts.                                                              */
-int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out);
-void gpmi_ctx_destroy(gpmi_ctx*);
+GPMI_API int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out);
+GPMI_API void gpmi_ctx_destroy(gpmi_ctx*);
 /* waits for ALL work on the context's device(s) (every entry point already returns with its results on the host; this is the
  * explicit bracket a timing harness puts around a measured region: hipDeviceSynchronize)                                  */
-int gpmi_ctx_synchronize(gpmi_ctx*);
-const char* gpmi_last_error(gpmi_ctx*);
-const char* gpmi_version(void);
+GPMI_API int gpmi_ctx_synchronize(gpmi_ctx*);
+GPMI_API const char* gpmi_last_error(gpmi_ctx*);
+GPMI_API const char* gpmi_version(void);
 
 /* ---- model object: replaces alloc_cK (src/GP.jl:14-20) + KernelData ----- */
 /* Copies x (d x n col-major, element type given by dtype) to the device and
  * allocates ONE n x n factor buffer (the reference keeps two, GP.jl:16-17).   */
-int gpmi_gp_create(gpmi_ctx*, int dtype /*64|32*/, int d, int64_t n, const void* x, gpmi_gp** out);
-void gpmi_gp_destroy(gpmi_gp*);
+GPMI_API int gpmi_gp_create(gpmi_ctx*, int dtype /*64|32*/, int d, int64_t n, const void* x, gpmi_gp** out);
+GPMI_API void gpmi_gp_destroy(gpmi_gp*);
 
 /* ---- fit: replaces update_cK! + update_mll! (src/GPE.jl:169-212) and
  *      make_posdef! (src/GP.jl:101-112) -------------------------------------
@@ -116,14 +119,14 @@ void gpmi_gp_destroy(gpmi_gp*);
  * mll_out:   -(y'alpha + logdet + n log 2pi)/2  (GPE.jl:210), always double.
  * alpha_out: n elements of dtype, may be NULL.
  * info_out:  0, or the 1-based failing pivot when GPMI_ENOTPD is returned.    */
-int gpmi_fit(gpmi_gp*, const gpmi_kernel*, const double* log_noise, int64_t n_noise,
+GPMI_API int gpmi_fit(gpmi_gp*, const gpmi_kernel*, const double* log_noise, int64_t n_noise,
              const void* y_minus_mu, double* mll_out, void* alpha_out, int64_t* info_out);
 
 /* ---- predict: replaces predict_f / predictMVN (src/GP.jl:25-84) ----------
  * xpred: d x p col-major.  mean_pred: mean(m, xpred), p elements.
  * full_cov == 0: var_out[p] = max(k(x*,x*) - |L^-1 k*|^2, 0)   (GP.jl:69-77, batched)
  * full_cov != 0: var_out[p x p] = Kpred - (L^-1 K*)'(L^-1 K*), no clamp (GP.jl:25-30,51-54) */
-int gpmi_predict(gpmi_gp*, const gpmi_kernel*, int64_t p, const void* xpred, const void* mean_pred,
+GPMI_API int gpmi_predict(gpmi_gp*, const gpmi_kernel*, int64_t p, const void* xpred, const void* mean_pred,
                  int full_cov, void* mu_out, void* var_out);
 
 /* ---- gradient: replaces update_dmll! (src/GPE.jl:298-324) for the kernel and noise parts ----
@@ -135,7 +138,7 @@ int gpmi_predict(gpmi_gp*, const gpmi_kernel*, int64_t p, const void* xpred, con
  * The mean part, dot(grad_mean, alpha) (GPE.jl:282-288), is O(N d) host work on alpha.
  * n_kern must equal the kernel's parameter count.  Allocates two more n x n device buffers on
  * first use.  Kernels beyond 64 parameters / d > 32 return GPMI_EARG (cov! itself: d <= 64).          */
-int gpmi_grad(gpmi_gp*, const gpmi_kernel*, const double* log_noise, int64_t n_noise, double* dkern_out, int32_t n_kern,
+GPMI_API int gpmi_grad(gpmi_gp*, const gpmi_kernel*, const double* log_noise, int64_t n_noise, double* dkern_out, int32_t n_kern,
               double* dnoise_out);
 
 /* ---- FITC sparse approximation (BASELINE.json configs[4]) ----------------------
@@ -150,22 +153,22 @@ int gpmi_grad(gpmi_gp*, const gpmi_kernel*, const double* log_noise, int64_t n_n
  * GPMI_ENOTPD when Kuu / SigmaQR fail to factor or a Lambda_i is not positive (info = pivot / 1-based index).
  * Device memory: three n x m matrices (Kfu, its whitened image, Kuf) -- sized for 288 GB, not for a host. */
 typedef struct gpmi_fitc gpmi_fitc;
-int gpmi_fitc_create(gpmi_ctx*, int dtype, int d, int64_t n, const void* x, int64_t m, const void* xu, gpmi_fitc** out);
-void gpmi_fitc_destroy(gpmi_fitc*);
-int gpmi_fitc_fit(gpmi_fitc*, const gpmi_kernel*, double log_noise, const void* y_minus_mu, double* mll_out, void* alpha_out,
+GPMI_API int gpmi_fitc_create(gpmi_ctx*, int dtype, int d, int64_t n, const void* x, int64_t m, const void* xu, gpmi_fitc** out);
+GPMI_API void gpmi_fitc_destroy(gpmi_fitc*);
+GPMI_API int gpmi_fitc_fit(gpmi_fitc*, const gpmi_kernel*, double log_noise, const void* y_minus_mu, double* mll_out, void* alpha_out,
                   int64_t* info_out);
 /* mu_out[p] = mean_pred[p] + Kxu alpha_u ; var_out: p variances clamped at 0 (GP.jl:75), or the p x p matrix
  * Kxx - Qxx + Kxu SigmaQR^-1 Kux (col-major == row-major, symmetric) when full_cov != 0 */
-int gpmi_fitc_predict(gpmi_fitc*, const gpmi_kernel*, int64_t p, const void* xpred, const void* mean_pred, int full_cov,
+GPMI_API int gpmi_fitc_predict(gpmi_fitc*, const gpmi_kernel*, int64_t p, const void* xpred, const void* mean_pred, int full_cov,
                       void* mu_out, void* var_out);
 /* alpha_u = SigmaQR \ (Kuf (Lambda \ (y - mu))), m elements (get_alpha_u) */
-int gpmi_fitc_alpha_u(gpmi_fitc*, void* out);
+GPMI_API int gpmi_fitc_alpha_u(gpmi_fitc*, void* out);
 /* update_dmll! on the FITC model of the last gpmi_fitc_fit (same kernel, same log_noise): dmll_kern!
  * (ASSUMES stationary leaves — every gpmi_op above is: the per-point term sum_i q_i dk(x_i,x_i)/dtheta of :218 is taken as
  * (sum_i q_i) dk/dtheta at r = 0; a kernel with any other leaf is refused with GPMI_EARG.)
  * (src/sparse/fully_indep_train_conditional.jl:200-234 over subsetofregressors.jl:219-256) -> dkern_out[n_kern] in
  * get_params order, dmll_noise (:243-257) -> *dnoise_out.  The mean part (GPE.jl:282-288) is grad_stack' * alpha on the host. */
-int gpmi_fitc_grad(gpmi_fitc*, const gpmi_kernel*, double log_noise, double* dkern_out, int32_t n_kern, double* dnoise_out);
+GPMI_API int gpmi_fitc_grad(gpmi_fitc*, const gpmi_kernel*, double log_noise, double* dkern_out, int32_t n_kern, double* dnoise_out);
 
 /* ---- blocked model object: packed storage on one device, row-block sharding over several ---------
  * The same gpmi_gp handle type and the same gpmi_fit / gpmi_predict / gpmi_grad / gpmi_logdet / gpmi_factor_diag, with the
@@ -189,40 +192,40 @@ typedef struct gpmi_comm_callbacks {
     int (*all_reduce_sum)(void* user, void* buf, int64_t count, int elem_bytes /* 8: double, 4: float */, void* stream);
     int (*host_allreduce)(void* user, double* vals, int32_t n, int32_t op);
 } gpmi_comm_callbacks;
-int gpmi_comm_create_callbacks(const gpmi_comm_callbacks* cb, int rank, int world, gpmi_comm** out);
+GPMI_API int gpmi_comm_create_callbacks(const gpmi_comm_callbacks* cb, int rank, int world, gpmi_comm** out);
 /* RCCL directly (librccl.so is opened at run time): rank 0 calls gpmi_comm_unique_id and hands the 128 bytes to every rank
  * (any out-of-band channel: the launcher's store, a file, MPI); every rank then calls gpmi_comm_create_rccl on its context.  */
-int gpmi_comm_unique_id(void* id128_out);
-int gpmi_comm_create_rccl(gpmi_ctx*, const void* id128, int rank, int world, gpmi_comm** out);
-void gpmi_comm_destroy(gpmi_comm*);
+GPMI_API int gpmi_comm_unique_id(void* id128_out);
+GPMI_API int gpmi_comm_create_rccl(gpmi_ctx*, const void* id128, int rank, int world, gpmi_comm** out);
+GPMI_API void gpmi_comm_destroy(gpmi_comm*);
 /* every collective of `comm` on small device buffers with rank-dependent patterns, verified on the host (collective call:
  * all ranks).  A launcher runs it once before its first fit so that a broken transport fails with a message of its own.  */
-int gpmi_comm_selftest(gpmi_ctx*, gpmi_comm*);
-int gpmi_gp_create_blocked(gpmi_ctx*, gpmi_comm* comm /* NULL: one rank */, int dtype, int d, int64_t n, const void* x,
+GPMI_API int gpmi_comm_selftest(gpmi_ctx*, gpmi_comm*);
+GPMI_API int gpmi_gp_create_blocked(gpmi_ctx*, gpmi_comm* comm /* NULL: one rank */, int dtype, int d, int64_t n, const void* x,
                            int64_t block_rows, int stripe_blocks, gpmi_gp** out);
 /* what the handle occupies: rows per block, stripes on this rank, bytes of factor storage on this rank */
-int gpmi_gp_blocked_info(gpmi_gp*, int64_t* block_rows, int32_t* n_stripes, int64_t* factor_bytes);
+GPMI_API int gpmi_gp_blocked_info(gpmi_gp*, int64_t* block_rows, int32_t* n_stripes, int64_t* factor_bytes);
 
 /* ---- cov: replaces cov / cov! (src/kernels/kernels.jl:31-71) -------------
  * out is n1 x n2 col-major; x2 == NULL selects the symmetric X1 === X2 form. */
-int gpmi_cov(gpmi_ctx*, const gpmi_kernel*, int dtype, int d, int64_t n1, const void* x1,
+GPMI_API int gpmi_cov(gpmi_ctx*, const gpmi_kernel*, int dtype, int d, int64_t n1, const void* x1,
              int64_t n2, const void* x2, void* out);
 
 /* ---- AbstractPDMat surface of the fitted factor (PDMats `\`, whiten!, logdet;
  *      src/GPE.jl:208,210, src/GP.jl:27,136, src/GPE.jl:162) ----------------
  * b_inout is n x nrhs col-major, overwritten with the result.               */
-int gpmi_solve(gpmi_gp*, int64_t nrhs, void* b_inout);  /* (K + noise)^-1 b     */
-int gpmi_whiten(gpmi_gp*, int64_t nrhs, void* b_inout); /* L^-1 b,  L = U'      */
+GPMI_API int gpmi_solve(gpmi_gp*, int64_t nrhs, void* b_inout);  /* (K + noise)^-1 b     */
+GPMI_API int gpmi_whiten(gpmi_gp*, int64_t nrhs, void* b_inout); /* L^-1 b,  L = U'      */
 /* out[i] = ((K + noise)^-1)_ii, n elements: what predict_LOO needs — inv(Σ) / diag in src/crossvalidation.jl:8-13
  * (SURVEY 8f rank 4).  n^3/3 flops on the device instead of the reference's dense inverse. */
-int gpmi_inv_diag(gpmi_gp*, void* out);
-int gpmi_logdet(gpmi_gp*, double* out);                 /* 2 sum log U_ii       */
+GPMI_API int gpmi_inv_diag(gpmi_gp*, void* out);
+GPMI_API int gpmi_logdet(gpmi_gp*, double* out);                 /* 2 sum log U_ii       */
 /* U_out: n x n col-major with the upper factor in its upper triangle and zeros
  * below (== Cholesky(factors,'U',0), src/GPE.jl:60).                        */
-int gpmi_factor_to_host(gpmi_gp*, void* U_out);
+GPMI_API int gpmi_factor_to_host(gpmi_gp*, void* U_out);
 /* diag_out[i] = U_ii, n elements of the model's dtype: `diag(cholfactors(cK))` without moving the n x n factor
  * (what PDMats.logdet sums, GPE.jl:210; lets a caller re-derive logdet on the host). */
-int gpmi_factor_diag(gpmi_gp*, void* diag_out);
+GPMI_API int gpmi_factor_diag(gpmi_gp*, void* diag_out);
 
 /* ---- measurement hooks (bench.py; no reference counterpart) --------------
  * When enabled, every launch of a profiled kernel class is bracketed by HIP
@@ -237,23 +240,23 @@ enum gpmi_prof_class {
 };
 /* on = 0: off; 1: every class; 2 + cls: the launches of class cls ONLY (a few dozen event pairs per fit for GPMI_PROF_SYRK,
  * against thousands for the panel kernels: what a timing harness leaves on inside its timed region).                       */
-int gpmi_profile_enable(gpmi_ctx*, int on);
+GPMI_API int gpmi_profile_enable(gpmi_ctx*, int on);
 /* launches, total milliseconds and algorithmic work (flops for SYRK/PANEL/
  * PREDICT, bytes for COV/SOLVE) accumulated since the last call for `cls`.  */
-int gpmi_profile_get(gpmi_ctx*, int cls, int64_t* launches, double* total_ms, double* work);
+GPMI_API int gpmi_profile_get(gpmi_ctx*, int cls, int64_t* launches, double* total_ms, double* work);
 /* algorithmic HBM bytes of the MFMA products of `cls` accumulated since the last call (every output entry read and
  * written once, the operand panels read once; K varies per launch since the two-level factorisation).             */
-int gpmi_profile_get_bytes(gpmi_ctx*, int cls, double* bytes);
+GPMI_API int gpmi_profile_get_bytes(gpmi_ctx*, int cls, double* bytes);
 /* Peak-rate micro-benchmark of v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32:
  * returns measured TFLOP/s with every SIMD issuing back-to-back MFMAs.      */
-int gpmi_mfma_peak(gpmi_ctx*, int dtype, double* tflops_out);
+GPMI_API int gpmi_mfma_peak(gpmi_ctx*, int dtype, double* tflops_out);
 /* Isolated timing of the trailing-update kernel  C[M x N] -= A[M x K] A[0:N, 0:K]'  on random
  * operands (lower != 0: SYRK tile set).  variant 0 is the 128 x 128 product kernel, 256 the
  * 256 x 128 one (csrc/update256.hip; needs lower != 0, falls back to 0 where it does not apply);
  * other values are the ablations of tools/gemm_ablate.py / tools/update256_ablate.py, compiled
  * only into a GPMI_TOOLS build of the library (make TOOLS=1; GPMI_EARG otherwise).  Returns
  * milliseconds per launch.                                                                     */
-int gpmi_bench_gemm(gpmi_ctx*, int dtype, int64_t M, int64_t N, int64_t K, int lower, int variant, int iters,
+GPMI_API int gpmi_bench_gemm(gpmi_ctx*, int dtype, int64_t M, int64_t N, int64_t K, int lower, int variant, int iters,
                     double* ms_out);
 
 #ifdef __cplusplus

@@ -27,6 +27,9 @@ def test_header_binding_and_library_agree():
     nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = sorted(set(re.findall(r"\bT (gpmi_[a-z0-9_]+)$", nm, flags=re.M)))
     assert exported == hdr
+    # ... and NOTHING else: no mangled C++ internals, no libstdc++ instantiations, no kernel stubs (-fvisibility=hidden + csrc/libgpmi.map)
+    every = sorted(line.split()[-1] for line in nm.splitlines() if line.strip())
+    assert every == hdr, [s for s in every if s not in hdr]
 
 
 def test_version_string():
