@@ -376,7 +376,7 @@ static int grad_t(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, do
     if (rc != GPMI_OK) return rc;
     const int n_hyp = c->h_prog->n_hyp;
     if (c->h_prog->n_ops > GRAD_MAX_NODES || n_hyp > GRAD_MAX_HYP || gp->d > GRAD_MAX_D) {
-        c->err = "gpmi_grad: kernel outside the device gradient path (<= 64 hyper-parameters, d <= 32)";
+        c->err = grad_limit_message();
         return GPMI_EARG;
     }
     const size_t bytes = (size_t)(npad * ld) * sizeof(T);
@@ -916,7 +916,7 @@ int gpmi_cov(gpmi_ctx* c, const gpmi_kernel* k, int dtype, int d, int64_t n1, co
     return dtype == 64 ? cov_t<double>(c, k, d, n1, x1, n2, x2, out) : cov_t<float>(c, k, d, n1, x1, n2, x2, out);
 }
 
-static int need_fit(gpmi_gp* gp, const char* who, bool blocked_ok = false) {
+static int need_fit(gpmi_gp* gp, const char* who, bool blocked_ok = true) {
     if (!gp) return GPMI_EARG;
     if (BlockedGP* b = blocked_of(gp)) {
         if (!blocked_ok) {
@@ -937,26 +937,44 @@ static int need_fit(gpmi_gp* gp, const char* who, bool blocked_ok = false) {
 }
 
 int gpmi_solve(gpmi_gp* gp, int64_t nrhs, void* b) {
-    int rc = need_fit(gp, "gpmi_solve");
+    int rc = need_fit(gp, "gpmi_solve", true);
     if (rc) return rc;
     if (nrhs <= 0 || !b) return earg((gp ? gp->ctx : nullptr), "gpmi_solve: bad argument");
     GPMI_HIP(gp->ctx, hipSetDevice(gp->ctx->device));
+    if (gp->group) return group_solve(gp, nrhs, b, true);
+    if (BlockedGP* bl = blocked_of(gp)) {
+        const int rcb = bl->solve(nrhs, b, true);
+        if (rcb != GPMI_OK) gp->ctx->err = bl->error();
+        return rcb;
+    }
     return gp->dtype == 64 ? solve_t<double>(gp, nrhs, b, true) : solve_t<float>(gp, nrhs, b, true);
 }
 
 int gpmi_whiten(gpmi_gp* gp, int64_t nrhs, void* b) {
-    int rc = need_fit(gp, "gpmi_whiten");
+    int rc = need_fit(gp, "gpmi_whiten", true);
     if (rc) return rc;
     if (nrhs <= 0 || !b) return earg((gp ? gp->ctx : nullptr), "gpmi_whiten: bad argument");
     GPMI_HIP(gp->ctx, hipSetDevice(gp->ctx->device));
+    if (gp->group) return group_solve(gp, nrhs, b, false);
+    if (BlockedGP* bl = blocked_of(gp)) {
+        const int rcb = bl->solve(nrhs, b, false);
+        if (rcb != GPMI_OK) gp->ctx->err = bl->error();
+        return rcb;
+    }
     return gp->dtype == 64 ? solve_t<double>(gp, nrhs, b, false) : solve_t<float>(gp, nrhs, b, false);
 }
 
 int gpmi_inv_diag(gpmi_gp* gp, void* out) {
     if (!gp || !out) return earg((gp ? gp->ctx : nullptr), "gpmi_inv_diag: bad argument");
-    int rc = need_fit(gp, "gpmi_inv_diag");
+    int rc = need_fit(gp, "gpmi_inv_diag", true);
     if (rc != GPMI_OK) return rc;
     hipSetDevice(gp->ctx->device);
+    if (gp->group) return group_inv_diag(gp, out);
+    if (BlockedGP* bl = blocked_of(gp)) {
+        const int rcb = bl->inv_diag(out);
+        if (rcb != GPMI_OK) gp->ctx->err = bl->error();
+        return rcb;
+    }
     return gp->dtype == 64 ? gpmi::inv_diag_t<double>(gp, out) : gpmi::inv_diag_t<float>(gp, out);
 }
 
@@ -973,11 +991,17 @@ int gpmi_logdet(gpmi_gp* gp, double* out) {
 }
 
 int gpmi_factor_to_host(gpmi_gp* gp, void* U_out) {
-    int rc = need_fit(gp, "gpmi_factor_to_host");
+    int rc = need_fit(gp, "gpmi_factor_to_host", true);
     if (rc) return rc;
     if (!U_out) return earg((gp ? gp->ctx : nullptr), "gpmi_factor_to_host: bad argument");
     gpmi_ctx* c = gp->ctx;
     GPMI_HIP(c, hipSetDevice(c->device));
+    if (gp->group) return group_factor_to_host(gp, U_out);
+    if (BlockedGP* bl = blocked_of(gp)) {
+        const int rcb = bl->factor_to_host(U_out);
+        if (rcb != GPMI_OK) gp->ctx->err = bl->error();
+        return rcb;
+    }
     const size_t es = gp->dtype == 64 ? 8 : 4;
     const int64_t n = gp->n;
     // row-major lower L  ==  column-major upper U: a straight 2-D copy, then clear the other triangle

@@ -28,6 +28,11 @@ class BlockedGP {
     int predict(const gpmi_kernel* k, int64_t P, const void* xpred_host, const void* mean_host, int full_cov, void* mu_out, void* var_out);
     int grad(const gpmi_kernel* k, const double* log_noise, int64_t n_noise, double* dkern_out, int n_kern, double* dnoise_out);
     int factor_diag(void* out_host);  // diag(U), n elements (every rank returns the full vector)
+    // AbstractPDMat surface (PDMats `\`, whiten!; GPE.jl:208, GP.jl:27,136, GPE.jl:162).  b: n x nrhs column-major on the host, overwritten
+    // with L^-1 b (backward = false) or (K + noise)^-1 b (true); every rank passes the same b and receives the same result
+    int solve(int64_t nrhs, void* b_inout_host, bool backward);
+    int inv_diag(void* out_host);        // diag((K + noise)^-1), n elements (crossvalidation.jl:8-13); needs the gradient's own-rows x N scratch
+    int factor_to_host(void* U_out_host);  // n x n column-major upper factor, zeros below (GPE.jl:60); every rank receives all of it
     bool fitted() const { return fitted_; }
     double logdet() const { return logdet_; }
     const std::string& error() const { return err_; }
@@ -94,6 +99,14 @@ class BlockedGP {
     void solve_and_gather(int64_t k, bool from_factor);  // from_factor: the rows are already solved (gradient: re-gather a stored panel)
     void update_cols(int64_t k, int64_t c_lo, int64_t c_hi, int64_t min_block);
     void join_on_main();
+    void backward_solve(char* v, char* out);  // L' out = v over the block-rows in reverse (v: rank 0 holds the right-hand side, the others zeros; consumed)
+    template <typename F>
+    void whiten_blocks(int64_t P, int64_t ldR, F visit);  // Rloc_ (P x own columns) <- rows whitened block by block; visit(k) sees V_k (P x WD) in Vk_
+    int whiten_identity_own();                // G1_ <- the own blocks' rows of L^-T (the whitened identity rows; the factor's panels re-gathered)
+    char *Bfull_ = nullptr, *Bc_ = nullptr;
+    int64_t Bfull_cap_ = 0, Bc_cap_ = 0;
+    double* dfull_ = nullptr;
+    int64_t dfull_cap_ = 0;
     int comm_rc_ = 0;
 };
 

@@ -228,6 +228,9 @@ int group_fit(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int64_
 int group_predict(gpmi_gp* gp, const gpmi_kernel* k, int64_t p, const void* xpred, const void* mean_pred, int full_cov, void* mu_out, void* var_out);
 int group_grad(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int64_t n_noise, double* dkern_out, int n_kern, double* dnoise_out);
 int group_factor_diag(gpmi_gp* gp, void* out);
+int group_solve(gpmi_gp* gp, int64_t nrhs, void* b_inout, bool backward);
+int group_inv_diag(gpmi_gp* gp, void* out);
+int group_factor_to_host(gpmi_gp* gp, void* U_out);
 
 // which look-ahead stream set the next factorisation uses: whole CUs (side_masked + upd_stream) or free slots (side_stream).
 // Returns the mode in effect (0 when masks are unavailable).
@@ -355,6 +358,7 @@ void launch_logdiag(gpmi_ctx* ctx, const T* A, int64_t ld, int64_t nrows, int64_
 constexpr int GRAD_MAX_NODES = 32;  // kernel-tree size the device gradient handles (cost grows with leaves^2)
 constexpr int GRAD_MAX_HYP = 64;    // hyper-parameters: (n_hyp + 1) x 256 double accumulators + the 64 x d row points share the 160 KB of LDS
 constexpr int GRAD_MAX_D = 32;      // input dimension (the pair's d squared differences live in registers)
+inline const char* grad_limit_message() { return "gpmi_grad: kernel outside the device gradient path (<= 64 hyper-parameters, d <= 32)"; }
 // A[i][i] = 1, everything else 0 (n x n, row-major)
 template <typename T>
 void launch_set_identity(gpmi_ctx* ctx, T* A, int64_t ld, int64_t n);

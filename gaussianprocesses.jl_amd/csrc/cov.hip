@@ -27,7 +27,7 @@ struct Tr;
 // v_ldexp_f64 (which flushes the underflow to 0 by itself).  |rel. error| < 3e-16 on [-745, 0] (tests/test_gpu_parity.py pins
 // cov! at rtol 1e-12 against the oracle's libm exp).
 __device__ __forceinline__ double exp_nonpos(double x) {
-    x = fmax(x, -750.0);
+    x = (x < -750.0) ? -750.0 : x;  // (not fmax: a NaN input must stay NaN and fail in the factorisation, as in the reference)
     const double kf = rint(x * 1.4426950408889634074);
     double r = fma(kf, -6.93147180369123816490e-01, x);
     r = fma(kf, -1.90821492927058770002e-10, r);

@@ -95,9 +95,10 @@ __global__ __launch_bounds__(1024) void qtrace_kernel(const T* __restrict__ Wt, 
     }
     if (threadIdx.x == 0) trace_acc[0] += sh[0];
 }
+// host scalar all-reduces carry at most this many doubles (the gradient sends n_hyp + 1 <= GRAD_MAX_HYP + 1)
+constexpr int HOST_RED_CAP = 256;
 __global__ void acc_add_kernel(double* __restrict__ out, const double* __restrict__ add, int n) {
-    const int i = threadIdx.x;
-    if (i < n) out[i] += add[i];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] += add[i];
 }
 
 template <typename T>
@@ -218,6 +219,13 @@ struct HipDev : Dev {
         *n_hyp = c->h_prog->n_hyp;
         return GPMI_OK;
     }
+    int grad_limits(int d) override {
+        if (c->h_prog->n_ops > GRAD_MAX_NODES || c->h_prog->n_hyp > GRAD_MAX_HYP || d > GRAD_MAX_D) {
+            err = grad_limit_message();
+            return GPMI_EARG;
+        }
+        return GPMI_OK;
+    }
     void assemble(const void* x, int64_t n, int d, int64_t row_off, int64_t nrows, double nugget, const double* nvec, void* A, int64_t ld,
                   int64_t ncols) override {
         const int64_t na = std::max<int64_t>(0, std::min<int64_t>(nrows, n - row_off));
@@ -306,7 +314,7 @@ struct HipDev : Dev {
         const int64_t nb2 = launch_dmll_rect<T>(c, (const T*)xa, na, (const T*)xb, nb, d, (const T*)Wt, ld, partial, n_hyp);
         double* red = partial + nb2 * (n_hyp + 1);
         launch_reduce_partials(c, partial, nb2, n_hyp + 1, red);
-        hipLaunchKernelGGL(acc_add_kernel, dim3(1), dim3(64), 0, c->stream, out, (const double*)red, n_hyp);
+        hipLaunchKernelGGL(acc_add_kernel, dim3(1), dim3(256), 0, c->stream, out, (const double*)red, n_hyp);
     }
 };
 
@@ -374,8 +382,8 @@ struct RcclComm : Comm {
         return g_rccl.AllReduce(buf, buf, (size_t)count, es == 8 ? 8 : 7, 0, comm, (hipStream_t)stream);
     }
     int host_allreduce(double* vals, int n, int op) override {
-        if (n > 64) return 1;
-        if (!d_tmp && hipMalloc(&d_tmp, 64 * sizeof(double)) != hipSuccess) return 1;
+        if (n > HOST_RED_CAP) return 1;
+        if (!d_tmp && hipMalloc(&d_tmp, HOST_RED_CAP * sizeof(double)) != hipSuccess) return 1;
         hipStream_t s = ctx->stream;
         if (hipMemcpyAsync(d_tmp, vals, (size_t)n * 8, hipMemcpyHostToDevice, s) != hipSuccess) return 1;
         const int rc = g_rccl.AllReduce(d_tmp, d_tmp, (size_t)n, 8, op == 0 ? 0 : (op == 1 ? 3 : 2), comm, s);
@@ -524,14 +532,14 @@ struct LocalComm : Comm {
         return 0;
     }
     int host_allreduce(double* vals, int n, int op) override {
-        if (n > 64) return 1;
+        if (n > HOST_RED_CAP) return 1;
         const int par = (int)(seq++ & 1);
-        for (int i = 0; i < n; ++i) g->hv[par][(size_t)rank * 64 + i] = vals[i];
+        for (int i = 0; i < n; ++i) g->hv[par][(size_t)rank * HOST_RED_CAP + i] = vals[i];
         if (!g->barrier()) return 2;
         for (int i = 0; i < n; ++i) {
             double a = g->hv[par][i];
             for (int q = 1; q < world; ++q) {
-                const double b = g->hv[par][(size_t)q * 64 + i];
+                const double b = g->hv[par][(size_t)q * HOST_RED_CAP + i];
                 a = op == 0 ? a + b : (op == 1 ? (b < a ? b : a) : (b > a ? b : a));
             }
             vals[i] = a;
@@ -573,7 +581,7 @@ int group_create(gpmi_ctx* primary, int n, const int* ids) {
         g->ptr[par].assign((size_t)n, nullptr);
         g->ready[par].assign((size_t)n, nullptr);
         g->done[par].assign((size_t)n, nullptr);
-        g->hv[par].assign((size_t)n * 64, 0.0);
+        g->hv[par].assign((size_t)n * HOST_RED_CAP, 0.0);
     }
     // direct peer copies between distinct devices (errors are not fatal: the runtime then stages through the host)
     for (int a = 0; a < n; ++a)
@@ -609,6 +617,9 @@ template <typename F>
 static int group_run(GroupHandle* h, F f) {
     LocalGroup* g = h->g;
     g->reset();
+    // a member that left the previous call early (EDEVICE / EARG -> abort) has issued fewer collectives than the others: every
+    // call starts from the same slot parity again (all streams were drained when the previous call returned)
+    for (auto& cm : h->comms) cm->seq = 0;
     std::vector<int> rc((size_t)g->n, GPMI_OK);
     auto body = [&](int r) {
         (void)hipSetDevice(g->members[(size_t)r]->device);
@@ -715,6 +726,31 @@ int group_factor_diag(gpmi_gp* gp, void* out) {
     std::vector<std::vector<char>> tmp((size_t)h->g->n);
     for (int r = 1; r < h->g->n; ++r) tmp[(size_t)r].resize((size_t)gp->n * es);
     return group_run(h, [&](int r) { return h->ranks[(size_t)r]->gp->factor_diag(r == 0 ? out : (void*)tmp[(size_t)r].data()); });
+}
+// the AbstractPDMat surface: every member receives the same right-hand sides and produces the (replicated) result; the members other than
+// rank 0 work on copies
+int group_solve(gpmi_gp* gp, int64_t nrhs, void* b, bool backward) {
+    GroupHandle* h = (GroupHandle*)gp->group;
+    const size_t bytes = (size_t)gp->n * (size_t)nrhs * (gp->dtype == 64 ? 8 : 4);
+    std::vector<std::vector<char>> tmp((size_t)h->g->n);
+    for (int r = 1; r < h->g->n; ++r) tmp[(size_t)r].assign((const char*)b, (const char*)b + bytes);
+    return group_run(h, [&](int r) { return h->ranks[(size_t)r]->gp->solve(nrhs, r == 0 ? b : (void*)tmp[(size_t)r].data(), backward); });
+}
+int group_inv_diag(gpmi_gp* gp, void* out) {
+    GroupHandle* h = (GroupHandle*)gp->group;
+    const size_t es = gp->dtype == 64 ? 8 : 4;
+    std::vector<std::vector<char>> tmp((size_t)h->g->n);
+    for (int r = 1; r < h->g->n; ++r) tmp[(size_t)r].resize((size_t)gp->n * es);
+    return group_run(h, [&](int r) { return h->ranks[(size_t)r]->gp->inv_diag(r == 0 ? out : (void*)tmp[(size_t)r].data()); });
+}
+int group_factor_to_host(gpmi_gp* gp, void* U_out) {
+    GroupHandle* h = (GroupHandle*)gp->group;
+    const size_t es = gp->dtype == 64 ? 8 : 4;
+    // ONE scratch image shared by the members other than rank 0 would race; each gets its own (n x n on the host: this entry point is for
+    // inspection at sizes where that is affordable — the factor of a large model stays on the devices)
+    std::vector<std::vector<char>> tmp((size_t)h->g->n);
+    for (int r = 1; r < h->g->n; ++r) tmp[(size_t)r].resize((size_t)gp->n * (size_t)gp->n * es);
+    return group_run(h, [&](int r) { return h->ranks[(size_t)r]->gp->factor_to_host(r == 0 ? U_out : (void*)tmp[(size_t)r].data()); });
 }
 
 }  // namespace gpmi

@@ -23,7 +23,7 @@ import os
 import numpy as np
 
 from . import _lib
-from .gpe import GPE
+from .gpe import GPE, HIPPDMat
 
 
 def default_block(n):
@@ -190,9 +190,10 @@ def rccl_comm(ctx):
     return RcclComm(ctx, 0, 1, exchange_id=lambda b: b)
 
 
-class BlockedPDMat:
-    """gp.cK of a blocked model: the gpmi_gp handle made by gpmi_gp_create_blocked (AbstractPDMat surface: logdet,
-    diag(cholfactors); `\\` and whiten! are not provided on a blocked handle)."""
+class BlockedPDMat(HIPPDMat):
+    """gp.cK of a blocked model: the gpmi_gp handle made by gpmi_gp_create_blocked.  The AbstractPDMat surface is HIPPDMat's — `\\`
+    (solve), whiten!, logdet, diag(inv(cK)), diag(cholfactors), cholfactors all answer on a blocked handle (results replicated on
+    every rank; cholfactors gathers the n x n factor on the host: for inspection at sizes where that is affordable)."""
 
     def __init__(self, ctx, x_colmajor, bits, comm=None, block=0, stripe_blocks=0):
         self.ctx, self.bits, self.comm = ctx, bits, comm
@@ -205,24 +206,6 @@ class BlockedPDMat:
         br, ns, fb = C.c_int64(), C.c_int32(), C.c_int64()
         ctx.check(_lib.load().gpmi_gp_blocked_info(h, C.byref(br), C.byref(ns), C.byref(fb)))
         self.block_rows, self.nstripes, self.factor_bytes = br.value, ns.value, fb.value
-
-    def __del__(self):
-        try:
-            if getattr(self, "h", None) and self.ctx.h:
-                _lib.load().gpmi_gp_destroy(self.h)
-                self.h = None
-        except Exception:  # noqa: BLE001
-            pass
-
-    def logdet(self):
-        out = C.c_double()
-        self.ctx.check(_lib.load().gpmi_logdet(self.h, C.byref(out)))
-        return out.value
-
-    def factor_diag(self):
-        out = np.empty(self.n, dtype=_lib.np_dtype(self.bits))
-        self.ctx.check(_lib.load().gpmi_factor_diag(self.h, out.ctypes.data))
-        return out
 
 
 class ShardedGPE(GPE):

@@ -145,6 +145,12 @@ class GPE:
         dt = _lib.np_dtype(self.bits)
         mu = self.mean.mean(self.x)
         ymu = np.ascontiguousarray(self.y - mu, dtype=dt)
+        if not (kern or noise) and self.alpha is not None:
+            # GPE.jl:203-211: only the mean changed — the factor is kept: alpha = cK \ (y - mu), mll from the stored logdet
+            self.alpha = self.cK.solve(ymu)
+            self.mll = -0.5 * (float(np.dot(np.asarray(ymu, dtype=np.float64), np.asarray(self.alpha, dtype=np.float64))) + self.cK.logdet()
+                               + self.nobs * 1.8378770664093453)
+            return self
         ln = np.atleast_1d(np.asarray(self.logNoise, dtype=np.float64))
         if ln.shape[0] not in (1, self.nobs):
             raise _lib.ArgumentError("logNoise must be a scalar or have one entry per observation")

@@ -99,8 +99,10 @@ withkernel(f, kd::KernelDesc) = GC.@preserve kd f(Ref(CKernel(length(kd.ops), po
 # HIPCovariance(comm=rccl_comm(...))   the factor row-block sharded over the ranks of a communicator: one Julia process per GPU
 #                                      (MPI.jl / Distributed launch), every rank runs the same script on the same data and gets the
 #                                      same mll / alpha / predictions / gradient back
-# update_mll!, update_dmll! / optimize!, predict_f (both full_cov branches) and predict_y work on all three; `\`, whiten!, tr,
-# Matrix(cK) are dense-only (libgpmi returns GPMI_EARG -> ArgumentError on a blocked handle).
+# update_mll!, update_dmll! / optimize!, predict_f (both full_cov branches), predict_y and the AbstractPDMat surface (`\`, ldiv!,
+# whiten!, predict_LOO's diag(inv(cK)), cholfactors / Matrix / tr) work on all three: libgpmi answers gpmi_solve / gpmi_whiten /
+# gpmi_inv_diag / gpmi_factor_to_host on blocked handles as well (results replicated on every rank; cholfactors gathers the whole
+# n x n factor on the host, so Matrix / tr / unwhiten! are for sizes where that is affordable).
 struct HIPCovariance <: CovarianceStrategy
     packed::Bool
     sharded::Bool         # a blocked handle without packing: on a device-group context (GPMI_DEVICES) one rank per GPU
@@ -149,7 +151,9 @@ Base.size(a::HIPPDMat) = (a.n, a.n); Base.size(a::HIPPDMat, i::Int) = a.n; dim(a
 # (every optimiser / MCMC step) reuse the resident x and buffers.  Identity alone would miss `gp.x .= ...` or an elastic
 # array grown in place: the number of observations and a content checksum (O(N d), negligible next to the O(N^2) cov!)
 # are compared as well, so a mutated x is re-uploaded instead of silently reusing the stale device copy.
-xchecksum(x::AbstractMatrix) = hash(x)
+# (Base.hash(::AbstractArray) only SAMPLES arrays of 8192+ elements, so it would miss most in-place edits at the sizes this
+# library is for: every element is folded in)
+xchecksum(x::AbstractMatrix) = foldl((h, v) -> hash(v, h), x; init = hash(size(x)))
 function ensure_handle!(a::HIPPDMat, x::AbstractMatrix)
     if a.handle == C_NULL || a.xref !== x || size(x, 2) != a.n || xchecksum(x) != a.xsum
         a.handle == C_NULL || ccall((:gpmi_gp_destroy, libgpmi), Cvoid, (Ptr{Cvoid},), a.handle)

@@ -179,8 +179,10 @@ GPMI_API int gpmi_fitc_grad(gpmi_fitc*, const gpmi_kernel*, double log_noise, do
  *     upper triangle is never allocated: N^2 (1 + 1/S) / 2 elements instead of alloc_cK's two N x N (src/GP.jl:14-20).
  * comm == NULL: one rank (a single device past the N x N ceiling: N = 250 000 fp64 on 288 GB) — or, when ctx is a device
  * group (gpmi_ctx_create with n_devices > 1), one rank per device of the group.  gpmi_grad on a blocked
- * handle needs ONE more own-rows x N matrix (N^2 / world) instead of two N x N.  gpmi_solve / gpmi_whiten / gpmi_inv_diag /
- * gpmi_factor_to_host are not provided on a blocked handle (GPMI_EARG).                                                  */
+ * handle needs ONE more own-rows x N matrix (N^2 / world) instead of two N x N; gpmi_inv_diag uses the same scratch.  The
+ * AbstractPDMat surface (gpmi_solve / gpmi_whiten / gpmi_inv_diag / gpmi_factor_to_host) answers on a blocked handle too: every
+ * rank passes the same right-hand sides and receives the same results (gpmi_factor_to_host gathers the whole n x n factor on
+ * every rank's host: for inspection at sizes where that is affordable).                                                  */
 typedef struct gpmi_comm gpmi_comm;
 /* Collectives on DEVICE buffers, to be enqueued on the HIP stream passed as `stream` (ordered after the work already on it;
  * later work on it must see the result); host_allreduce reduces n host doubles in place (op 0 sum, 1 min, 2 max).

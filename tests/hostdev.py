@@ -306,6 +306,9 @@ class HostBlockedGP:
         L.hostdev_predict.argtypes = [vp, i64, vp, vp, ci, vp, vp]
         L.hostdev_grad.argtypes = [vp, pd, i64, pd, ci, pd]
         L.hostdev_factor_diag.argtypes = [vp, vp]
+        L.hostdev_solve.argtypes = [vp, i64, vp, ci]
+        L.hostdev_inv_diag.argtypes = [vp, vp]
+        L.hostdev_factor_to_host.argtypes = [vp, vp]
         L.hostdev_logdet.restype = dbl
         L.hostdev_logdet.argtypes = [vp]
         L.hostdev_block_rows.restype = i64
@@ -373,6 +376,32 @@ class HostBlockedGP:
         out = np.empty(self.n)
         self._check(self.lib.hostdev_factor_diag(self.h, out.ctypes.data))
         return out
+
+    # AbstractPDMat surface of the blocked handle (b: n or n x nrhs, column-major like Julia's)
+    def _rhs(self, b):
+        b = np.array(b, dtype=np.float64, order="F", copy=True)
+        assert b.shape[0] == self.n
+        return b, (1 if b.ndim == 1 else b.shape[1])
+
+    def solve(self, b):
+        b, nrhs = self._rhs(b)
+        self._check(self.lib.hostdev_solve(self.h, nrhs, b.ctypes.data, 1))
+        return b
+
+    def whiten(self, b):
+        b, nrhs = self._rhs(b)
+        self._check(self.lib.hostdev_solve(self.h, nrhs, b.ctypes.data, 0))
+        return b
+
+    def inv_diag(self):
+        out = np.empty(self.n)
+        self._check(self.lib.hostdev_inv_diag(self.h, out.ctypes.data))
+        return out
+
+    def cholfactors(self):
+        U = np.empty((self.n, self.n), order="F")
+        self._check(self.lib.hostdev_factor_to_host(self.h, U.ctypes.data))
+        return U
 
     @property
     def block_rows(self):

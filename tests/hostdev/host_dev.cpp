@@ -55,6 +55,13 @@ struct HostDev : Dev {
         *kdiag = ops.kdiag(n_hyp);
         return GPMI_OK;
     }
+    int grad_limits(int d) override {  // the device gradient's input-dimension limit (common.h GRAD_MAX_D), so the driver's refusal path runs on the host too
+        if (d > 32) {
+            err = "gpmi_grad: kernel outside the device gradient path (<= 64 hyper-parameters, d <= 32)";
+            return GPMI_EARG;
+        }
+        return GPMI_OK;
+    }
     void assemble(const void* x, int64_t n, int d, int64_t row_off, int64_t nrows, double nugget, const double* nvec, void* A, int64_t ld,
                   int64_t ncols) override {
         ops.assemble((const double*)x, n, d, row_off, nrows, nugget, nvec, (double*)A, ld, ncols);
@@ -170,6 +177,9 @@ int hostdev_grad(void* p, const double* log_noise, int64_t n_noise, double* dker
     return ((HostGP*)p)->gp->grad(&k, log_noise, n_noise, dkern, n_kern, dnoise);
 }
 int hostdev_factor_diag(void* p, double* out) { return ((HostGP*)p)->gp->factor_diag(out); }
+int hostdev_solve(void* p, int64_t nrhs, double* b, int backward) { return ((HostGP*)p)->gp->solve(nrhs, b, backward != 0); }
+int hostdev_inv_diag(void* p, double* out) { return ((HostGP*)p)->gp->inv_diag(out); }
+int hostdev_factor_to_host(void* p, double* U) { return ((HostGP*)p)->gp->factor_to_host(U); }
 double hostdev_logdet(void* p) { return ((HostGP*)p)->gp->logdet(); }
 int64_t hostdev_block_rows(void* p) { return ((HostGP*)p)->gp->block_rows(); }
 int hostdev_nstripes(void* p) { return ((HostGP*)p)->gp->nstripes(); }

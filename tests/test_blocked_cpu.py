@@ -56,6 +56,25 @@ def _check_all(gp, x, y, xs, spec=SPEC, ln=LN, grad=True):
         d = G.update_dmll(spec, x, y, ln, MEAN, fit=ref)
         np.testing.assert_allclose(gp.dkern, d["dkern"], rtol=1e-8, atol=1e-9 * np.abs(d["dkern"]).max())
         assert abs(gp.dnoise - d["dnoise"]) <= 1e-8 * abs(d["dnoise"])
+        _check_pdmat(gp, ref, y)
+
+
+def _check_pdmat(gp, ref, y):
+    """the AbstractPDMat surface of a blocked handle (gpmi_solve / gpmi_whiten / gpmi_inv_diag / gpmi_factor_to_host) against LAPACK on
+    the oracle's factor: `\\` with one and with several right-hand sides, whiten!, diag(inv(cK)) (predict_LOO), cholfactors"""
+    import scipy.linalg as sla
+
+    U = np.triu(ref["U"])
+    n = U.shape[0]
+    rng = np.random.default_rng(3)
+    B = rng.standard_normal((n, 3))
+    np.testing.assert_allclose(gp.cholfactors(), U, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(gp.whiten(B), sla.solve_triangular(U, B, trans="T", lower=False), rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(gp.solve(B), sla.cho_solve((U, False), B), rtol=1e-7, atol=1e-9 * np.abs(B).max())
+    # update_mll!(kern = false, noise = false) is `cK \ (y - mu)` on the kept factor (GPE.jl:204-208)
+    np.testing.assert_allclose(gp.solve(y - MEAN[1]), ref["alpha"], rtol=1e-7, atol=1e-9)
+    Kinv = sla.cho_solve((U, False), np.eye(n))
+    np.testing.assert_allclose(gp.inv_diag(), np.diag(Kinv), rtol=1e-8)
 
 
 @pytest.mark.parametrize("n,block,stripes", [(300, 0, 0), (1100, 256, 2), (1900, 512, 0), (2100, 256, 3)])
@@ -73,6 +92,20 @@ def test_one_rank(n, block, stripes):
     gp.set_spec(spec2, LN + 0.05)
     gp.update_mll()
     _check_all(gp, x, y, xs, spec2, LN + 0.05, grad=False)
+    gp.close()
+
+
+def test_gradient_refused_beyond_the_device_limit_on_a_blocked_handle():
+    """a blocked handle accepts d up to 64, the device gradient only d <= 32 — the blocked gradient must refuse
+    (GPMI_EARG, the dense path's message) instead of running a kernel whose distance loop stops at 32"""
+    rng = np.random.default_rng(2)
+    n, d = 300, 40
+    x = rng.uniform(size=(d, n))
+    y = rng.standard_normal(n)
+    gp = H.HostBlockedGP(("se_iso", 0.3, 0.0), x, y, LN)
+    with pytest.raises(RuntimeError, match="outside the device gradient path"):
+        gp.update_dmll()
+    gp.update_mll()  # the handle stays usable
     gp.close()
 
 

