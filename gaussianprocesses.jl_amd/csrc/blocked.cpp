@@ -115,9 +115,9 @@ int BlockedGP::init(const void* x_host) {
     if (G_ == 1) {
         take(&S_[1], srows * ldP_ * es_, true);  // one rank: the solved image IS the panel in global order; two of them alternate
     } else {
-        take(&Praw_, (int64_t)G_ * maxown_ * WD_ * ldP_ * es_, false);
-        take(&P_[0], npad_ * ldP_ * es_, true);
-        take(&P_[1], npad_ * ldP_ * es_, true);
+        const int64_t prow = (int64_t)maxown_ * G_ * WD_;  // whole groups of G blocks: the gather of the last group may run past npad
+        take(&P_[0], prow * ldP_ * es_, true);
+        take(&P_[1], prow * ldP_ * es_, true);
     }
     if (!ok) return fail(GPMI_EDEVICE, "blocked GP: out of device memory (" + dev_->err + ")");
     dev_->upload(x_, x_host, n_ * d_ * es_);
@@ -208,17 +208,19 @@ void BlockedGP::solve_and_gather(int64_t k, bool from_factor) {
     if (G_ == 1 || k + 1 >= nblk_) return;
     dev_->use(DS_COMM);
     dev_->wait(ev_sr);
-    int maxsend = 0;
-    for (int q = 0; q < G_; ++q) maxsend = std::max(maxsend, n_below(q, k));
-    const int64_t each = (int64_t)maxsend * WD_ * ldP_ * es_;
-    comm_rc_ |= comm_->all_gather(S, Praw_, each, dev_->native_stream());
+    // straight into P_k in GLOBAL row order, no staging copy: block b lives on rank b mod G, so the G blocks [g G, (g + 1) G) are one
+    // equal-size all-gather whose slot order IS the global order — one collective per group of G blocks (a communicator that can
+    // fuses them: Comm::group_begin / group_end = ncclGroupStart / End).  A rank whose block of the group is not below k (the first
+    // group) or past the end (the last) contributes a block of its send buffer that nobody reads.
     char* P = P_[k & 1];
-    for (int q = 0; q < G_; ++q) {
-        const int cnt = n_below(q, k);
-        if (cnt == 0) continue;
-        const int64_t first = (int64_t)n_le(q, k) * G_ + q;  // rank q's first block below k (global index)
-        dev_->copy2d(P + first * WD_ * ldP_ * es_, (int64_t)G_ * WD_ * ldP_ * es_, Praw_ + (int64_t)q * each, WD_ * ldP_ * es_, WD_ * ldP_ * es_, cnt);
+    const int64_t blk = WD_ * ldP_ * es_;
+    comm_->group_begin();
+    for (int64_t g = (k + 1) / G_; g * G_ < nblk_; ++g) {
+        const int64_t b = g * G_ + rank_;  // my block of this group; its local index is g
+        const char* send = (b > k && b < nblk_) ? S + (g - nle) * blk : S;
+        comm_rc_ |= comm_->all_gather(send, P + g * G_ * blk, blk, dev_->native_stream());
     }
+    comm_rc_ |= comm_->group_end();
     ev_p_ = dev_->record();
 }
 

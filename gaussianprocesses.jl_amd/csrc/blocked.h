@@ -64,7 +64,7 @@ class BlockedGP {
     std::vector<void*> allocs_;
     int64_t stored_bytes_ = 0;
     char *x_ = nullptr, *LW_ = nullptr, *linv_ = nullptr, *invd_ = nullptr, *alpha_ = nullptr, *v_ = nullptr, *ymu_ = nullptr, *seg_ = nullptr;
-    char *S_[2] = {nullptr, nullptr}, *Praw_ = nullptr, *P_[2] = {nullptr, nullptr};
+    char *S_[2] = {nullptr, nullptr}, *P_[2] = {nullptr, nullptr};
     double* noise_ = nullptr;
     // predict / gradient scratch, grown on demand
     char *xp_ = nullptr, *Rloc_ = nullptr, *Vk_ = nullptr, *small_ = nullptr, *Kpp_ = nullptr, *aloc_ = nullptr, *xloc_ = nullptr;

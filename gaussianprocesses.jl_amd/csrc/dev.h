@@ -102,6 +102,9 @@ struct Comm {
     virtual int all_gather(const void* send, void* recv, int64_t bytes_each, void* stream) = 0;  // recv: world x bytes_each
     virtual int all_reduce_sum(void* buf, int64_t count, int es, void* stream) = 0;              // es 8: double, 4: float
     virtual int host_allreduce(double* vals, int n, int op /*0 sum, 1 min, 2 max*/) = 0;
+    // a run of collectives on one stream that the transport may fuse into one launch (RCCL: ncclGroupStart / ncclGroupEnd)
+    virtual void group_begin() {}
+    virtual int group_end() { return 0; }
 };
 
 }  // namespace gpmi

@@ -329,6 +329,8 @@ struct Rccl {
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     std::string err;
     bool load() {
         if (lib) return true;
@@ -353,6 +355,8 @@ struct Rccl {
         AllGather = (decltype(AllGather))sym("ncclAllGather");
         AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
         GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");  // optional: without them the gathers of a step go out one by one
+        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
         if (!GetUniqueId || !CommInitRank || !CommDestroy || !Broadcast || !AllGather || !AllReduce) {
             err = "librccl.so lacks an nccl* entry point";
             return false;
@@ -378,6 +382,10 @@ struct RcclComm : Comm {
     int all_gather(const void* send, void* recv, int64_t bytes_each, void* stream) override {
         return g_rccl.AllGather(send, recv, (size_t)bytes_each, 0, comm, (hipStream_t)stream);
     }
+    void group_begin() override {
+        if (g_rccl.GroupStart && g_rccl.GroupEnd) (void)g_rccl.GroupStart();
+    }
+    int group_end() override { return (g_rccl.GroupStart && g_rccl.GroupEnd) ? g_rccl.GroupEnd() : 0; }
     int all_reduce_sum(void* buf, int64_t count, int es, void* stream) override {
         return g_rccl.AllReduce(buf, buf, (size_t)count, es == 8 ? 8 : 7, 0, comm, (hipStream_t)stream);
     }
