@@ -127,6 +127,32 @@ def _cpu_fit_predict(n, d, p, ll):
     return {"cov": t1 - t0, "dpotrf": t2 - t1, "dpotrs_mll": t3 - t2, "predict": t4 - t3}, t4 - t0, mll, mu, s2
 
 
+def _numpy_cov_seconds(n, d, ll, rows=2048):
+    """SURVEY 8(d)'s SECOND cov! figure: the vectorised-NumPy variant beside the reference-order scalar loop.  K = s2 exp(-r/2) with
+    r = |x_i / l - x_j / l|^2 by the BLAS expansion, in row panels of `rows` (the whole N x N would be a second 20 GB matrix); timed on
+    min(n, 16384) rows and scaled to N^2 — it is O(N^2) streaming work, stated as scaled."""
+    import numpy as _np
+
+    rng = _np.random.default_rng(1)
+    x = rng.uniform(size=(n, d)) / _np.exp(_np.asarray(ll))[None, :]
+    sq = (x * x).sum(axis=1)
+    nrows = min(n, 16384)
+    out = _np.empty((rows, n))
+    t0 = time.perf_counter()
+    for r0 in range(0, nrows, rows):
+        r1 = min(r0 + rows, nrows)
+        o = out[: r1 - r0]
+        _np.matmul(x[r0:r1], x.T, out=o)
+        o *= -2.0
+        o += sq[r0:r1, None]
+        o += sq[None, :]
+        _np.maximum(o, 0.0, out=o)
+        o *= -0.5
+        _np.exp(o, out=o)
+    el = time.perf_counter() - t0
+    return el * (n / nrows), nrows
+
+
 def cpu_baseline(n_bench, d, p, ll, budget_s):
     """The oracle MEASURED at the bench size when a probe says it fits `budget_s`, otherwise at N = 20 000 (stated).
     Nothing is scaled: `value` is 1 / (measured seconds) of the run named in `sample`."""
@@ -150,6 +176,10 @@ def cpu_baseline(n_bench, d, p, ll, budget_s):
         why = (f" (the bench size N={n_bench} was estimated at {est:.0f} s from a N={probe_n} probe / needs {need_gb:.0f} GB of "
                f"host RAM, over the {budget_s:.0f} s budget: measured at N={n_meas} instead — NOT the bench size)")
     st, tot, mll, mu, s2 = _cpu_fit_predict(n_meas, d, p, ll)
+    try:
+        np_cov_s, np_rows = _numpy_cov_seconds(n_meas, d, ll)
+    except Exception:  # noqa: BLE001
+        np_cov_s, np_rows = None, 0
     return {
         "_mu": mu,       # popped by main() before printing: the oracle's predictions for the `parity` object
         "_s2": s2,
@@ -162,6 +192,13 @@ def cpu_baseline(n_bench, d, p, ll, budget_s):
         "cpu_model": model,
         "blas": blas,
         "stage_s": st,
+        # "also report a vectorised-NumPy variant" of cov! — the 12 s single-threaded loop is the REFERENCE's behaviour
+        # (kernels.jl:39-50), not the best a CPU can do: with it the fit+predict would take `total_s_with_numpy_cov`
+        "cov_numpy_vectorised_s": np_cov_s,
+        "cov_numpy_note": (f"K = exp(-|xi - xj|^2 / 2) by the BLAS expansion in 2048-row panels on the host's BLAS threads, timed on {np_rows} rows "
+                           f"and scaled to N^2 (streaming O(N^2) work)") if np_cov_s is not None else None,
+        "total_s_with_numpy_cov": (tot - st["cov"] + np_cov_s) if np_cov_s is not None else None,
+        "fits_per_sec_with_numpy_cov": (1.0 / (tot - st["cov"] + np_cov_s)) if np_cov_s is not None else None,
         "mll": mll,
         "sample": (f"ONE oracle fit+predict MEASURED at N={n_meas} d={d} P={p} SEArd fp64 in {tot:.2f} s: cov! single-threaded C "
                    f"loop (like the reference's) {st['cov']:.2f} s, LAPACK dpotrf {st['dpotrf']:.2f} s on {nthreads} BLAS "
@@ -201,6 +238,7 @@ def run_workload(g, ctx, n, d, p, dtype, steps, warmup, barrier, comm=None, shar
     # the constructor's fit is at the BASE hyper-parameters — the ones the cpu_baseline oracle run uses: keep its mll and
     # predictions so that the JSON line carries full-size parity (main(): `parity`)
     base_mll = gp.mll
+    base_alpha = np.asarray(gp.alpha, dtype=np.float64).copy()
     base_mu, base_s2 = gp.predict_f(xpred)
 
     wall = {"fit": 0.0, "predict": 0.0}
@@ -249,7 +287,8 @@ def run_workload(g, ctx, n, d, p, dtype, steps, warmup, barrier, comm=None, shar
     assert np.all(np.isfinite(mu)) and np.all(np.isfinite(s2)) and math.isfinite(gp.mll)
     return {"elapsed": elapsed, "prof": prof, "syrk_bytes": syrk_bytes, "t_build": t_build, "mll": gp.mll, "ll": ll,
             "fit_ms": 1e3 * wall["fit"] / steps, "predict_ms": 1e3 * wall["predict"] / steps,
-            "base_mll": base_mll, "base_mu": np.asarray(base_mu, dtype=np.float64), "base_s2": np.asarray(base_s2, dtype=np.float64)}
+            "base_mll": base_mll, "base_mu": np.asarray(base_mu, dtype=np.float64), "base_s2": np.asarray(base_s2, dtype=np.float64),
+            "base_alpha": base_alpha}
 
 
 def roofline_object(args, res, n, d, p, dtype, steps):
@@ -323,6 +362,26 @@ def parity_object(res, cpu, n, dtype):
 C3_SPEC_NOTE = "Sum(Sum(SEArd, Mat52Iso), Noise)"
 
 
+def sparse_probe_parity(res, n, d, p, tol):
+    """`parity` of a fit too large for a host factorisation (C4: N = 200 000): the device's alpha at the base hyper-parameters must
+    satisfy (K + s2 I) alpha = y on 512 random rows of K REBUILT by the fp64 oracle, and mu = K*' alpha on 64 test points rebuilt the
+    same way (the checks of tests/test_gpu_fullsize.py::test_c4_fp32_n200000..., inside the driver's own run)."""
+    from oracle import gp_oracle as G
+
+    x, y, xpred = synthetic_inputs(n, d, p)
+    spec = ("se_ard", _ll(d), 0.0)
+    nv = math.exp(2.0 * math.log(0.1))
+    a = res["base_alpha"]
+    rows = np.sort(np.random.default_rng(7).choice(n, 512, replace=False))
+    r = G.cov(spec, x[:, rows], x) @ a + nv * a[rows] - y[rows]
+    resid = float(np.abs(r).max() / np.abs(y).max())
+    mu_o = G.cov(spec, xpred[:, :64], x) @ a
+    mu_err = float(np.abs(res["base_mu"][:64] - mu_o).max() / max(np.abs(mu_o).max(), 1e-300))
+    return {"checked": True, "what": "solve residual |(K + s2 I) alpha - y| / max|y| on 512 oracle-rebuilt rows; mu = K*' alpha on 64 oracle-rebuilt "
+                                     "test points", "residual_over_max_abs_y": resid, "mu_max_err_over_max_abs": mu_err, "tol": tol,
+            "ok": bool(resid <= tol and mu_err <= tol)}
+
+
 def run_c3(g, ctx, steps=3):
     """BASELINE configs[2]: N = 50 000, d = 8, (SEArd + Mat52Iso) + Noise, fp64 — the composite-kernel cov! path."""
     import gc
@@ -354,6 +413,27 @@ def run_c3(g, ctx, steps=3):
     }
 
 
+def directional_parity(gp, h=1e-3, tol=1e-4):
+    """`parity` of a gradient at full size: the analytic directional derivative dmll . v against the central difference of the
+    device mll (itself oracle-checked in `parity` / the -m gpu tests) along a fixed direction v over ALL parameters
+    [logNoise; kernel...] — two extra fits (test/kernels.jl:148-164 checks dtarget against a finite difference the same way)."""
+    base = np.asarray(gp.get_params(), dtype=np.float64)
+    grad = np.asarray(gp.dmll, dtype=np.float64).copy()
+    rng = np.random.default_rng(123)
+    v = rng.uniform(0.5, 1.0, size=base.shape) * np.where(rng.uniform(size=base.shape) < 0.5, -1.0, 1.0)
+    f = []
+    for sgn in (1.0, -1.0):
+        gp.set_params(base + sgn * h * v)
+        gp.update_mll()
+        f.append(gp.mll)
+    gp.set_params(base)
+    fd = (f[0] - f[1]) / (2.0 * h)
+    an = float(grad @ v)
+    rel = abs(an - fd) / max(abs(fd), 1e-300)
+    return {"checked": True, "what": "dmll . v vs central difference of the device mll along a fixed direction over all parameters",
+            "h": h, "analytic": an, "central_difference": fd, "rel_err": rel, "tol": tol, "ok": bool(rel <= tol)}
+
+
 def run_grad(g, ctx, n=50000, d=8):
     """update_dmll! (src/GPE.jl:298-324) at the bench size: K^-1 via the whitened identity + the fused dK/dtheta trace pass."""
     import gc
@@ -373,6 +453,7 @@ def run_grad(g, ctx, n=50000, d=8):
         "frac_of_fp64_matrix_peak": fl / el * 1e-12 / FP64_MFMA_PEAK_TFLOPS,
         "mll": gp.mll,
         "dmll_inf_norm": float(np.abs(gp.dmll).max()),
+        "parity": directional_parity(gp),
     }
 
 
@@ -403,6 +484,8 @@ def run_c5(g, ctx, n=1000000, m=4096, d=8):
     t_grad = time.perf_counter() - t0
     assert np.all(np.isfinite(mu)) and np.all(var >= 0) and math.isfinite(gp.mll)
     fl = 2.0 * n * float(m) * m           # W = Kfu Luu^-T (n m^2) + U'U'^T (n m^2)
+    mll_timed, dinf = gp.mll, float(np.abs(gp.dmll).max())
+    par = directional_parity(gp)
     return {
         "workload": f"FITC N={n}, M={m}, d={d}, SEArd + MeanZero, f64 (BASELINE.json configs[4])",
         "first_fit_incl_alloc_upload_s": t_first,
@@ -412,8 +495,9 @@ def run_c5(g, ctx, n=1000000, m=4096, d=8):
         "predict_f_1024_ms": 1e3 * t_pred,
         "update_dmll_s": t_grad,
         "mll_base_params": mll0,
-        "mll": gp.mll,
-        "dmll_inf_norm": float(np.abs(gp.dmll).max()),
+        "mll": mll_timed,
+        "dmll_inf_norm": dinf,
+        "parity": par,
     }
 
 
@@ -618,6 +702,7 @@ def main():
                 "fits_per_sec": 1.0 / c4_el,
                 "chol_equiv_TFLOPs": (200000.0 ** 3 / 3.0) / c4_el * 1e-12,
                 "mll": c4["mll"],
+                **({"parity": sparse_probe_parity(c4, 200000, 16, 1024, 1e-2)} if rank == 0 else {}),
             }
         except KeyError:
             pass

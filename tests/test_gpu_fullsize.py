@@ -257,10 +257,11 @@ def test_c3_n50000_composite_direct_vs_oracle():
 
 
 def test_c4_fp32_n200000_d16_properties_at_full_size():
-    """BASELINE configs[3]'s size — N = 200 000, d = 16, SEArd, fp32 (160 GB factor on ONE device): the fp64 counterpart
-    (320 GB) exists nowhere, so parity is through size-independent properties evaluated by the fp64 oracle on sparse
-    probes: the solve residual (K + s2 I) alpha = y on 512 rows, the factor identity |L^-1 K v|^2 = v'Kv, the leading 4096
-    pivots against LAPACK in fp64, logdet from the fetched diagonal, mll from its parts, mu = K*' alpha; bar 1e-2 (fp32)."""
+    """BASELINE configs[3]'s size — N = 200 000, d = 16, SEArd, fp32 (160 GB factor on ONE device).  Size-independent properties
+    evaluated by the fp64 oracle on sparse probes — the solve residual (K + s2 I) alpha = y on 512 rows, the factor identity
+    |L^-1 K v|^2 = v'Kv, the leading 4096 pivots against LAPACK in fp64, logdet from the fetched diagonal, mll from its parts,
+    mu = K*' alpha — and (round 4) mll / alpha / mu / s2 DIRECTLY against the fp64 fit of the same model in packed storage
+    (~180 GB), for the dense fp32 handle and for the blocked fp32 handle; bar 1e-2 (fp32)."""
     _free_device_memory()
     n, d = 200000, 16
     x, y, xs = G.synthetic_inputs(n, d, p=256)
@@ -295,3 +296,29 @@ def test_c4_fp32_n200000_d16_properties_at_full_size():
     # predictions at training inputs reproduce the data within the noise (test/gp.jl:47-50)
     mu_t, _ = gp.predict_f(x[:, :128])
     np.testing.assert_allclose(mu_t, y[:128], atol=0.5)
+    mll32, mu32, s232 = gp.mll, np.array(mu), np.array(s2)
+    del gp
+    _free_device_memory()
+    # (round 4) the same model through the BLOCKED fp32 handle — the per-rank code of the 8-GPU run — on one rank
+    from gpmi355x import dist as gd
+
+    gb = gd.ShardedGPE(x, y, g.MeanZero(), g.from_spec(spec), log_noise, dtype=np.float32)
+    mub, s2b = gb.predict_f(xs)
+    mllb, ab = gb.mll, np.asarray(gb.alpha, dtype=np.float64)
+    del gb
+    _free_device_memory()
+    # ... and DIRECTLY against fp64 at this size: packed storage holds N = 200 000 fp64 in ~180 GB on the one device (the dense fp64
+    # matrix would need 320 GB); the fp64 fit certifies itself by its solve residual on the oracle-rebuilt rows
+    g64 = g.GP(x, y, g.MeanZero(), g.from_spec(spec), log_noise, packed=True, stripe_blocks=8)
+    a64 = np.asarray(g64.alpha, dtype=np.float64)
+    r64 = G.cov(spec, x[:, rows], x) @ a64 + nv * a64[rows] - y[rows]
+    assert np.abs(r64).max() <= 1e-8 * np.abs(y).max()
+    mu64, s264 = g64.predict_f(xs)
+    print(f"[C4 N=200000 d=16] mll fp32 dense {mll32:.3f} / fp32 blocked {mllb:.3f} / fp64 packed {g64.mll:.3f} "
+          f"(rel {abs(mll32 / g64.mll - 1):.2e}, {abs(mllb / g64.mll - 1):.2e}); max|dmu| {np.abs(mu32 - mu64).max():.2e} / {np.abs(mub - mu64).max():.2e}, "
+          f"max|ds2| {np.abs(s232 - s264).max():.2e} / {np.abs(s2b - s264).max():.2e}, fp64 residual {np.abs(r64).max():.1e}")
+    for mll_, a_, mu_, s2_ in ((mll32, a, mu32, s232), (mllb, ab, mub, s2b)):
+        assert mll_ == pytest.approx(g64.mll, rel=1e-2)                                       # north_star's fp32 bar
+        np.testing.assert_allclose(mu_, mu64, rtol=1e-2, atol=1e-2 * np.abs(mu64).max())
+        np.testing.assert_allclose(s2_, s264, rtol=1e-2, atol=1e-2 * np.abs(s264).max())
+        np.testing.assert_allclose(a_, a64, rtol=0, atol=1e-2 * np.abs(a64).max())
