@@ -220,13 +220,23 @@ static int drain_profile(gpmi_ctx* c) {
 
 // Both look-ahead stream sets are created WITH the context: the CU-masked pair here, right after the context's own stream (the
 // priority side stream comes before it: gpmi_ctx_create).
+// words of a 256-bit CU mask: bit b = CU (b / 8) of XCC (b % 8) (tools/cumask_probe.hip) — half p of EVERY XCD is words [4 p, 4 p + 4)
+static void partition_mask(int part, uint32_t m[8]) {
+    for (int w = 0; w < 8; ++w) m[w] = (part == 0 || w / 4 == part - 1) ? ~0u : 0u;
+}
+
 static void create_lookahead_streams(gpmi_ctx* c) {
     if (!c->mask_ok) return;
     // one CU per XCD for the chain: mask bit k * 33 (k = 0..7) lands on XCC k, one CU each (tools/cumask_probe.hip,
     // profiles/r01_coresidency_cumask_probe.log); the update stream gets the other 248
-    uint32_t side_m[8] = {0}, upd_m[8];
-    for (int k = 0; k < 8; ++k) side_m[(k * 33) / 32] |= 1u << ((k * 33) % 32);
-    for (int w = 0; w < 8; ++w) upd_m[w] = ~side_m[w];
+    uint32_t side_m[8] = {0}, upd_m[8], part_m[8];
+    partition_mask(c->cu_part, part_m);
+    // (a CU partition reserves its own first CU of every XCD: bits 128 (p - 1) + k)
+    for (int k = 0; k < 8; ++k) {
+        const int b = c->cu_part ? 128 * (c->cu_part - 1) + k : k * 33;
+        side_m[b / 32] |= 1u << (b % 32);
+    }
+    for (int w = 0; w < 8; ++w) upd_m[w] = part_m[w] & ~side_m[w];
     if (hipExtStreamCreateWithCUMask(&c->side_masked, 8, side_m) != hipSuccess ||
         hipExtStreamCreateWithCUMask(&c->upd_stream, 8, upd_m) != hipSuccess) {
         (void)hipGetLastError();
@@ -626,8 +636,9 @@ int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return GPMI_EDEVICE;  // no GPU: no fallback
     for (int i = 0; i < n_devices; ++i) {
-        const int dev = device_ids ? device_ids[i] : 0;
-        if (dev < 0 || dev >= count) return GPMI_EARG;
+        const int code = device_ids ? device_ids[i] : 0;
+        const int dev = code & 255, part = code >> 8;  // id + 256 (1 + p): CU partition p of device id (include/gpmi.h)
+        if (code < 0 || dev >= count || part > 2) return GPMI_EARG;
     }
     gpmi_ctx* c = nullptr;
     int rc = create_one_context(device_ids ? device_ids[0] : 0, &c);
@@ -640,10 +651,26 @@ int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out) {
     return GPMI_OK;
 }
 
-static int create_one_context(int dev, gpmi_ctx** out) {
+static int create_one_context(int dev_code, gpmi_ctx** out) {
     *out = nullptr;
     gpmi_ctx* c = new gpmi_ctx();
+    const int dev = dev_code & 255;
     c->device = dev;
+    c->cu_part = dev_code >> 8;
+    if (c->cu_part) {
+        // A CU PARTITION of the device: every stream of this context is confined to 16 of the 32 CUs of every XCD (the same 8-XCD
+        // round-robin, half the width), so two such contexts run side by side without sharing a compute unit — the software
+        // stand-in for the driver's compute partitioning (CPX was refused on the leased device: profiles/r04_a_cpx_refused.log).
+        uint32_t pm[8];
+        partition_mask(c->cu_part, pm);
+        if (hipSetDevice(dev) != hipSuccess || hipExtStreamCreateWithCUMask(&c->side_stream, 8, pm) != hipSuccess ||
+            hipExtStreamCreateWithCUMask(&c->own_stream, 8, pm) != hipSuccess) {
+            (void)hipGetLastError();
+            c->stream = c->own_stream;
+            gpmi_ctx_destroy(c);
+            return GPMI_EDEVICE;
+        }
+    } else
     // Stream creation ORDER matters on this runtime (profiles/r03_d_stream_order.log, r03_e_*): priority side stream, the
     // context's own stream, then the two CU-masked streams.  The masked streams must directly follow the own stream (created
     // after the priority stream, or lazily after a large factorisation, they cost N = 20 000 ten ms per step), and the priority
@@ -656,7 +683,7 @@ static int create_one_context(int dev, gpmi_ctx** out) {
             c->side_stream = nullptr;
         }
     }
-    if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+    if (hipSetDevice(dev) != hipSuccess || (!c->own_stream && hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) ||
         hipMalloc(&c->d_prog, sizeof(DevProgram)) != hipSuccess ||
         hipHostMalloc(&c->h_prog, sizeof(DevProgram)) != hipSuccess || hipMalloc(&c->d_info, sizeof(int)) != hipSuccess ||
         hipMalloc(&c->d_scal, 8 * sizeof(double)) != hipSuccess ||
@@ -672,13 +699,15 @@ static int create_one_context(int dev, gpmi_ctx** out) {
     c->stream = c->own_stream;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
+    const int device_cus = c->num_cus;
+    if (c->cu_part) c->num_cus = device_cus / 2;
     // look-ahead Cholesky: a high-priority side stream for the next panel's serial chain, and how many of the chip's
     // workgroup slots the main trailing-update launch leaves free for it (GPMI_LOOKAHEAD=0 switches it off)
     {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = greatest priority (numerically lowest)
         const char* cm = getenv("GPMI_CUMASK");
-        c->mask_ok = !(cm && atoi(cm) == 0) && c->num_cus == 256;
+        c->mask_ok = !(cm && atoi(cm) == 0) && device_cus == 256;
         (void)hi;
         create_lookahead_streams(c);
         c->lookahead_slots = 16;  // 8 in round 1 (a 7-launch chain per panel); the super-block factorisation has launches of up to 28 workgroups
@@ -741,7 +770,7 @@ void gpmi_ctx_destroy(gpmi_ctx* c) {
             hipStreamSynchronize(st);
             hipStreamDestroy(st);
         }
-    for (void* p : {c->sup_lw, c->sup_lwt, c->sup_l256, c->sup_ut, c->sup_s})
+    for (void* p : {c->sup_lw, c->sup_lwt, c->sup_l256, c->sup_ut, c->sup_s, c->cov_scaled})
         if (p) hipFree(p);
     if (c->d_prog) hipFree(c->d_prog);
     if (c->h_prog) hipHostFree(c->h_prog);

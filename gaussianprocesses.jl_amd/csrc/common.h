@@ -75,6 +75,7 @@ struct SuperPart {
 
 struct gpmi_ctx {
     int device = 0;
+    int cu_part = 0;        // 0: the whole device; 1 / 2: every stream of this context is confined to half (p - 1) of every XCD (gpmi_ctx_create)
     void* group = nullptr;  // non-null: member of an in-process device group (gpmi_ctx_create with n_devices > 1; dev_hip.hip)
     int group_rank = 0;     // 0 = the primary (the handle the caller holds)
     hipStream_t stream = nullptr;
@@ -129,6 +130,7 @@ struct gpmi_ctx {
     void* sup_lwt = nullptr; int64_t sup_lwt_cap = 0;
     void* sup_l256 = nullptr; int64_t sup_l256_cap = 0;
     void* sup_ut = nullptr;  int64_t sup_ut_cap = 0;
+    void* cov_scaled = nullptr;  int64_t cov_scaled_cap = 0;  // cov.hip: pre-scaled, zero-padded copies of the two input blocks of a single-leaf cov!
     void* sup_s = nullptr;   int64_t sup_s_cap = 0;
     int64_t sup_wld = 0;
     int64_t grad_chunk = 2048;           // K chunk of the gradient's K^-1 = L^-T L^-1 accumulation (GPMI_GRAD_CHUNK; 0 = one product)
@@ -259,7 +261,7 @@ int upload_program(gpmi_ctx* c, const gpmi_kernel* k, int d);                 //
 int grow(gpmi_ctx* c, void** p, int64_t* cap, int64_t need_bytes);            // (re)allocate a device scratch buffer
 
 // kernel launchers (each enqueues on ctx->stream; T = double | float) -------------------------
-enum CovFlags { COV_LOWER = 1, COV_NUGGET = 2, COV_PAD_IDENTITY = 4 };
+enum CovFlags { COV_LOWER = 1, COV_NUGGET = 2, COV_PAD_IDENTITY = 4, COV_NO_FAST = 8 /* internal: the interpreter takes every tile */ };
 
 // C[i][j] = k(xa_i, xb_j) for i < nrows_total, j < ncols_total (row-major, ld = ldc).
 // rows >= na / cols >= nb are padding: 0, or the identity when COV_PAD_IDENTITY.

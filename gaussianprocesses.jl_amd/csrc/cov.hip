@@ -91,32 +91,11 @@ __device__ __forceinline__ T leaf_value(int op, T r, T s2, T p0inv, T p1) {
     }
 }
 
-// the same without the RQ leaves (fp64 pow drags ~90 VGPRs into whatever kernel contains it)
-template <typename T>
-__device__ __forceinline__ T leaf_value_nopow(int op, T r, T s2, T p0inv) {
-    switch (op) {
-        case GPMI_K_SE_ISO: return s2 * Tr<T>::exp_((T(-0.5) * r) * p0inv);
-        case GPMI_K_SE_ARD: return s2 * Tr<T>::exp_(T(-0.5) * r);
-        case GPMI_K_MAT12_ISO: return s2 * Tr<T>::exp_(-(Tr<T>::sqrt_(r) * p0inv));
-        case GPMI_K_MAT12_ARD: return s2 * Tr<T>::exp_(-Tr<T>::sqrt_(r));
-        case GPMI_K_MAT32_ISO:
-        case GPMI_K_MAT32_ARD: {
-            T s = T(1.7320508075688772935) * Tr<T>::sqrt_(r) * p0inv;
-            return s2 * (T(1) + s) * Tr<T>::exp_(-s);
-        }
-        case GPMI_K_MAT52_ISO:
-        case GPMI_K_MAT52_ARD: {
-            T s = T(2.2360679774997896964) * Tr<T>::sqrt_(r) * p0inv;
-            return s2 * (T(1) + s + s * s * T(1.0 / 3.0)) * Tr<T>::exp_(-s);
-        }
-        default: return s2;
-    }
-}
-
 // Is this tile one the fast kernel takes?  One stationary leaf (the bench's SEArd; any single SE / Matern / RQ kernel) and a
 // tile that needs neither padding nor the diagonal (nugget).  Both kernels evaluate it, so every tile has exactly one owner.
 __device__ __forceinline__ bool fast_tile(const DevProgram* __restrict__ prog, int nops, int flags, int64_t row0, int64_t col0,
                                           int TR, int TC, int64_t na, int64_t nb, int64_t nrows, int64_t ncols, int64_t row_off) {
+    if (flags & COV_NO_FAST) return false;
     if (nops != 1) {
         if (prog->fast_class < 0) return false;  // multi-leaf: the specialised kernel's programs only
     } else {
@@ -128,241 +107,386 @@ __device__ __forceinline__ bool fast_tile(const DevProgram* __restrict__ prog, i
     return interior && !on_diag;
 }
 
-// cov_fast_kernel: the same tiling as cov_kernel for the tiles fast_tile() selects.  Weights and leaf constants are read
-// once, there is no evaluation stack and no per-entry edge logic: about half the VALU instructions per entry of the
-// interpreter, and few enough registers for 6+ waves per SIMD (the interpreter needs 177 VGPRs: 2 waves).
+// ---- single stationary leaf: cov_leaf_kernel (round 4; replaces round 1's cov_fast_kernel) ------------------------------------
+// The PMC record of the old kernel (profiles/r04_a_cov_pmc_before.json) says what bounded it: 70 VALU lane-instructions per entry
+// (fp64, d = 8) at 67 % VALU issue utilisation — twice what the arithmetic needs, because the leaf switch, the `k < d` tests and the
+// polynomial's literal constants (re-materialised by v_mov_b64) all sat inside the row loop.  This kernel does per entry only
+//   d x (v_add_f64, v_fma_f64)   the squared distance of PRE-SCALED inputs: x_k sqrt(w_k c) is formed once per call by
+//                                scale_inputs_kernel into zero-padded rows of DMAX (N d elements against N^2 entries), so the ARD /
+//                                iso / Masked weight and the leaf's reciprocal length constant cost nothing here;
+//   the leaf function            on the family FAM (template: no switch), exp by exp_nonpos with its constants in scalar registers;
+// the row operand comes through SCALAR loads (the row pointer is wave-uniform: s_load_dwordx8/16, no LDS, no barrier), the column
+// operand is loaded once per wave into registers (this lane's VEC columns: DMAX contiguous elements each), two rows per iteration
+// for instruction-level parallelism.  Same tiles, same owner rule (fast_tile) and the same 1 KiB-per-row wavefront stores as before.
+enum LeafFamily { FAM_SE = 0, FAM_MAT12 = 1, FAM_MAT32 = 2, FAM_MAT52 = 3, FAM_RQ = 4 };
+
+template <int DMAX>
+struct ScaleW {
+    double sw[DMAX];  // sqrt(w_k * c): c = the leaf's reciprocal length constant folded into the weights (host, fp64)
+};
+
+// amax (may be null): running maximum of |x| over everything scaled so far, as the bit pattern of a non-negative IEEE number
+// (ordered like the number itself) — the Noise prefilter's scale
 template <typename T, int DMAX>
-__global__ __launch_bounds__(256) void cov_fast_kernel(const T* __restrict__ xa, int64_t na, const T* __restrict__ xb,
-                                                       int64_t nb, int d, T* __restrict__ C, int64_t ldc, int64_t nrows,
-                                                       int64_t ncols, const DevProgram* __restrict__ prog, int flags,
-                                                       int64_t row_off) {
+__global__ __launch_bounds__(256) void scale_inputs_kernel(const T* __restrict__ x, int64_t n, int d, ScaleW<DMAX> w, T* __restrict__ out,
+                                                           unsigned long long* __restrict__ amax) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    T av = T(0);
+    if (i < n * DMAX) {
+        const int64_t row = i / DMAX;
+        const int k = (int)(i - row * DMAX);
+        const T v = k < d ? x[row * d + k] : T(0);
+        av = fabs(v);
+        out[i] = (T)((double)v * w.sw[k]);
+    }
+    if (amax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const T o = __shfl_xor(av, off, 64);
+            av = o > av ? o : av;
+        }
+        if ((threadIdx.x & 63) == 0) {
+            unsigned long long bits;
+            if constexpr (sizeof(T) == 8)
+                bits = (unsigned long long)__double_as_longlong((double)av);
+            else
+                bits = (unsigned long long)__float_as_uint((float)av);
+            atomicMax(amax, bits);
+        }
+    }
+}
+
+// sqrt(r) for r >= 0 in fp64 without the library's scaling / special cases: v_rsq_f64 + two Goldschmidt steps (|rel. error| < 2e-16);
+// r = 0 (coincident points) gives exactly 0, as distij(::Euclidean) does
+__device__ __forceinline__ double sqrt_nonneg(double r) {
+    const double rc = fmax(r, 1e-300);
+    double y = __builtin_amdgcn_rsq(rc);
+    double g = rc * y, h = 0.5 * y;
+    double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    const double res = fma(fma(-g, g, rc), h, g);
+    return r > 0.0 ? res : 0.0;
+}
+__device__ __forceinline__ float sqrt_nonneg(float r) { return sqrtf(r); }
+
+// the leaf function on the squared distance of the PRE-SCALED inputs (file header of each kernel in include/gpmi.h)
+template <typename T, int FAM>
+__device__ __forceinline__ T leaf_family(T r, T s2, T p1) {
+    if constexpr (FAM == FAM_SE) {
+        return s2 * Tr<T>::exp_(T(-0.5) * r);                                   // se_iso.jl:39, se_ard.jl:43 (1/l2 in the weights)
+    } else if constexpr (FAM == FAM_MAT12) {
+        return s2 * Tr<T>::exp_(-sqrt_nonneg(r));                               // mat12_*.jl (1/l^2 in the weights)
+    } else if constexpr (FAM == FAM_MAT32) {
+        const T s = sqrt_nonneg(r);                                             // mat32_*.jl (3/l^2 in the weights)
+        return s2 * (T(1) + s) * Tr<T>::exp_(-s);
+    } else if constexpr (FAM == FAM_MAT52) {
+        const T s = sqrt_nonneg(r);                                             // mat52_*.jl (5/l^2 in the weights): 1 + s + s^2/3
+        return s2 * Tr<T>::fma_(s, Tr<T>::fma_(s, T(1.0 / 3.0), T(1)), T(1)) * Tr<T>::exp_(-s);
+    } else {
+        return s2 * Tr<T>::pow_(T(1) + r, -p1);                                 // rq_*.jl (1/(2 a l2) resp. 0.5/a in the weights)
+    }
+}
+
+template <typename T, int DMAX, int FAM>
+__global__ __launch_bounds__(256) void cov_leaf_kernel(const T* __restrict__ xas, int64_t na, const T* __restrict__ xbs, int64_t nb,
+                                                       T* __restrict__ C, int64_t ldc, int64_t nrows, int64_t ncols,
+                                                       const DevProgram* __restrict__ prog, int flags, int64_t row_off, T s2, T p1) {
     constexpr int VEC = 16 / sizeof(T);
     constexpr int TC = 64 * VEC;
     constexpr int TR = 64;
     using VT = T __attribute__((ext_vector_type(VEC)));
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* sa = reinterpret_cast<T*>(smem);  // [TR][d]
-    T* sbT = sa + TR * d;                // [d][TC]
     const int64_t row0 = (int64_t)blockIdx.y * TR;
     const int64_t col0 = (int64_t)blockIdx.x * TC;
     if ((flags & COV_LOWER) && col0 > row_off + row0 + TR - 1) return;  // tile strictly above the diagonal
-    if (!fast_tile(prog, prog->n_ops, flags, row0, col0, TR, TC, na, nb, nrows, ncols, row_off)) return;
-    const int tid = threadIdx.x;
-    for (int e = tid; e < TR * d; e += 256) sa[e] = xa[(row0 + e / d) * d + (e % d)];
-    for (int e = tid; e < TC * d; e += 256) {
-        const int c = e / d, k = e - c * d;
-        sbT[k * TC + c] = xb[(col0 + c) * d + k];
-    }
-    __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
+    if (!fast_tile(prog, 1, flags, row0, col0, TR, TC, na, nb, nrows, ncols, row_off)) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // provably wave-uniform: the row operand goes through SMEM
+    // this lane's VEC columns of the (scaled, zero-padded) column block: DMAX contiguous elements each
     T xbr[DMAX][VEC];
 #pragma unroll
-    for (int k = 0; k < DMAX; ++k) {
-        if (k < d) {
-            const VT v = *reinterpret_cast<const VT*>(&sbT[k * TC + lane * VEC]);
+    for (int q = 0; q < VEC; ++q) {
+        const T* pb = xbs + (col0 + (int64_t)lane * VEC + q) * DMAX;
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) xbr[k][q] = v[q];
-        } else {
+        for (int k = 0; k < DMAX; k += VEC) {
+            const VT v = *reinterpret_cast<const VT*>(pb + k);
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) xbr[k][q] = T(0);
+            for (int j = 0; j < VEC; ++j) xbr[k + j][q] = v[j];
         }
     }
-    const int op0 = prog->leaf[0].op;
-    const double* w = prog->w + prog->leaf[0].woff;
-    T wk[DMAX];
+    const T* __restrict__ ar = xas + (row0 + wave * (TR / 4)) * DMAX;
+    T* __restrict__ crow = C + (row0 + wave * (TR / 4)) * ldc + col0 + (int64_t)lane * VEC;
+#pragma unroll 1
+    for (int rr = 0; rr < TR / 4; rr += 2) {
+        T r0[VEC], r1[VEC];
 #pragma unroll
-    for (int k = 0; k < DMAX; ++k) wk[k] = k < d ? (T)w[k] : T(0);
-    const T s2 = (T)prog->leaf[0].s2, p0inv = (T)prog->leaf[0].p0, p1 = (T)prog->leaf[0].p1;
-    for (int rr = 0; rr < TR / 4; ++rr) {
-        const int row = wave * (TR / 4) + rr;
-        const T* sar = sa + row * d;
-        T r[VEC];
-#pragma unroll
-        for (int q = 0; q < VEC; ++q) r[q] = T(0);
+        for (int q = 0; q < VEC; ++q) r0[q] = r1[q] = T(0);
 #pragma unroll
         for (int k = 0; k < DMAX; ++k) {
-            if (k < d) {
-                const T a = sar[k];
+            const T a0 = ar[rr * DMAX + k], a1 = ar[(rr + 1) * DMAX + k];  // wave-uniform addresses: scalar loads
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) {
-                    const T df = a - xbr[k][q];
-                    r[q] = Tr<T>::fma_(df * df, wk[k], r[q]);  // same operation order as the interpreter
-                }
+            for (int q = 0; q < VEC; ++q) {
+                const T d0 = a0 - xbr[k][q], d1 = a1 - xbr[k][q];
+                r0[q] = Tr<T>::fma_(d0, d0, r0[q]);
+                r1[q] = Tr<T>::fma_(d1, d1, r1[q]);
             }
         }
-        VT out;
+        VT o0, o1;
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) out[q] = leaf_value<T>(op0, r[q], s2, p0inv, p1);
-        *reinterpret_cast<VT*>(&C[(row0 + row) * ldc + col0 + (int64_t)lane * VEC]) = out;
+        for (int q = 0; q < VEC; ++q) {
+            o0[q] = leaf_family<T, FAM>(r0[q], s2, p1);
+            o1[q] = leaf_family<T, FAM>(r1[q], s2, p1);
+        }
+        *reinterpret_cast<VT*>(crow + (int64_t)rr * ldc) = o0;
+        *reinterpret_cast<VT*>(crow + (int64_t)(rr + 1) * ldc) = o1;
     }
 }
 
 // cov_multi_kernel: the interior, off-diagonal tiles of a MULTI-LEAF program (Sum / Prod of stationary, Const and Noise leaves,
-// evaluation depth <= 3: DevProgram::fast_class) — BASELINE configs[2], (SEArd + Mat52Iso) + Noise, is one.  Same tiling as
-// cov_fast_kernel; against the generic interpreter it has no per-entry edge logic, a three-deep stack instead of a six-deep
-// one, no fp64 pow unless the program has an RQ leaf (FEAT & 1: the library routine alone costs ~90 VGPRs) and the Noise leaf
-// (FEAT & 2) behind a prefilter: noise.jl:31-37 asks x_z ~ y_z for every active row z (isapprox, rtol sqrt(eps)), which needs
-// (x_z - y_z)^2 <= (rtol max|x|)^2 for all z — one v_max per row on the squared differences the other leaves need anyway; the
-// exact test runs only where some lane of the wave passes it (coincident points: the diagonal, duplicates).
+// evaluation depth <= 3: DevProgram::fast_class) — BASELINE configs[2], (SEArd + Mat52Iso) + Noise, is one.  Round 4 rewrite on the
+// PMC record of round 3's form (profiles/r04_a_cov_pmc_before.json: 204 VALU lane-instructions per entry at 75 % VALU issue utilisation — the
+// arithmetic needs ~110; the rest were `k < d` selects, literal-constant moves and per-row scalar loads of the leaf parameters with
+// their waits): the operands come zero-padded to DMAX (scale_inputs_kernel with unit weights: no k < d tests; the row operand
+// through scalar loads, the column operand straight into registers — no LDS transposition, no barrier after the prologue), every
+// leaf's parameters and weights sit in LDS in the element type (one broadcast read per use instead of an SMEM round trip), TWO rows
+// per pass over the program (the wave-uniform control flow is paid once per four / eight entries of a lane), sqrt by rsq + Goldschmidt.
+// No fp64 pow unless the program has an RQ leaf (FEAT & 1: the library routine alone costs ~90 VGPRs); the Noise leaf (FEAT & 2)
+// behind a prefilter: noise.jl:31-37 asks x_z ~ y_z for every active row z (isapprox, rtol sqrt(eps)), which needs
+// (x_z - y_z)^2 <= (rtol max|x|)^2 for all z — one v_max per row on the squared differences the other leaves need anyway; the exact
+// test runs only where some lane of the wave passes it (coincident points: the diagonal, duplicates).
+template <typename T, int DMAX>
+struct LeafLds {
+    T w[DMAX];
+    T s2, p0, p1;
+    int op, pad_;
+};
+
 template <typename T, int DMAX, int FEAT>
-__global__ __launch_bounds__(256) void cov_multi_kernel(const T* __restrict__ xa, int64_t na, const T* __restrict__ xb,
-                                                        int64_t nb, int d, T* __restrict__ C, int64_t ldc, int64_t nrows,
-                                                        int64_t ncols, const DevProgram* __restrict__ prog, int flags,
-                                                        int64_t row_off) {
+__global__ __launch_bounds__(256) void cov_multi_kernel(const T* __restrict__ xas, int64_t na, const T* __restrict__ xbs, int64_t nb,
+                                                        T* __restrict__ C, int64_t ldc, int64_t nrows, int64_t ncols,
+                                                        const DevProgram* __restrict__ prog, int flags, int64_t row_off,
+                                                        const unsigned long long* __restrict__ amax) {
     constexpr int VEC = 16 / sizeof(T);
     constexpr int TC = 64 * VEC;
     constexpr int TR = 64;
     using VT = T __attribute__((ext_vector_type(VEC)));
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* sa = reinterpret_cast<T*>(smem);  // [TR][d]
-    T* sbT = sa + TR * d;                // [d][TC]
-    __shared__ T s_max[4];
+    __shared__ LeafLds<T, DMAX> s_leaf[GPMI_MAX_OPS];
     const int64_t row0 = (int64_t)blockIdx.y * TR;
     const int64_t col0 = (int64_t)blockIdx.x * TC;
     if ((flags & COV_LOWER) && col0 > row_off + row0 + TR - 1) return;  // tile strictly above the diagonal
     const int nops = prog->n_ops;
     if (nops == 1 || !fast_tile(prog, nops, flags, row0, col0, TR, TC, na, nb, nrows, ncols, row_off)) return;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    T amax = T(0);
-    for (int e = tid; e < TR * d; e += 256) {
-        const T v = xa[(row0 + e / d) * d + (e % d)];
-        sa[e] = v;
-        if constexpr (FEAT & 2) amax = fabs(v) > amax ? fabs(v) : amax;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const int d = prog->d;
+    for (int e = tid; e < nops * (DMAX + 4); e += 256) {  // the program, once per workgroup
+        const int o = e / (DMAX + 4), j = e - o * (DMAX + 4);
+        const DevLeaf& lf = prog->leaf[o];
+        if (j < DMAX)
+            s_leaf[o].w[j] = (j < d && lf.op < GPMI_K_SUM) ? (T)prog->w[lf.woff + j] : T(0);
+        else if (j == DMAX)
+            s_leaf[o].s2 = (T)lf.s2;
+        else if (j == DMAX + 1)
+            s_leaf[o].p0 = (T)lf.p0;
+        else if (j == DMAX + 2)
+            s_leaf[o].p1 = (T)lf.p1;
+        else
+            s_leaf[o].op = lf.op;
     }
-    for (int e = tid; e < TC * d; e += 256) {
-        const int c = e / d, k = e - c * d;
-        const T v = xb[(col0 + c) * d + k];
-        sbT[k * TC + c] = v;
-        if constexpr (FEAT & 2) amax = fabs(v) > amax ? fabs(v) : amax;
-    }
-    if constexpr (FEAT & 2) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const T o = __shfl_xor(amax, off, 64);
-            amax = o > amax ? o : amax;
-        }
-        if (lane == 0) s_max[wave] = amax;
-    }
-    __syncthreads();
-    T thr2 = T(0);
-    if constexpr (FEAT & 2) {
-        T m = s_max[0];
-        for (int w = 1; w < 4; ++w) m = s_max[w] > m ? s_max[w] : m;
-        const T thr = Tr<T>::isapprox_rtol * m * T(1.0000001);
-        thr2 = thr * thr;
-    }
+    // this lane's VEC columns of the zero-padded column block
     T xbr[DMAX][VEC];
 #pragma unroll
-    for (int k = 0; k < DMAX; ++k) {
-        if (k < d) {
-            const VT v = *reinterpret_cast<const VT*>(&sbT[k * TC + lane * VEC]);
+    for (int q = 0; q < VEC; ++q) {
+        const T* pb = xbs + (col0 + (int64_t)lane * VEC + q) * DMAX;
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) xbr[k][q] = v[q];
-        } else {
+        for (int k = 0; k < DMAX; k += VEC) {
+            const VT v = *reinterpret_cast<const VT*>(pb + k);
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) xbr[k][q] = T(0);
+            for (int j = 0; j < VEC; ++j) xbr[k + j][q] = v[j];
         }
     }
-    for (int rr = 0; rr < TR / 4; ++rr) {
-        const int row = wave * (TR / 4) + rr;
-        const T* sar = sa + row * d;
-        T dsq[DMAX][VEC];
+    __syncthreads();
+    // Noise prefilter threshold: isapprox needs |a - b| <= rtol max(|a|, |b|) <= rtol xmax (xmax: max |x| over both input blocks)
+    T xmax;
+    if constexpr (sizeof(T) == 8)
+        xmax = (T)__longlong_as_double((long long)amax[0]);
+    else
+        xmax = (T)__uint_as_float((unsigned)amax[0]);
+    const T thr = Tr<T>::isapprox_rtol * xmax * T(1.0000001);
+    const T thr2 = thr * thr;
+    const T* __restrict__ ar = xas + (row0 + wave * (TR / 4)) * DMAX;
+    T* __restrict__ crow = C + (row0 + wave * (TR / 4)) * ldc + col0 + (int64_t)lane * VEC;
+    constexpr int NR = 2;  // rows per pass
+#pragma unroll 1
+    for (int rr = 0; rr < TR / 4; rr += NR) {
+        T dsq[NR][DMAX][VEC];
 #pragma unroll
         for (int k = 0; k < DMAX; ++k) {
-            const T a = k < d ? sar[k] : T(0);
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) {
-                const T df = a - xbr[k][q];
-                dsq[k][q] = df * df;
-            }
-        }
-        T s0[VEC], s1[VEC], s2[VEC];
-#pragma unroll
-        for (int q = 0; q < VEC; ++q) s0[q] = s1[q] = s2[q] = T(0);
-        for (int o = 0; o < nops; ++o) {  // wave-uniform control flow throughout
-            const int op = prog->leaf[o].op;
-            if (op == GPMI_K_SUM || op == GPMI_K_PROD) {
+            for (int i = 0; i < NR; ++i) {
+                const T a = ar[(rr + i) * DMAX + k];  // wave-uniform address: scalar load
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) {
-                    s0[q] = (op == GPMI_K_SUM) ? (s1[q] + s0[q]) : (s1[q] * s0[q]);
-                    s1[q] = s2[q];
+                    const T df = a - xbr[k][q];
+                    dsq[i][k][q] = df * df;
                 }
+            }
+        }
+        T s0[NR][VEC], s1[NR][VEC], s2[NR][VEC];
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) s0[i][q] = s1[i][q] = s2[i][q] = T(0);
+#pragma unroll 1
+        for (int o = 0; o < nops; ++o) {  // wave-uniform control flow throughout
+            const int op = __builtin_amdgcn_readfirstlane(s_leaf[o].op);
+            if (op == GPMI_K_SUM || op == GPMI_K_PROD) {
+#pragma unroll
+                for (int i = 0; i < NR; ++i)
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) {
+                        s0[i][q] = (op == GPMI_K_SUM) ? (s1[i][q] + s0[i][q]) : (s1[i][q] * s0[i][q]);
+                        s1[i][q] = s2[i][q];
+                    }
                 continue;
             }
-            T val[VEC];
-            const T sig2 = (T)prog->leaf[o].s2;
-            const double* w = prog->w + prog->leaf[o].woff;
+            T val[NR][VEC];
+            const T sig2 = s_leaf[o].s2;
             if (op == GPMI_K_CONST) {
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) val[q] = sig2;
-            } else if (op == GPMI_K_NOISE) {
-                if constexpr (FEAT & 2) {
-                    T mx[VEC];
+                for (int i = 0; i < NR; ++i)
 #pragma unroll
-                    for (int q = 0; q < VEC; ++q) mx[q] = T(0);
+                    for (int q = 0; q < VEC; ++q) val[i][q] = sig2;
+            } else if (op == GPMI_K_NOISE) {
+#pragma unroll
+                for (int i = 0; i < NR; ++i)
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) val[i][q] = T(0);
+                if constexpr (FEAT & 2) {
+                    T mx[NR][VEC];
+#pragma unroll
+                    for (int i = 0; i < NR; ++i)
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) mx[i][q] = T(0);
 #pragma unroll
                     for (int k = 0; k < DMAX; ++k) {
-                        if (k < d && w[k] != 0.0) {
+                        const T act = s_leaf[o].w[k];  // 0 on rows the leaf does not act on (and on the padding)
 #pragma unroll
-                            for (int q = 0; q < VEC; ++q) mx[q] = dsq[k][q] > mx[q] ? dsq[k][q] : mx[q];
-                        }
+                        for (int i = 0; i < NR; ++i)
+#pragma unroll
+                            for (int q = 0; q < VEC; ++q) {
+                                const T v = act != T(0) ? dsq[i][k][q] : T(0);
+                                mx[i][q] = v > mx[i][q] ? v : mx[i][q];
+                            }
                     }
                     bool cand = false;
 #pragma unroll
-                    for (int q = 0; q < VEC; ++q) cand = cand || (mx[q] <= thr2);
+                    for (int i = 0; i < NR; ++i)
 #pragma unroll
-                    for (int q = 0; q < VEC; ++q) val[q] = T(0);
+                        for (int q = 0; q < VEC; ++q) cand = cand || (mx[i][q] <= thr2);
                     if (__any(cand)) {  // the exact test of noise.jl:31-37, as the interpreter does it
 #pragma unroll
-                        for (int q = 0; q < VEC; ++q) {
-                            bool same = true;
-                            for (int k = 0; k < d; ++k) {
-                                if (w[k] != 0.0) {
-                                    const T a = sar[k], b = sbT[k * TC + lane * VEC + q];
-                                    const T m = fabs(a) > fabs(b) ? fabs(a) : fabs(b);
-                                    same = same && ((a == b) || (fabs(a - b) <= Tr<T>::isapprox_rtol * m));
-                                }
-                            }
-                            val[q] = same ? sig2 : T(0);
-                        }
-                    }
-                } else {
+                        for (int i = 0; i < NR; ++i)
 #pragma unroll
-                    for (int q = 0; q < VEC; ++q) val[q] = T(0);
+                            for (int q = 0; q < VEC; ++q) {
+                                bool same = true;
+                                for (int k = 0; k < d; ++k) {
+                                    if (s_leaf[o].w[k] != T(0)) {
+                                        const T a = ar[(rr + i) * DMAX + k], b = xbs[(col0 + (int64_t)lane * VEC + q) * DMAX + k];
+                                        const T m = fabs(a) > fabs(b) ? fabs(a) : fabs(b);
+                                        same = same && ((a == b) || (fabs(a - b) <= Tr<T>::isapprox_rtol * m));
+                                    }
+                                }
+                                val[i][q] = same ? sig2 : T(0);
+                            }
+                    }
                 }
             } else {
-                T r[VEC];
+                T r[NR][VEC];
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) r[q] = T(0);
+                for (int i = 0; i < NR; ++i)
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) r[i][q] = T(0);
 #pragma unroll
                 for (int k = 0; k < DMAX; ++k) {
-                    if (k < d) {
-                        const T wk = (T)w[k];
+                    const T wk = s_leaf[o].w[k];  // LDS broadcast
 #pragma unroll
-                        for (int q = 0; q < VEC; ++q) r[q] = Tr<T>::fma_(dsq[k][q], wk, r[q]);
-                    }
+                    for (int i = 0; i < NR; ++i)
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) r[i][q] = Tr<T>::fma_(dsq[i][k][q], wk, r[i][q]);
                 }
-                const T p0inv = (T)prog->leaf[o].p0, p1 = (T)prog->leaf[o].p1;
-                if ((FEAT & 1) && (op == GPMI_K_RQ_ISO || op == GPMI_K_RQ_ARD)) {
+                const T p0inv = s_leaf[o].p0, p1 = s_leaf[o].p1;
+                (void)p1;
+                switch (op) {  // the leaf files' formulas (include/gpmi.h), r = the weighted squared distance
+                    case GPMI_K_SE_ISO:
+                    case GPMI_K_SE_ARD:
 #pragma unroll
-                    for (int q = 0; q < VEC; ++q) val[q] = sig2 * Tr<T>::pow_(T(1) + r[q] * p0inv, -p1);
-                } else {
+                        for (int i = 0; i < NR; ++i)
 #pragma unroll
-                    for (int q = 0; q < VEC; ++q) val[q] = leaf_value_nopow<T>(op, r[q], sig2, p0inv);
+                            for (int q = 0; q < VEC; ++q) val[i][q] = sig2 * Tr<T>::exp_((T(-0.5) * r[i][q]) * p0inv);
+                        break;
+                    case GPMI_K_MAT12_ISO:
+                    case GPMI_K_MAT12_ARD:
+#pragma unroll
+                        for (int i = 0; i < NR; ++i)
+#pragma unroll
+                            for (int q = 0; q < VEC; ++q) val[i][q] = sig2 * Tr<T>::exp_(-(sqrt_nonneg(r[i][q]) * p0inv));
+                        break;
+                    case GPMI_K_MAT32_ISO:
+                    case GPMI_K_MAT32_ARD:
+#pragma unroll
+                        for (int i = 0; i < NR; ++i)
+#pragma unroll
+                            for (int q = 0; q < VEC; ++q) {
+                                const T sv = T(1.7320508075688772935) * sqrt_nonneg(r[i][q]) * p0inv;
+                                val[i][q] = sig2 * (T(1) + sv) * Tr<T>::exp_(-sv);
+                            }
+                        break;
+                    case GPMI_K_MAT52_ISO:
+                    case GPMI_K_MAT52_ARD:
+#pragma unroll
+                        for (int i = 0; i < NR; ++i)
+#pragma unroll
+                            for (int q = 0; q < VEC; ++q) {
+                                const T sv = T(2.2360679774997896964) * sqrt_nonneg(r[i][q]) * p0inv;
+                                val[i][q] = sig2 * (T(1) + sv + sv * sv * T(1.0 / 3.0)) * Tr<T>::exp_(-sv);
+                            }
+                        break;
+                    default:  // GPMI_K_RQ_*
+                        if constexpr (FEAT & 1) {
+#pragma unroll
+                            for (int i = 0; i < NR; ++i)
+#pragma unroll
+                                for (int q = 0; q < VEC; ++q) val[i][q] = sig2 * Tr<T>::pow_(T(1) + r[i][q] * p0inv, -p1);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < NR; ++i)
+#pragma unroll
+                                for (int q = 0; q < VEC; ++q) val[i][q] = sig2;
+                        }
+                        break;
                 }
             }
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) {  // push
-                s2[q] = s1[q];
-                s1[q] = s0[q];
-                s0[q] = val[q];
-            }
+            for (int i = 0; i < NR; ++i)
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) {  // push
+                    s2[i][q] = s1[i][q];
+                    s1[i][q] = s0[i][q];
+                    s0[i][q] = val[i][q];
+                }
         }
-        VT out;
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) out[q] = s0[q];
-        *reinterpret_cast<VT*>(&C[(row0 + row) * ldc + col0 + (int64_t)lane * VEC]) = out;
+        for (int i = 0; i < NR; ++i) {
+            VT out;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) out[q] = s0[i][q];
+            *reinterpret_cast<VT*>(crow + (int64_t)(rr + i) * ldc) = out;
+        }
     }
 }
 
@@ -562,18 +686,71 @@ void launch_cov_t(gpmi_ctx* ctx, const T* xa, int64_t na, const T* xb, int64_t n
     size_t lds = (size_t)(TR + TC) * d * sizeof(T);
     auto kern = cov_kernel<T, DMAX>;
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const DevProgram* hp = ctx->h_prog;
+    bool single_leaf = false, multi = false;
+    T *xas = nullptr, *xbs = nullptr;
+    unsigned long long* amax = nullptr;
+    if constexpr (DMAX > 0) {
+        single_leaf = hp->n_ops == 1 && hp->leaf[0].op != GPMI_K_NOISE && hp->leaf[0].op != GPMI_K_CONST;
+        multi = hp->n_ops > 1 && hp->fast_class >= 0;
+        // both specialised kernels work on zero-padded (single leaf: also pre-scaled) copies of the two input blocks, 16 bytes of header
+        // (max |x|) in front: without the scratch the interpreter takes every tile
+        if ((single_leaf || multi) && grow(ctx, &ctx->cov_scaled, &ctx->cov_scaled_cap, 16 + (na + nb) * DMAX * (int64_t)sizeof(T)) != GPMI_OK) {
+            (void)hipGetLastError();
+            single_leaf = multi = false;
+            flags |= COV_NO_FAST;
+        }
+        if (single_leaf || multi) {
+            amax = (unsigned long long*)ctx->cov_scaled;
+            xas = (T*)((char*)ctx->cov_scaled + 16);
+            xbs = xas + na * DMAX;
+        }
+    }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, xa, na, xb, nb, d, C, ldc, nrows_total, ncols_total,
                        ctx->d_prog, flags, nugget, nugget_vec, row_off);
     if constexpr (DMAX > 0) {
-        const DevProgram* hp = ctx->h_prog;
-        if (hp->n_ops == 1 && hp->leaf[0].op != GPMI_K_NOISE && hp->leaf[0].op != GPMI_K_CONST) {
-            auto fk = cov_fast_kernel<T, DMAX>;
-            hipLaunchKernelGGL(fk, grid, dim3(256), lds, ctx->stream, xa, na, xb, nb, d, C, ldc, nrows_total, ncols_total,
-                               ctx->d_prog, flags, row_off);
-        } else if (hp->n_ops > 1 && hp->fast_class >= 0) {
+        if (single_leaf) {
+            // pre-scaled, zero-padded copies of the two input blocks (na d + nb d elements), then the family's kernel
+            const DevLeaf& lf = hp->leaf[0];
+            int fam = FAM_SE;
+            double mult = lf.p0;  // SE iso: 1/l2; RQ: 1/(2 a l2) | 0.5/a; ARD SE: 1
+            switch (lf.op) {
+                case GPMI_K_MAT12_ISO: case GPMI_K_MAT12_ARD: fam = FAM_MAT12; mult = lf.p0 * lf.p0; break;
+                case GPMI_K_MAT32_ISO: case GPMI_K_MAT32_ARD: fam = FAM_MAT32; mult = 3.0 * lf.p0 * lf.p0; break;
+                case GPMI_K_MAT52_ISO: case GPMI_K_MAT52_ARD: fam = FAM_MAT52; mult = 5.0 * lf.p0 * lf.p0; break;
+                case GPMI_K_RQ_ISO: case GPMI_K_RQ_ARD: fam = FAM_RQ; break;
+                default: break;
+            }
+            ScaleW<DMAX> sw;
+            for (int k = 0; k < DMAX; ++k) sw.sw[k] = k < d ? sqrt(hp->w[lf.woff + k] * mult) : 0.0;
+            {
+                if (na > 0)
+                    hipLaunchKernelGGL((scale_inputs_kernel<T, DMAX>), dim3((unsigned)((na * DMAX + 255) / 256)), dim3(256), 0, ctx->stream, xa, na, d, sw, xas,
+                                       (unsigned long long*)nullptr);
+                hipLaunchKernelGGL((scale_inputs_kernel<T, DMAX>), dim3((unsigned)((nb * DMAX + 255) / 256)), dim3(256), 0, ctx->stream, xb, nb, d, sw, xbs,
+                                   (unsigned long long*)nullptr);
+                auto go = [&](auto lk) {
+                    hipLaunchKernelGGL(lk, grid, dim3(256), 0, ctx->stream, (const T*)xas, na, (const T*)xbs, nb, C, ldc, nrows_total, ncols_total,
+                                       ctx->d_prog, flags, row_off, (T)lf.s2, (T)lf.p1);
+                };
+                switch (fam) {
+                    case FAM_SE: go(cov_leaf_kernel<T, DMAX, FAM_SE>); break;
+                    case FAM_MAT12: go(cov_leaf_kernel<T, DMAX, FAM_MAT12>); break;
+                    case FAM_MAT32: go(cov_leaf_kernel<T, DMAX, FAM_MAT32>); break;
+                    case FAM_MAT52: go(cov_leaf_kernel<T, DMAX, FAM_MAT52>); break;
+                    default: go(cov_leaf_kernel<T, DMAX, FAM_RQ>); break;
+                }
+            }
+        } else if (multi) {
+            ScaleW<DMAX> one;  // unit weights: the copies are only zero-padded to DMAX
+            for (int k = 0; k < DMAX; ++k) one.sw[k] = 1.0;
+            (void)hipMemsetAsync(amax, 0, 16, ctx->stream);
+            if (na > 0)
+                hipLaunchKernelGGL((scale_inputs_kernel<T, DMAX>), dim3((unsigned)((na * DMAX + 255) / 256)), dim3(256), 0, ctx->stream, xa, na, d, one, xas, amax);
+            hipLaunchKernelGGL((scale_inputs_kernel<T, DMAX>), dim3((unsigned)((nb * DMAX + 255) / 256)), dim3(256), 0, ctx->stream, xb, nb, d, one, xbs, amax);
             auto go = [&](auto mk) {
-                hipLaunchKernelGGL(mk, grid, dim3(256), lds, ctx->stream, xa, na, xb, nb, d, C, ldc, nrows_total, ncols_total, ctx->d_prog, flags,
-                                   row_off);
+                hipLaunchKernelGGL(mk, grid, dim3(256), 0, ctx->stream, (const T*)xas, na, (const T*)xbs, nb, C, ldc, nrows_total, ncols_total, ctx->d_prog,
+                                   flags, row_off, (const unsigned long long*)amax);
             };
             switch (hp->fast_class) {
                 case 0: go(cov_multi_kernel<T, DMAX, 0>); break;

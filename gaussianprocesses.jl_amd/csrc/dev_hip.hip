@@ -464,6 +464,13 @@ __global__ __launch_bounds__(256) void sum_ranks_kernel(T* __restrict__ out, con
     out[i] = s;
 }
 
+// TEST HOOK (tests/test_gpu_dist.py: injected-latency overlap test): a kernel that occupies one wave for `us` microseconds of the
+// constant 100 MHz wall clock, enqueued in front of a collective on the stream the collective was given
+__global__ void comm_delay_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 struct LocalComm : Comm {
     LocalGroup* g;
     gpmi_ctx* c;
@@ -518,8 +525,35 @@ struct LocalComm : Comm {
                 if (hipStreamWaitEvent(s, g->done[par][q], 0) != hipSuccess) return 1;
         return 0;
     }
-    int broadcast(void* buf, int64_t bytes, int root, void* stream) override { return exchange(buf, stream, bytes, root, buf); }
-    int all_gather(const void* send, void* recv, int64_t bytes_each, void* stream) override { return exchange(send, stream, bytes_each, -1, recv); }
+    // GPMI_TEST_COMM_DELAY_US (read per call, so a test can change it between fits): extra latency in front of every inverse broadcast and
+    // every panel exchange (its per-group gathers are one exchange: the delay goes in front of the first) — how tests measure what the
+    // look-ahead pipeline of blocked.cpp really hides
+    long long delayed = 0;
+    bool in_group = false, group_delayed = false;
+    void inject_delay(void* stream) {
+        const char* e = getenv("GPMI_TEST_COMM_DELAY_US");
+        const long long us = e ? atoll(e) : 0;
+        if (us <= 0) return;
+        hipLaunchKernelGGL(comm_delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, us * 100);
+        ++delayed;
+    }
+    void group_begin() override {
+        in_group = true;
+        group_delayed = false;
+    }
+    int group_end() override {
+        in_group = false;
+        return 0;
+    }
+    int broadcast(void* buf, int64_t bytes, int root, void* stream) override {
+        inject_delay(stream);
+        return exchange(buf, stream, bytes, root, buf);
+    }
+    int all_gather(const void* send, void* recv, int64_t bytes_each, void* stream) override {
+        if (!in_group || !group_delayed) inject_delay(stream);
+        group_delayed = true;
+        return exchange(send, stream, bytes_each, -1, recv);
+    }
     int all_reduce_sum(void* buf, int64_t count, int es, void* stream) override {
         const int64_t need = (int64_t)world * count * es;
         if (red_cap < need) {
@@ -594,9 +628,9 @@ int group_create(gpmi_ctx* primary, int n, const int* ids) {
     // direct peer copies between distinct devices (errors are not fatal: the runtime then stages through the host)
     for (int a = 0; a < n; ++a)
         for (int b = 0; b < n; ++b)
-            if (ids[a] != ids[b]) {
-                (void)hipSetDevice(ids[a]);
-                if (hipDeviceEnablePeerAccess(ids[b], 0) != hipSuccess) (void)hipGetLastError();
+            if ((ids[a] & 255) != (ids[b] & 255)) {  // (ids may carry a CU-partition code above bit 8)
+                (void)hipSetDevice(ids[a] & 255);
+                if (hipDeviceEnablePeerAccess(ids[b] & 255, 0) != hipSuccess) (void)hipGetLastError();
             }
     (void)hipSetDevice(primary->device);
     return GPMI_OK;

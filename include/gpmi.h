@@ -96,7 +96,11 @@ typedef struct gpmi_gp gpmi_gp;   /* one per GPE: resident x, factor, alpha     
  * on such a context shards the model row-block-wise over the group's devices and runs one worker thread per member inside
  * every gpmi_fit / gpmi_predict / gpmi_grad on it; every other entry point runs on device_ids[0].  This is the
  * single-process multi-GPU form (a Julia session driving all the GPUs of a node); the one-process-per-GPU form is a
- * communicator (gpmi_comm_*) on single-device contexts.                                                              */
+ * communicator (gpmi_comm_*) on single-device contexts.
+ * CU PARTITIONS: a device id may be given as  id + 256 * (1 + p),  p = 0 | 1: the context's streams are then confined to half p
+ * of every XCD (16 of its 32 compute units, 128 in all), so two such contexts — or the two members of a device group
+ * {id + 256, id + 512} — run side by side on one MI355X without sharing a compute unit: the software stand-in for the driver's
+ * compute partitioning where that is not available (two models on one GPU; two logical devices for the multi-device path).  */
 GPMI_API int gpmi_ctx_create(int n_devices, const int* device_ids, gpmi_ctx** out);
 GPMI_API void gpmi_ctx_destroy(gpmi_ctx*);
 /* waits for ALL work on the context's device(s) (every entry point already returns with its results on the host; this is the
