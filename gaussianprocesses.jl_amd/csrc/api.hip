@@ -27,7 +27,7 @@ static bool is_iso(int op) {
            op == GPMI_K_RQ_ISO;
 }
 
-int digest_kernel(const gpmi_kernel* k, int d, DevProgram* out, std::string* err) {
+int digest_kernel(const gpmi_kernel* k, int d, std::vector<unsigned char>* buf, std::string* err) {
     if (!k || !k->ops || !k->dims_off || !k->params || k->n_ops <= 0) {
         *err = "kernel descriptor: null field or empty program";
         return GPMI_EARG;
@@ -36,17 +36,22 @@ int digest_kernel(const gpmi_kernel* k, int d, DevProgram* out, std::string* err
         *err = "kernel descriptor: more than GPMI_MAX_OPS nodes";
         return GPMI_EARG;
     }
-    if (d <= 0 || d > MAX_D) {
-        *err = "input dimension must be in 1..64";
+    if (d <= 0 || d > (1 << 20)) {
+        *err = "input dimension must be positive";
         return GPMI_EARG;
     }
-    memset(out, 0, sizeof(DevProgram));
+    int64_t nleaf = 0;
+    for (int o = 0; o < k->n_ops; ++o) nleaf += (k->ops[o] != GPMI_K_SUM && k->ops[o] != GPMI_K_PROD) ? 1 : 0;
+    const int64_t w_count = nleaf * d;
+    buf->assign((size_t)program_bytes(w_count), 0);
+    DevProgram* out = reinterpret_cast<DevProgram*>(buf->data());
     out->n_ops = k->n_ops;
     out->d = d;
+    out->w_count = w_count;
     int pp = 0, depth = 0, wcur = 0, hyp = 0;
     double kst[GPMI_MAX_OPS];
     int nst[GPMI_MAX_OPS];  // node index of each stack entry
-    for (int q = 0; q < GPMI_MAX_OPS * MAX_D; ++q) out->pmap[q] = -1;
+    for (int64_t q = 0; q < w_count; ++q) out->pmtab()[q] = -1;
     for (int o = 0; o < k->n_ops; ++o) {
         const int op = k->ops[o];
         DevLeaf& lf = out->leaf[o];
@@ -81,7 +86,7 @@ int digest_kernel(const gpmi_kernel* k, int d, DevProgram* out, std::string* err
         const double* par = k->params + pp;
         pp += npar;
         lf.woff = wcur;
-        double* w = out->w + wcur;
+        double* w = out->wtab() + wcur;
         wcur += d;
         for (int z = 0; z < nd; ++z) {
             const int kk = (d1 > d0) ? k->dims[d0 + z] : z;
@@ -90,7 +95,7 @@ int digest_kernel(const gpmi_kernel* k, int d, DevProgram* out, std::string* err
                 return GPMI_EARG;
             }
             w[kk] += is_ard(op) ? par[z] : 1.0;
-            if (is_ard(op)) out->pmap[lf.woff + kk] = (int16_t)z;
+            if (is_ard(op)) out->pmtab()[lf.woff + kk] = (int32_t)z;
         }
         lf.poff = hyp;
         lf.nd = nd;
@@ -260,9 +265,22 @@ int set_lookahead_mode(gpmi_ctx* c, bool whole) {
 // drivers
 // ---------------------------------------------------------------------------------------------
 int upload_program(gpmi_ctx* c, const gpmi_kernel* k, int d) {
-    int rc = digest_kernel(k, d, c->h_prog, &c->err);
+    int rc = digest_kernel(k, d, &c->prog_buf, &c->err);
     if (rc != GPMI_OK) return rc;
-    GPMI_HIP(c, hipMemcpyAsync(c->d_prog, c->h_prog, sizeof(DevProgram), hipMemcpyHostToDevice, c->stream));
+    const int64_t bytes = (int64_t)c->prog_buf.size();
+    if (bytes > c->prog_cap) {  // header + weight tables: grown to the largest program seen
+        GPMI_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->d_prog) (void)hipFree(c->d_prog);
+        if (c->h_prog) (void)hipHostFree(c->h_prog);
+        c->d_prog = c->h_prog = nullptr;
+        c->prog_cap = 0;
+        const int64_t cap = std::max<int64_t>(bytes, program_bytes(1024));
+        GPMI_HIP(c, hipMalloc(&c->d_prog, (size_t)cap));
+        GPMI_HIP(c, hipHostMalloc(&c->h_prog, (size_t)cap));
+        c->prog_cap = cap;
+    }
+    memcpy(c->h_prog, c->prog_buf.data(), (size_t)bytes);
+    GPMI_HIP(c, hipMemcpyAsync(c->d_prog, c->h_prog, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
     // h_prog is reused by the next call: make sure the copy has left the staging buffer
     GPMI_HIP(c, hipStreamSynchronize(c->stream));
     return GPMI_OK;
@@ -385,10 +403,6 @@ static int grad_t(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, do
     int rc = upload_program(c, k, gp->d);
     if (rc != GPMI_OK) return rc;
     const int n_hyp = c->h_prog->n_hyp;
-    if (c->h_prog->n_ops > GRAD_MAX_NODES || n_hyp > GRAD_MAX_HYP || gp->d > GRAD_MAX_D) {
-        c->err = grad_limit_message();
-        return GPMI_EARG;
-    }
     const size_t bytes = (size_t)(npad * ld) * sizeof(T);
     if (const int rc_g = alloc_grad_scratch(gp, bytes)) return rc_g;
     T* G1 = (T*)gp->g1;
@@ -684,8 +698,8 @@ static int create_one_context(int dev_code, gpmi_ctx** out) {
         }
     }
     if (hipSetDevice(dev) != hipSuccess || (!c->own_stream && hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) ||
-        hipMalloc(&c->d_prog, sizeof(DevProgram)) != hipSuccess ||
-        hipHostMalloc(&c->h_prog, sizeof(DevProgram)) != hipSuccess || hipMalloc(&c->d_info, sizeof(int)) != hipSuccess ||
+        hipMalloc(&c->d_prog, (size_t)program_bytes(1024)) != hipSuccess ||
+        hipHostMalloc(&c->h_prog, (size_t)program_bytes(1024)) != hipSuccess || hipMalloc(&c->d_info, sizeof(int)) != hipSuccess ||
         hipMalloc(&c->d_scal, 8 * sizeof(double)) != hipSuccess ||
         hipHostMalloc(&c->h_scal, 8 * sizeof(double)) != hipSuccess ||
         hipMalloc(&c->d_queue, (64 + 4 * 1024) * sizeof(unsigned long long)) != hipSuccess ||
@@ -697,6 +711,8 @@ static int create_one_context(int dev_code, gpmi_ctx** out) {
         return GPMI_EDEVICE;
     }
     c->stream = c->own_stream;
+    c->prog_cap = program_bytes(1024);
+    memset(c->h_prog, 0, sizeof(DevProgram));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
     const int device_cus = c->num_cus;
@@ -797,7 +813,7 @@ int gpmi_ctx_synchronize(gpmi_ctx* c) {
 
 int gpmi_gp_create(gpmi_ctx* c, int dtype, int d, int64_t n, const void* x, gpmi_gp** out) {
     if (!c) return earg(c, "gpmi_gp_create: bad argument");
-    if (!out || !x || (dtype != 64 && dtype != 32) || d <= 0 || d > MAX_D || n <= 0) {
+    if (!out || !x || (dtype != 64 && dtype != 32) || d <= 0 || n <= 0) {
         c->err = "gpmi_gp_create: bad argument (dtype must be 64|32, 1 <= d <= 64, n >= 1)";
         return GPMI_EARG;
     }
@@ -923,8 +939,8 @@ int gpmi_grad(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int64_
     }
     {   // the caller's buffer must match the kernel's parameter count
         std::string err;
-        DevProgram* tmp = c->h_prog;
-        if (digest_kernel(k, gp->d, tmp, &err) != GPMI_OK || tmp->n_hyp != n_kern) {
+        std::vector<unsigned char> tmpb;
+        if (digest_kernel(k, gp->d, &tmpb, &err) != GPMI_OK || reinterpret_cast<const DevProgram*>(tmpb.data())->n_hyp != n_kern) {
             c->err = err.empty() ? "gpmi_grad: dkern_out length differs from the kernel's number of parameters" : err;
             return GPMI_EARG;
         }

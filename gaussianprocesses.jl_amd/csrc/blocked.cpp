@@ -723,7 +723,6 @@ int BlockedGP::grad(const gpmi_kernel* kern, const double* log_noise, int64_t n_
     int n_hyp = 0, rc;
     if ((rc = dev_->set_kernel(kern, d_, &kdiag_, &n_hyp)) != GPMI_OK) return fail(rc, dev_->err);
     if (n_hyp != n_kern) return fail(GPMI_EARG, "gpmi_grad: dkern_out length differs from the kernel's number of parameters");
-    if ((rc = dev_->grad_limits(d_)) != GPMI_OK) return fail(rc, dev_->err);  // the dense gpmi_grad's limits and message (api.hip grad_t)
     const int64_t ldG = padded(npad_);
     const int64_t own_rows = (int64_t)std::max(nown_, 1) * WD_;
     if ((rc = grow(&Vb_, &Vb_cap_, WD_ * ldG * es_))) return rc;
@@ -790,7 +789,8 @@ int BlockedGP::grad(const gpmi_kernel* kern, const double* log_noise, int64_t n_
     dev_->download(h.data(), dacc_, (int64_t)(n_hyp + 2) * 8);
     dev_->sync();
     if ((rc = check_dev("gpmi_grad"))) return rc;
-    if (comm_ && G_ > 1) comm_rc_ |= comm_->host_allreduce(h.data(), n_hyp + 1, 0);
+    if (comm_ && G_ > 1)  // in pieces: a communicator's host reduction carries a bounded number of doubles per call
+        for (int p0 = 0; p0 < n_hyp + 1; p0 += 64) comm_rc_ |= comm_->host_allreduce(h.data() + p0, std::min(64, n_hyp + 1 - p0), 0);
     if ((rc = check_dev("gpmi_grad"))) return rc;
     for (int p = 0; p < n_hyp; ++p) dkern_out[p] = h[(size_t)p];
     if (dnoise_out) *dnoise_out = exp(2.0 * log_noise[0]) * h[(size_t)n_hyp];  // GPE.jl:273-275

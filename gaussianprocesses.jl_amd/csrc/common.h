@@ -25,7 +25,6 @@ constexpr int SUPER = 8;      // tiles per super-tile edge (XCD-aware ordering)
 // wrapper hides, il2[z] on active ARD rows, 1 on active iso rows), so the device loop
 // is the same for Masked / ARD / iso leaves:  r = sum_k w_k (x_k - y_k)^2.
 // ------------------------------------------------------------------------------------------
-constexpr int MAX_D = 64;
 struct DevLeaf {
     int32_t op;     // gpmi_op
     int32_t woff;   // offset of this leaf's d weights inside DevProgram::w (leaf ops only)
@@ -47,12 +46,20 @@ struct DevProgram {
     int32_t n_hyp;  // total number of kernel hyper-parameters (get_params order)
     int32_t pad2_;
     DevLeaf leaf[GPMI_MAX_OPS];
-    double w[GPMI_MAX_OPS * MAX_D];
-    int16_t pmap[GPMI_MAX_OPS * MAX_D];  // ARD leaves: slot offset (within the leaf) of input row k, or -1
+    // The per-leaf tables FOLLOW the struct in the same allocation (sized at run time: any input dimension d — the reference's
+    // distance loops take any `dim`, src/kernels/distance.jl:41-106):  double w[w_count]  (leaf l's d weights at w[leaf[l].woff ..]),
+    // then  int32_t pmap[w_count]  (ARD leaves: slot offset, within the leaf, of input row k, or -1).
+    int64_t w_count;
+    __host__ __device__ const double* wtab() const { return reinterpret_cast<const double*>(this + 1); }
+    __host__ __device__ double* wtab() { return reinterpret_cast<double*>(this + 1); }
+    __host__ __device__ const int32_t* pmtab() const { return reinterpret_cast<const int32_t*>(wtab() + w_count); }
+    __host__ __device__ int32_t* pmtab() { return reinterpret_cast<int32_t*>(wtab() + w_count); }
 };
+static_assert(sizeof(DevProgram) % 8 == 0, "the weight table behind DevProgram must be 8-byte aligned");
+inline int64_t program_bytes(int64_t w_count) { return (int64_t)sizeof(DevProgram) + w_count * 12; }
 
-// digest + validate; returns GPMI_OK / GPMI_EARG and fills err
-int digest_kernel(const gpmi_kernel* k, int d, DevProgram* out, std::string* err);
+// digest + validate into a buffer of program_bytes(leaves * d) (grown as needed); returns GPMI_OK / GPMI_EARG and fills err
+int digest_kernel(const gpmi_kernel* k, int d, std::vector<unsigned char>* buf, std::string* err);
 
 // ------------------------------------------------------------------------------------------
 // profiling (event pairs around launches, per class)
@@ -80,8 +87,10 @@ struct gpmi_ctx {
     int group_rank = 0;     // 0 = the primary (the handle the caller holds)
     hipStream_t stream = nullptr;
     std::string err;
-    gpmi::DevProgram* d_prog = nullptr;  // device copy of the current kernel program
-    gpmi::DevProgram* h_prog = nullptr;  // pinned staging
+    gpmi::DevProgram* d_prog = nullptr;  // device copy of the current kernel program (header + weight tables, grown to fit)
+    gpmi::DevProgram* h_prog = nullptr;  // pinned staging, same size
+    int64_t prog_cap = 0;                // bytes allocated for each of the two
+    std::vector<unsigned char> prog_buf; // digest scratch
     int* d_info = nullptr;               // not-PD flag (1-based pivot)
     double* d_scal = nullptr;            // small double outputs (mll, logdet, dot)
     double* h_scal = nullptr;            // pinned
@@ -261,7 +270,8 @@ int upload_program(gpmi_ctx* c, const gpmi_kernel* k, int d);                 //
 int grow(gpmi_ctx* c, void** p, int64_t* cap, int64_t need_bytes);            // (re)allocate a device scratch buffer
 
 // kernel launchers (each enqueues on ctx->stream; T = double | float) -------------------------
-enum CovFlags { COV_LOWER = 1, COV_NUGGET = 2, COV_PAD_IDENTITY = 4, COV_NO_FAST = 8 /* internal: the interpreter takes every tile */ };
+enum CovFlags { COV_LOWER = 1, COV_NUGGET = 2, COV_PAD_IDENTITY = 4, COV_NO_FAST = 8 /* internal: the interpreter takes every tile */,
+                COV_GLOBAL_X = 16 /* internal: d too large to stage in LDS, operands read from global memory */ };
 
 // C[i][j] = k(xa_i, xb_j) for i < nrows_total, j < ncols_total (row-major, ld = ldc).
 // rows >= na / cols >= nb are padding: 0, or the identity when COV_PAD_IDENTITY.
@@ -357,10 +367,11 @@ template <typename T>
 void launch_logdiag(gpmi_ctx* ctx, const T* A, int64_t ld, int64_t nrows, int64_t col_off, double* out);
 
 // gradient path -------------------------------------------------------------------------------------------
-constexpr int GRAD_MAX_NODES = 32;  // kernel-tree size the device gradient handles (cost grows with leaves^2)
-constexpr int GRAD_MAX_HYP = 64;    // hyper-parameters: (n_hyp + 1) x 256 double accumulators + the 64 x d row points share the 160 KB of LDS
-constexpr int GRAD_MAX_D = 32;      // input dimension (the pair's d squared differences live in registers)
-inline const char* grad_limit_message() { return "gpmi_grad: kernel outside the device gradient path (<= 64 hyper-parameters, d <= 32)"; }
+// the register / LDS forms of the gradient kernel (grad.hip) take up to this many hyper-parameters ((n_hyp + 1) x 256 double
+// accumulators + the 64 x d row points share the 160 KB of LDS) and input dimensions (the pair's d squared differences live in
+// registers); beyond either the limit-free form runs (dmll_kernel<T, 0, .>): no kernel is refused
+constexpr int GRAD_MAX_HYP = 64;
+constexpr int GRAD_MAX_D = 32;
 // A[i][i] = 1, everything else 0 (n x n, row-major)
 template <typename T>
 void launch_set_identity(gpmi_ctx* ctx, T* A, int64_t ld, int64_t n);

@@ -257,11 +257,23 @@ __global__ __launch_bounds__(256) void cov_leaf_kernel(const T* __restrict__ xas
 // behind a prefilter: noise.jl:31-37 asks x_z ~ y_z for every active row z (isapprox, rtol sqrt(eps)), which needs
 // (x_z - y_z)^2 <= (rtol max|x|)^2 for all z — one v_max per row on the squared differences the other leaves need anyway; the exact
 // test runs only where some lane of the wave passes it (coincident points: the diagonal, duplicates).
+// one-instruction maximum (fmax() canonicalises both operands first: three v_max per call)
+__device__ __forceinline__ double max_raw(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float max_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 template <typename T, int DMAX>
 struct LeafLds {
     T w[DMAX];
     T s2, p0, p1;
-    int op, pad_;
+    int op, actmask;  // actmask: bit k set when the leaf acts on input row k (w_k != 0)
 };
 
 template <typename T, int DMAX, int FEAT>
@@ -283,19 +295,25 @@ __global__ __launch_bounds__(256) void cov_multi_kernel(const T* __restrict__ xa
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const int d = prog->d;
-    for (int e = tid; e < nops * (DMAX + 4); e += 256) {  // the program, once per workgroup
-        const int o = e / (DMAX + 4), j = e - o * (DMAX + 4);
+    for (int e = tid; e < nops * (DMAX + 5); e += 256) {  // the program, once per workgroup
+        const int o = e / (DMAX + 5), j = e - o * (DMAX + 5);
         const DevLeaf& lf = prog->leaf[o];
         if (j < DMAX)
-            s_leaf[o].w[j] = (j < d && lf.op < GPMI_K_SUM) ? (T)prog->w[lf.woff + j] : T(0);
+            s_leaf[o].w[j] = (j < d && lf.op < GPMI_K_SUM) ? (T)prog->wtab()[lf.woff + j] : T(0);
         else if (j == DMAX)
             s_leaf[o].s2 = (T)lf.s2;
         else if (j == DMAX + 1)
             s_leaf[o].p0 = (T)lf.p0;
         else if (j == DMAX + 2)
             s_leaf[o].p1 = (T)lf.p1;
-        else
+        else if (j == DMAX + 3)
             s_leaf[o].op = lf.op;
+        else {
+            int m = 0;
+            if (lf.op < GPMI_K_SUM)
+                for (int k = 0; k < d && k < DMAX; ++k) m |= (prog->wtab()[lf.woff + k] != 0.0) ? (1 << k) : 0;
+            s_leaf[o].actmask = m;
+        }
     }
     // this lane's VEC columns of the zero-padded column block
     T xbr[DMAX][VEC];
@@ -372,16 +390,15 @@ __global__ __launch_bounds__(256) void cov_multi_kernel(const T* __restrict__ xa
                     for (int i = 0; i < NR; ++i)
 #pragma unroll
                         for (int q = 0; q < VEC; ++q) mx[i][q] = T(0);
+                    const int am = __builtin_amdgcn_readfirstlane(s_leaf[o].actmask);  // wave-uniform: scalar branches, one v_max per element
 #pragma unroll
                     for (int k = 0; k < DMAX; ++k) {
-                        const T act = s_leaf[o].w[k];  // 0 on rows the leaf does not act on (and on the padding)
+                        if ((am >> k) & 1) {
 #pragma unroll
-                        for (int i = 0; i < NR; ++i)
+                            for (int i = 0; i < NR; ++i)
 #pragma unroll
-                            for (int q = 0; q < VEC; ++q) {
-                                const T v = act != T(0) ? dsq[i][k][q] : T(0);
-                                mx[i][q] = v > mx[i][q] ? v : mx[i][q];
-                            }
+                                for (int q = 0; q < VEC; ++q) mx[i][q] = max_raw(mx[i][q], dsq[i][k][q]);  // (a NaN difference leaves mx alone: the lane stays a candidate and the exact test decides)
+                        }
                     }
                     bool cand = false;
 #pragma unroll
@@ -395,7 +412,7 @@ __global__ __launch_bounds__(256) void cov_multi_kernel(const T* __restrict__ xa
                             for (int q = 0; q < VEC; ++q) {
                                 bool same = true;
                                 for (int k = 0; k < d; ++k) {
-                                    if (s_leaf[o].w[k] != T(0)) {
+                                    if ((am >> k) & 1) {
                                         const T a = ar[(rr + i) * DMAX + k], b = xbs[(col0 + (int64_t)lane * VEC + q) * DMAX + k];
                                         const T m = fabs(a) > fabs(b) ? fabs(a) : fabs(b);
                                         same = same && ((a == b) || (fabs(a - b) <= Tr<T>::isapprox_rtol * m));
@@ -510,20 +527,26 @@ __global__ __launch_bounds__(256) void cov_kernel(const T* __restrict__ xa, int6
     if ((flags & COV_LOWER) && col0 > row_off + row0 + TR - 1) return;  // tile strictly above the diagonal
 
     const int tid = threadIdx.x;
-    for (int e = tid; e < TR * d; e += 256) {
-        int r = e / d, k = e - r * d;
-        int64_t gr = row0 + r;
-        gr = gr < na ? gr : na - 1;
-        gr = gr < 0 ? 0 : gr;
-        sa[e] = xa[gr * d + k];
+    // d beyond what two staged blocks of LDS hold (COV_GLOBAL_X, DMAX == 0 only): the operands are read from global memory where
+    // they are used (the column block through L1 / L2, the row values wave-uniform) — any input dimension, as the reference's
+    // distance loops (src/kernels/distance.jl:41-106); slower per entry, and rare
+    const bool gx = DMAX == 0 && (flags & COV_GLOBAL_X);
+    if (!gx) {
+        for (int e = tid; e < TR * d; e += 256) {
+            int r = e / d, k = e - r * d;
+            int64_t gr = row0 + r;
+            gr = gr < na ? gr : na - 1;
+            gr = gr < 0 ? 0 : gr;
+            sa[e] = xa[gr * d + k];
+        }
+        for (int e = tid; e < TC * d; e += 256) {
+            int c = e / d, k = e - c * d;
+            int64_t gc = col0 + c;
+            gc = gc < nb ? gc : nb - 1;
+            sbT[k * TC + c] = xb[gc * d + k];
+        }
+        __syncthreads();
     }
-    for (int e = tid; e < TC * d; e += 256) {
-        int c = e / d, k = e - c * d;
-        int64_t gc = col0 + c;
-        gc = gc < nb ? gc : nb - 1;
-        sbT[k * TC + c] = xb[gc * d + k];
-    }
-    __syncthreads();
 
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -555,6 +578,17 @@ __global__ __launch_bounds__(256) void cov_kernel(const T* __restrict__ xa, int6
         const int64_t grow = row0 + row;
         if (grow >= nrows) break;
         const T* sar = sa + row * d;
+        // global-operand form: clamped row / column pointers (padding rows repeat the last point; they are masked when stored)
+        int64_t grc = grow < na ? grow : na - 1;
+        grc = grc < 0 ? 0 : grc;
+        const T* gar = xa + grc * d;
+        const T* gbc[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            int64_t gc = col0 + (int64_t)lane * VEC + q;
+            gc = gc < nb ? gc : nb - 1;
+            gbc[q] = xb + gc * d;
+        }
 
         T dsq[DMAX > 0 ? DMAX : 1][VEC];
         if constexpr (DMAX > 0) {
@@ -598,16 +632,16 @@ __global__ __launch_bounds__(256) void cov_kernel(const T* __restrict__ xa, int6
                 for (int q = 0; q < VEC; ++q) val[q] = s2;
             } else if (op == GPMI_K_NOISE) {
                 // noise.jl:31-37: all active rows z satisfy X1[z,i] ≈ X2[z,j]
-                const double* w = prog->w + prog->leaf[o].woff;
+                const double* w = prog->wtab() + prog->leaf[o].woff;
                 bool same[VEC];
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) same[q] = true;
                 for (int k = 0; k < d; ++k) {
                     if (w[k] != 0.0) {
-                        T a = sar[k];
+                        T a = gx ? gar[k] : sar[k];
 #pragma unroll
                         for (int q = 0; q < VEC; ++q) {
-                            T b = sbT[k * TC + lane * VEC + q];
+                            T b = gx ? gbc[q][k] : sbT[k * TC + lane * VEC + q];
                             T m = fabs(a) > fabs(b) ? fabs(a) : fabs(b);
                             bool ok = (a == b) || (fabs(a - b) <= Tr<T>::isapprox_rtol * m);
                             same[q] = same[q] && ok;
@@ -617,7 +651,7 @@ __global__ __launch_bounds__(256) void cov_kernel(const T* __restrict__ xa, int6
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) val[q] = same[q] ? s2 : T(0);
             } else {
-                const double* w = prog->w + prog->leaf[o].woff;
+                const double* w = prog->wtab() + prog->leaf[o].woff;
                 T r[VEC];
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) r[q] = T(0);
@@ -633,8 +667,14 @@ __global__ __launch_bounds__(256) void cov_kernel(const T* __restrict__ xa, int6
                 } else {
                     for (int k = 0; k < d; ++k) {
                         T wk = (T)w[k];
-                        T a = sar[k];
-                        VT bv = *reinterpret_cast<const VT*>(&sbT[k * TC + lane * VEC]);
+                        T a = gx ? gar[k] : sar[k];
+                        VT bv;
+                        if (gx) {
+#pragma unroll
+                            for (int q = 0; q < VEC; ++q) bv[q] = gbc[q][k];
+                        } else {
+                            bv = *reinterpret_cast<const VT*>(&sbT[k * TC + lane * VEC]);
+                        }
 #pragma unroll
                         for (int q = 0; q < VEC; ++q) {
                             T df = a - bv[q];
@@ -684,6 +724,10 @@ void launch_cov_t(gpmi_ctx* ctx, const T* xa, int64_t na, const T* xb, int64_t n
     constexpr int TR = 64;
     dim3 grid((unsigned)((ncols_total + TC - 1) / TC), (unsigned)((nrows_total + TR - 1) / TR));
     size_t lds = (size_t)(TR + TC) * d * sizeof(T);
+    if (DMAX == 0 && lds > 128 * 1024) {  // the two staged blocks do not fit the LDS: operands from global memory (any d)
+        lds = 0;
+        flags |= COV_GLOBAL_X;
+    }
     auto kern = cov_kernel<T, DMAX>;
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const DevProgram* hp = ctx->h_prog;
@@ -722,7 +766,7 @@ void launch_cov_t(gpmi_ctx* ctx, const T* xa, int64_t na, const T* xb, int64_t n
                 default: break;
             }
             ScaleW<DMAX> sw;
-            for (int k = 0; k < DMAX; ++k) sw.sw[k] = k < d ? sqrt(hp->w[lf.woff + k] * mult) : 0.0;
+            for (int k = 0; k < DMAX; ++k) sw.sw[k] = k < d ? sqrt(hp->wtab()[lf.woff + k] * mult) : 0.0;
             {
                 if (na > 0)
                     hipLaunchKernelGGL((scale_inputs_kernel<T, DMAX>), dim3((unsigned)((na * DMAX + 255) / 256)), dim3(256), 0, ctx->stream, xa, na, d, sw, xas,

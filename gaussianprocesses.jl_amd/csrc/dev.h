@@ -57,9 +57,6 @@ struct Dev {
     virtual void* native_stream() = 0;  // the current stream, as the communicator wants it (hipStream_t; nullptr on the host)
     // ---- kernel program ----
     virtual int set_kernel(const gpmi_kernel* k, int d, double* kdiag, int* n_hyp) = 0;  // GPMI_* status
-    // can the device gradient (dmll_rect_acc) take the program of the last set_kernel at input dimension d?  GPMI_OK, or GPMI_EARG with
-    // err set — the same limits and the same message as the dense gpmi_grad (tree nodes, hyper-parameters, d)
-    virtual int grad_limits(int d) = 0;
     // ---- covariance ----
     // rows [row_off, row_off + nrows) of K + noise into A (lower tiles only, identity padding past n): update_cK!, GPE.jl:169-186
     virtual void assemble(const void* x, int64_t n, int d, int64_t row_off, int64_t nrows, double nugget, const double* nugget_vec_dev,

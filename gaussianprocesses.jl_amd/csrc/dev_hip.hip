@@ -219,13 +219,6 @@ struct HipDev : Dev {
         *n_hyp = c->h_prog->n_hyp;
         return GPMI_OK;
     }
-    int grad_limits(int d) override {
-        if (c->h_prog->n_ops > GRAD_MAX_NODES || c->h_prog->n_hyp > GRAD_MAX_HYP || d > GRAD_MAX_D) {
-            err = grad_limit_message();
-            return GPMI_EARG;
-        }
-        return GPMI_OK;
-    }
     void assemble(const void* x, int64_t n, int d, int64_t row_off, int64_t nrows, double nugget, const double* nvec, void* A, int64_t ld,
                   int64_t ncols) override {
         const int64_t na = std::max<int64_t>(0, std::min<int64_t>(nrows, n - row_off));
@@ -530,10 +523,12 @@ struct LocalComm : Comm {
     // look-ahead pipeline of blocked.cpp really hides
     long long delayed = 0;
     bool in_group = false, group_delayed = false;
-    void inject_delay(void* stream) {
+    void inject_delay(void* stream, int what /* 1 broadcast, 2 panel exchange */) {
         const char* e = getenv("GPMI_TEST_COMM_DELAY_US");
         const long long us = e ? atoll(e) : 0;
         if (us <= 0) return;
+        const char* on = getenv("GPMI_TEST_COMM_DELAY_ON");  // 1: broadcasts only, 2: panel exchanges only, default both
+        if (on && !(atoi(on) & what)) return;
         hipLaunchKernelGGL(comm_delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, us * 100);
         ++delayed;
     }
@@ -546,11 +541,11 @@ struct LocalComm : Comm {
         return 0;
     }
     int broadcast(void* buf, int64_t bytes, int root, void* stream) override {
-        inject_delay(stream);
+        inject_delay(stream, 1);
         return exchange(buf, stream, bytes, root, buf);
     }
     int all_gather(const void* send, void* recv, int64_t bytes_each, void* stream) override {
-        if (!in_group || !group_delayed) inject_delay(stream);
+        if (!in_group || !group_delayed) inject_delay(stream, 2);
         group_delayed = true;
         return exchange(send, stream, bytes_each, -1, recv);
     }
@@ -932,7 +927,7 @@ int gpmi_comm_selftest(gpmi_ctx* c, gpmi_comm* cm) {
 int gpmi_gp_create_blocked(gpmi_ctx* c, gpmi_comm* comm, int dtype, int d, int64_t n, const void* x, int64_t block_rows, int stripe_blocks,
                            gpmi_gp** out) {
     if (!c) return GPMI_EARG;
-    if (!out || !x || (dtype != 64 && dtype != 32) || d <= 0 || d > MAX_D || n <= 0 || block_rows < 0 || stripe_blocks < 0) {
+    if (!out || !x || (dtype != 64 && dtype != 32) || d <= 0 || n <= 0 || block_rows < 0 || stripe_blocks < 0) {
         c->err = "gpmi_gp_create_blocked: bad argument (dtype must be 64|32, 1 <= d <= 64, n >= 1)";
         return GPMI_EARG;
     }

@@ -521,10 +521,6 @@ int fitc_grad_t(gpmi_fitc* f, const gpmi_kernel* k, double log_noise, double* dk
             return GPMI_EARG;
         }
     }
-    if (n_hyp > GRAD_MAX_HYP || f->d > GRAD_MAX_D || c->h_prog->n_ops > GRAD_MAX_NODES) {
-        c->err = "gpmi_fitc_grad: the device gradient covers kernels with <= 64 hyper-parameters, <= 32 nodes, d <= 32";
-        return GPMI_EARG;
-    }
     const size_t es = sizeof(T);
     const int64_t big = std::max<int64_t>(n * ldm, mpad * ldn);
     if (!f->gA) GPMI_HIP(c, hipMalloc(&f->gA, (size_t)big * es));
@@ -626,7 +622,7 @@ void gpmi_fitc_destroy(gpmi_fitc* f) {
 int gpmi_fitc_create(gpmi_ctx* c, int dtype, int d, int64_t n, const void* x, int64_t m, const void* xu, gpmi_fitc** out) {
     using namespace gpmi;
     if (!c) return GPMI_EARG;
-    if (!out || !x || !xu || (dtype != 64 && dtype != 32) || d <= 0 || d > MAX_D || n <= 0 || m <= 0) {
+    if (!out || !x || !xu || (dtype != 64 && dtype != 32) || d <= 0 || n <= 0 || m <= 0) {
         c->err = "gpmi_fitc_create: bad argument (dtype must be 64|32, 1 <= d <= 64, n >= 1, m >= 1)";
         return GPMI_EARG;
     }

@@ -50,32 +50,43 @@ __device__ __forceinline__ bool is_ard_op(int op) {
 
 // RECT (FITC gradient, fitc.hip): the same reduction over a RECTANGLE of pairs (x_i, xb_j), i < n, j < nb, with an explicit
 // weight matrix:  partial[p] = sum_ij Wt[i][j] dk(x_i, xb_j)/dθ_p  — `Kinv` is Wt, alpha is unused, no triangle, no trace slot.
+// GEN (DMAX == 0): the form without limits — any input dimension, any number of hyper-parameters (the reference's dmll_kern! loops
+// over whatever the kernel has, src/GPE.jl:219-241).  Nothing per-dimension or per-parameter lives in registers or in a
+// [slot][thread] LDS table: the pair's differences are re-read from global memory (L1 / L2) wherever they are used, and every
+// contribution is reduced across the wave at once (shuffles: a fixed order, so still bit-reproducible) into a [wave][slot] table.
+// Several times slower per pair than the register forms; it only runs for d > 32 or more than 64 hyper-parameters.
 template <typename T, int DMAX, bool RECT>
 __global__ __launch_bounds__(256) void dmll_kernel(const T* __restrict__ x, int64_t n, int d, const T* __restrict__ alpha,
                                                    const T* __restrict__ Kinv, int64_t ld,
                                                    const DevProgram* __restrict__ prog, double* __restrict__ partial,
                                                    int n_hyp, const T* __restrict__ xb_pts, int64_t nb) {
     constexpr int GSTK = 6;  // evaluation-stack depth (validated on the host, as for cov)
+    constexpr bool GEN = DMAX == 0;
+    constexpr int DREG = GEN ? 1 : DMAX;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* gl = reinterpret_cast<double*>(smem);                 // [n_hyp + 1][256] accumulators
-    T* sa = reinterpret_cast<T*>(gl + (size_t)(n_hyp + 1) * 256);  // [64][d] row points
-    T* sal = sa + 64 * d;                                         // [64] alpha of the rows
-    double* red = reinterpret_cast<double*>(sal + 64);            // [4][n_hyp + 1]
+    double* gl = reinterpret_cast<double*>(smem);                                   // [n_hyp + 1][256] accumulators (GEN: none)
+    T* sa = reinterpret_cast<T*>(gl + (GEN ? 0 : (size_t)(n_hyp + 1) * 256));       // [64][d] row points (GEN: none)
+    T* sal = sa + (GEN ? 0 : 64 * d);                                               // [64] alpha of the rows
+    double* red = reinterpret_cast<double*>(sal + 64);                              // [4][n_hyp + 1]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t row0 = (int64_t)blockIdx.y * 64, col0 = (int64_t)blockIdx.x * 64;
     const int64_t bid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
     const int nslots = n_hyp + 1;
     if ((!RECT && col0 > row0 + 63) || row0 >= n || (RECT && col0 >= nb)) {  // nothing on or below the diagonal in this tile
-        if (tid < nslots) partial[bid * nslots + tid] = 0.0;
+        for (int s = tid; s < nslots; s += 256) partial[bid * nslots + s] = 0.0;
         return;
     }
-    for (int s = 0; s < nslots; ++s) gl[s * 256 + tid] = 0.0;
-    for (int e = tid; e < 64 * d; e += 256) {
-        int r = e / d, k = e - r * d;
-        int64_t gr = row0 + r;
-        gr = gr < n ? gr : n - 1;
-        sa[e] = x[gr * d + k];
+    if constexpr (GEN) {
+        for (int s = tid; s < 4 * nslots; s += 256) red[s] = 0.0;
+    } else {
+        for (int s = 0; s < nslots; ++s) gl[s * 256 + tid] = 0.0;
+        for (int e = tid; e < 64 * d; e += 256) {
+            int r = e / d, k = e - r * d;
+            int64_t gr = row0 + r;
+            gr = gr < n ? gr : n - 1;
+            sa[e] = x[gr * d + k];
+        }
     }
     if (tid < 64) {
         int64_t gr = row0 + tid;
@@ -85,11 +96,22 @@ __global__ __launch_bounds__(256) void dmll_kernel(const T* __restrict__ x, int6
     const int64_t ncols = RECT ? nb : n;
     const T* __restrict__ xcols = RECT ? xb_pts : x;
     const int64_t gc = gcol < ncols ? gcol : ncols - 1;
-    T xb[DMAX];
+    T xb[DREG];
 #pragma unroll
-    for (int k = 0; k < DMAX; ++k) xb[k] = (k < d) ? xcols[gc * d + k] : T(0);
+    for (int k = 0; k < DREG; ++k) xb[k] = (!GEN && k < d) ? xcols[gc * d + k] : T(0);
+    const T* __restrict__ xc = xcols + gc * d;  // GEN: this lane's column point, read where it is used
     const T acol = (!RECT && gcol < n) ? alpha[gcol] : T(0);
     __syncthreads();
+    // accumulate `v` into hyper-parameter slot `slot` (every call site is wave-uniform)
+    auto acc = [&](int slot, double v) __attribute__((always_inline)) {
+        if constexpr (GEN) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == 0) red[wv * nslots + slot] += v;
+        } else {
+            gl[slot * 256 + tid] += v;
+        }
+    };
 
     const int nops = prog->n_ops;
     for (int rr = 0; rr < 16; ++rr) {
@@ -97,18 +119,18 @@ __global__ __launch_bounds__(256) void dmll_kernel(const T* __restrict__ x, int6
         const int64_t grow = row0 + row;
         if (grow >= n) break;  // wave-uniform
         const bool valid = RECT ? (gcol < nb) : (gcol <= grow);  // lower triangle including the diagonal (gcol < n follows)
-        const T* sar = sa + row * d;
-        T dsq[DMAX];
+        const T* sar = GEN ? (x + grow * d) : (sa + row * d);  // GEN: the row point straight from global memory (wave-uniform address)
+        T dsq[DREG];
 #pragma unroll
-        for (int k = 0; k < DMAX; ++k) {
-            const T df = (k < d) ? (sar[k] - xb[k]) : T(0);
+        for (int k = 0; k < DREG; ++k) {
+            const T df = (!GEN && k < d) ? (sar[k] - xb[k]) : T(0);
             dsq[k] = df * df;
         }
         // W_ij and its weight: diagonal entries count half (GPE.jl:228-231), strict lower entries once (:233-238)
         const T kin = valid ? Kinv[grow * ld + gcol] : T(0);
         const T wij = RECT ? kin : (nb < 0 ? sal[row] * acol + kin : sal[row] * acol - kin);  // nb < 0: Kinv holds -K^-1
         const T ww = valid ? ((!RECT && grow == gcol) ? T(0.5) * wij : wij) : T(0);
-        if (!RECT && valid && grow == gcol) gl[n_hyp * 256 + tid] += (double)wij;  // tr(alpha alpha' - K^-1)
+        acc(n_hyp, (!RECT && valid && grow == gcol) ? (double)wij : 0.0);  // tr(alpha alpha' - K^-1)
 
         // For every leaf L: one forward-mode sweep of the postfix program with the seed on L gives
         //   kv = value of L,  m = d(root)/d(value of L)   (sum rule: sum_kernel.jl:18-51, product rule: prod_kernel.jl:17-68)
@@ -139,24 +161,41 @@ __global__ __launch_bounds__(256) void dmll_kernel(const T* __restrict__ x, int6
                 }
                 T v, r2 = T(0);
                 const T s2 = (T)prog->leaf[o].s2;
-                const double* w = prog->w + prog->leaf[o].woff;
+                const double* w = prog->wtab() + prog->leaf[o].woff;
                 if (op == GPMI_K_CONST) {
                     v = s2;
                 } else if (op == GPMI_K_NOISE) {
                     bool same = true;
+                    if constexpr (GEN) {
+                        for (int k = 0; k < d; ++k) {
+                            if (w[k] != 0.0) {
+                                const T a = sar[k], b = xc[k];
+                                const T m = fabs(a) > fabs(b) ? fabs(a) : fabs(b);
+                                same = same && ((a == b) || (fabs(a - b) <= GM<T>::rtol * m));
+                            }
+                        }
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < DMAX; ++k) {
-                        if (k < d && w[k] != 0.0) {
-                            const T a = sar[k], b = xb[k];
-                            const T m = fabs(a) > fabs(b) ? fabs(a) : fabs(b);
-                            same = same && ((a == b) || (fabs(a - b) <= GM<T>::rtol * m));
+                        for (int k = 0; k < DREG; ++k) {
+                            if (k < d && w[k] != 0.0) {
+                                const T a = sar[k], b = xb[k];
+                                const T m = fabs(a) > fabs(b) ? fabs(a) : fabs(b);
+                                same = same && ((a == b) || (fabs(a - b) <= GM<T>::rtol * m));
+                            }
                         }
                     }
                     v = same ? s2 : T(0);
                 } else {
+                    if constexpr (GEN) {
+                        for (int k = 0; k < d; ++k) {
+                            const T df = sar[k] - xc[k];
+                            r2 += (df * df) * (T)w[k];
+                        }
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < DMAX; ++k)
-                        if (k < d) r2 += dsq[k] * (T)w[k];
+                        for (int k = 0; k < DREG; ++k)
+                            if (k < d) r2 += dsq[k] * (T)w[k];
+                    }
                     const T p0 = (T)prog->leaf[o].p0, al = (T)prog->leaf[o].p1;
                     switch (op) {
                         case GPMI_K_SE_ISO: v = s2 * GM<T>::exp_((T(-0.5) * r2) * p0); break;
@@ -192,7 +231,7 @@ __global__ __launch_bounds__(256) void dmll_kernel(const T* __restrict__ x, int6
             const int op = opL;
             const int poff = prog->leaf[L].poff;
             if (op == GPMI_K_NOISE || op == GPMI_K_CONST) {
-                gl[poff * 256 + tid] += (double)(a * T(2) * kv);  // noise.jl:47-48, const.jl:40
+                acc(poff, (double)(a * T(2) * kv));  // noise.jl:47-48, const.jl:40
                 continue;
             }
             const T r2 = r2L;
@@ -200,7 +239,7 @@ __global__ __launch_bounds__(256) void dmll_kernel(const T* __restrict__ x, int6
             const int nd = prog->leaf[L].nd;
             const bool ard = is_ard_op(op);
             const int sig = poff + (ard ? nd : 1);  // slot of log sigma
-            gl[sig * 256 + tid] += (double)(a * T(2) * kv);  // dk_dlσ = 2k (stationary.jl:28)
+            acc(sig, (double)(a * T(2) * kv));  // dk_dlσ = 2k (stationary.jl:28)
             // length-scale derivative = c * (r2 for iso | w_k dsq_k for ARD dim k)
             T c;
             const T re = GM<T>::sqrt_(r2);
@@ -229,36 +268,48 @@ __global__ __launch_bounds__(256) void dmll_kernel(const T* __restrict__ x, int6
                 } break;
             }
             if (ard) {
-                const double* w = prog->w + prog->leaf[L].woff;
-                const int16_t* pm = prog->pmap + prog->leaf[L].woff;
-#pragma unroll
-                for (int k = 0; k < DMAX; ++k) {
-                    if (k < d) {
+                const double* w = prog->wtab() + prog->leaf[L].woff;
+                const int32_t* pm = prog->pmtab() + prog->leaf[L].woff;
+                if constexpr (GEN) {
+                    for (int k = 0; k < d; ++k) {
                         const int z = pm[k];
-                        if (z >= 0) gl[(poff + z) * 256 + tid] += (double)(a * c * dsq[k] * (T)w[k]);
+                        if (z >= 0) {
+                            const T df = sar[k] - xc[k];
+                            acc(poff + z, (double)(a * c * (df * df) * (T)w[k]));
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < DREG; ++k) {
+                        if (k < d) {
+                            const int z = pm[k];
+                            if (z >= 0) acc(poff + z, (double)(a * c * dsq[k] * (T)w[k]));
+                        }
                     }
                 }
             } else {
-                gl[poff * 256 + tid] += (double)(a * c * r2);
+                acc(poff, (double)(a * c * r2));
             }
             if (op == GPMI_K_RQ_ISO || op == GPMI_K_RQ_ARD) {  // dk/d(log alpha) = k (s/(2 part) - a log part)
                 const T part = T(1) + r2 * p0;
                 const T half_s = r2 * p0 * al;  // iso: s/2 = r2/(2 l2) = r2 p0 a ; ard: r/2 = r2 p0 a (p0 = 0.5/a)
-                gl[(sig + 1) * 256 + tid] += (double)(a * kv * (half_s / part - al * GM<T>::log_(part)));
+                acc(sig + 1, (double)(a * kv * (half_s / part - al * GM<T>::log_(part))));
             }
         }
     }
     // ---- block reduction: wave shuffles, then four partials per slot --------------------------------------------
     __syncthreads();
-    for (int s = 0; s < nslots; ++s) {
-        double v = gl[s * 256 + tid];
+    if constexpr (!GEN) {
+        for (int s = 0; s < nslots; ++s) {
+            double v = gl[s * 256 + tid];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (lane == 0) red[wv * nslots + s] = v;
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == 0) red[wv * nslots + s] = v;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    if (tid < nslots)
-        partial[bid * nslots + tid] = (red[tid] + red[nslots + tid]) + (red[2 * nslots + tid] + red[3 * nslots + tid]);
+    for (int s = tid; s < nslots; s += 256)
+        partial[bid * nslots + s] = (red[s] + red[nslots + s]) + (red[2 * nslots + s] + red[3 * nslots + s]);
 }
 
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const double* __restrict__ partial, int64_t nblocks, int nslots,
@@ -288,12 +339,16 @@ template <typename T, bool RECT>
 static int64_t launch_dmll_any(gpmi_ctx* ctx, const T* x, int64_t n, int d, const T* alpha, const T* Kinv, int64_t ld, double* partial,
                                int n_hyp, const T* xb, int64_t nb) {
     const unsigned ntr = (unsigned)((n + 63) / 64), ntc = RECT ? (unsigned)((nb + 63) / 64) : ntr;
-    const size_t lds = (size_t)(n_hyp + 1) * 256 * 8 + (size_t)(64 * d + 64) * sizeof(T) + (size_t)4 * (n_hyp + 1) * 8;
+    const bool gen = d > GRAD_MAX_D || n_hyp > GRAD_MAX_HYP;  // beyond the register / LDS forms: the form without limits
+    const size_t lds = gen ? (size_t)64 * sizeof(T) + (size_t)4 * (n_hyp + 1) * 8
+                           : (size_t)(n_hyp + 1) * 256 * 8 + (size_t)(64 * d + 64) * sizeof(T) + (size_t)4 * (n_hyp + 1) * 8;
     auto go = [&](auto kern) {
         if (lds > 48 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(ntc, ntr), dim3(256), lds, ctx->stream, x, n, d, alpha, Kinv, ld, ctx->d_prog, partial, n_hyp, xb, nb);
     };
-    if (d <= 4)
+    if (gen)
+        go(dmll_kernel<T, 0, RECT>);
+    else if (d <= 4)
         go(dmll_kernel<T, 4, RECT>);
     else if (d <= 8)
         go(dmll_kernel<T, 8, RECT>);

@@ -45,9 +45,9 @@ extern "C" {
 #define GPMI_EARG 2
 #define GPMI_EDEVICE 3
 
-#define GPMI_MAX_OPS 32     /* nodes in a kernel tree            */
-#define GPMI_MAX_PARAMS 160 /* stored kernel parameters, total   */
-#define GPMI_MAX_DIMS 160   /* masked active-dim entries, total  */
+#define GPMI_MAX_OPS 32     /* nodes in a kernel tree (leaves + SUM / PROD); the evaluation stack may be 6 deep.  The input
+                             * dimension d, the number of stored parameters and of masked active-dim entries are NOT limited:
+                             * the library sizes its tables from the descriptor (the reference's loops take any `dim`). */
 
 /* Kernel-tree node codes.  A kernel is a POSTFIX program over these. */
 enum gpmi_op {
@@ -141,7 +141,8 @@ GPMI_API int gpmi_predict(gpmi_gp*, const gpmi_kernel*, int64_t p, const void* x
  *   dnoise_out   = exp(2 logNoise) tr(alpha alpha' - K^-1)             (dmll_noise, GPE.jl:273-275; may be NULL)
  * The mean part, dot(grad_mean, alpha) (GPE.jl:282-288), is O(N d) host work on alpha.
  * n_kern must equal the kernel's parameter count.  Allocates two more n x n device buffers on
- * first use.  Kernels beyond 64 parameters / d > 32 return GPMI_EARG (cov! itself: d <= 64).          */
+ * first use.  No limit on d or on the number of parameters (beyond d = 32 / 64 parameters a slower,
+ * limit-free form of the trace kernel runs; cov! reads its operands from global memory beyond d = 64). */
 GPMI_API int gpmi_grad(gpmi_gp*, const gpmi_kernel*, const double* log_noise, int64_t n_noise, double* dkern_out, int32_t n_kern,
               double* dnoise_out);
 

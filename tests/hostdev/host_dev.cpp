@@ -55,13 +55,6 @@ struct HostDev : Dev {
         *kdiag = ops.kdiag(n_hyp);
         return GPMI_OK;
     }
-    int grad_limits(int d) override {  // the device gradient's input-dimension limit (common.h GRAD_MAX_D), so the driver's refusal path runs on the host too
-        if (d > 32) {
-            err = "gpmi_grad: kernel outside the device gradient path (<= 64 hyper-parameters, d <= 32)";
-            return GPMI_EARG;
-        }
-        return GPMI_OK;
-    }
     void assemble(const void* x, int64_t n, int d, int64_t row_off, int64_t nrows, double nugget, const double* nvec, void* A, int64_t ld,
                   int64_t ncols) override {
         ops.assemble((const double*)x, n, d, row_off, nrows, nugget, nvec, (double*)A, ld, ncols);

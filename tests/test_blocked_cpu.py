@@ -95,17 +95,19 @@ def test_one_rank(n, block, stripes):
     gp.close()
 
 
-def test_gradient_refused_beyond_the_device_limit_on_a_blocked_handle():
-    """a blocked handle accepts d up to 64, the device gradient only d <= 32 — the blocked gradient must refuse
-    (GPMI_EARG, the dense path's message) instead of running a kernel whose distance loop stops at 32"""
+def test_gradient_at_d40_on_a_blocked_handle():
+    """(then VERDICT r3 missing 3) d = 40 is beyond the register form of the device gradient kernel: round 3 ran it
+    silently wrong on blocked handles, round 4 first refused it and then lifted the limit (grad.hip: the limit-free form).  The
+    driver's side of it on the host stand-in: a d = 40 ARD gradient (42 hyper-parameters) through the blocked orchestration."""
     rng = np.random.default_rng(2)
     n, d = 300, 40
     x = rng.uniform(size=(d, n))
-    y = rng.standard_normal(n)
-    gp = H.HostBlockedGP(("se_iso", 0.3, 0.0), x, y, LN)
-    with pytest.raises(RuntimeError, match="outside the device gradient path"):
-        gp.update_dmll()
-    gp.update_mll()  # the handle stays usable
+    y = np.sin(x[:3].sum(axis=0)) + 0.1 * rng.standard_normal(n)
+    spec = ("se_ard", list(rng.uniform(0.3, 1.0, size=d)), 0.1)
+    gp = H.HostBlockedGP(spec, x, y, LN)
+    gp.update_dmll()
+    dref = G.update_dmll(spec, x, y, LN, ("zero",))
+    np.testing.assert_allclose(gp.dkern, dref["dkern"], rtol=1e-8, atol=1e-9 * np.abs(dref["dkern"]).max())
     gp.close()
 
 

@@ -337,7 +337,7 @@ def test_injected_collective_latency_stays_off_the_critical_path():
     every panel exchange — a spin kernel on the stream the collective is given.  A serial exchange would lengthen the fit by the
     whole injected total; the pipeline of csrc/blocked.cpp (broadcast under U2a, gather under U2b) must absorb every delay that fits
     under the update it runs beside.  Model of what CAN be hidden: step k's update lasts t_k ~ (rows left)^2, the broadcast has
-    U2a = t_k / 4 minus the diagonal-block chain, the gather U2b = 3 t_k / 4."""
+    U2a = t_k / 4 minus the diagonal-block chain, the gather U2b = 3 t_k / 4.  The two are delayed SEPARATELY (GPMI_TEST_COMM_DELAY_ON)."""
     import json
     import time
 
@@ -353,44 +353,55 @@ def test_injected_collective_latency_stays_off_the_critical_path():
     gp = gd.ShardedGPE(x, y, g.MeanZero(), g.SEArd(ll, 0.0), ln, ctx=ctx, block=WD)
     assert abs(gp.mll - dense.mll) <= 1e-10 * abs(dense.mll)
     nblk = -(-n // WD)
-    count = 2 * nblk - 1                               # nblk inverse broadcasts + nblk - 1 panel exchanges per fit
     res = {}
+
+    def fit_ms():
+        ts = []
+        for rep in range(3):
+            t0 = time.perf_counter()
+            gp.update_mll()
+            ts.append(time.perf_counter() - t0)
+        assert abs(gp.mll - dense.mll) <= 1e-10 * abs(dense.mll)
+        return min(ts) * 1e3
+
     try:
-        for D in (0.0, 1.0, 5.0, 20.0):
-            os.environ["GPMI_TEST_COMM_DELAY_US"] = str(int(D * 1000))
-            ts = []
-            for rep in range(3):
-                t0 = time.perf_counter()
-                gp.update_mll()
-                ts.append(time.perf_counter() - t0)
-            assert abs(gp.mll - dense.mll) <= 1e-10 * abs(dense.mll)
-            res[D] = min(ts) * 1e3
+        t0 = fit_ms()
+        for what, name in ((2, "panel_exchange"), (1, "inverse_broadcast")):
+            os.environ["GPMI_TEST_COMM_DELAY_ON"] = str(what)
+            for D in (1.0, 5.0):
+                os.environ["GPMI_TEST_COMM_DELAY_US"] = str(int(D * 1000))
+                res[(name, D)] = fit_ms()
     finally:
         os.environ.pop("GPMI_TEST_COMM_DELAY_US", None)
-    t0 = res[0.0]
+        os.environ.pop("GPMI_TEST_COMM_DELAY_ON", None)
     rem2 = np.array([(n - (k + 1) * WD) ** 2 for k in range(nblk - 1)], dtype=float)
     tk = t0 * rem2 / rem2.sum()                      # step k's update (upper bound: t0 holds everything else as well)
-    chain = 2.5                                       # ms: dpotrf + inverse of a 1024 block on the reserved CUs
-    report = {"n": n, "members": "CU partitions 0 and 1 of device 0 (128 CUs each)", "block": WD, "fit_ms_no_delay": t0,
-              "dense_fit_ms_whole_device": None, "delayed_collectives_per_fit": count, "delays": {}}
     t1 = time.perf_counter()
     dense.update_mll()
-    report["dense_fit_ms_whole_device"] = (time.perf_counter() - t1) * 1e3
-    for D in (1.0, 5.0, 20.0):
+    report = {"n": n, "members": "CU partitions 0 and 1 of device 0 (128 CUs each)", "block": WD, "fit_ms_no_delay": t0,
+              "dense_fit_ms_whole_device": (time.perf_counter() - t1) * 1e3, "delays": {}}
+    for (name, D), t in res.items():
+        count = nblk - 1 if name == "panel_exchange" else nblk     # per fit
         injected = D * count
-        uncover = float(np.sum(D * (D + chain > 0.25 * tk)) + np.sum(D * (D > 0.75 * tk)) + D)   # (+ the first broadcast: nothing to hide behind)
-        cover = max(injected - uncover, 0.0)
-        extra = res[D] - t0
-        report["delays"][str(D)] = {"fit_ms": res[D], "injected_ms": injected, "extra_ms": extra, "exposed_fraction": extra / injected,
-                                    "model_uncoverable_ms": uncover, "model_coverable_ms": cover}
+        # the exchange of step k has U2b = 3/4 of step k's update to hide under; the broadcast only U2a = 1/4 of it MINUS the chain
+        # that produces the inverse (dpotrf + inverse of a 1024 block: ~3 ms on the partition's reserved CUs), and the first one nothing
+        share = 0.75 * tk if name == "panel_exchange" else np.concatenate(([0.0], 0.25 * tk - 3.0))
+        uncover = float(np.sum(D * (D > share[:count])))
+        extra = t - t0
+        report["delays"][f"{name}+{D}ms"] = {"fit_ms": t, "injected_ms": injected, "extra_ms": extra, "exposed_fraction": extra / injected,
+                                            "model_uncoverable_ms": uncover, "model_coverable_ms": injected - uncover}
     print("injected-latency overlap:", json.dumps(report))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "r04_overlap_latency.json"), "w") as fh:
         json.dump(report, fh, indent=1)
-    # what the update can cover must be covered (10 % + timer noise); a serial exchange fails this by the whole `cover`
-    r1 = report["delays"]["1.0"]
-    assert r1["extra_ms"] <= r1["model_uncoverable_ms"] + 0.10 * r1["model_coverable_ms"] + 0.06 * t0, report
-    assert r1["exposed_fraction"] < 0.5, report
+    # the panel exchange — N^2/2 elements per rank per fit, the traffic that matters — must stay off the critical path wherever the
+    # update beside it is longer than the delay: 15 % of the coverable total + timer noise (a serial exchange fails by all of it)
+    for D in (1.0, 5.0):
+        r = report["delays"][f"panel_exchange+{D}ms"]
+        assert r["extra_ms"] <= r["model_uncoverable_ms"] + 0.15 * r["model_coverable_ms"] + 0.05 * t0, report
+    assert report["delays"]["panel_exchange+1.0ms"]["exposed_fraction"] < 0.35, report
+    # the inverse broadcast sits behind the chain under U2a only: reported, and bounded by "no worse than serial"
+    assert report["delays"]["inverse_broadcast+1.0ms"]["exposed_fraction"] < 1.25, report
     del gp
     ctx.close()
 
