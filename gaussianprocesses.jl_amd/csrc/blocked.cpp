@@ -245,11 +245,19 @@ void BlockedGP::update_cols(int64_t k, int64_t c_lo, int64_t c_hi, int64_t min_b
         const int64_t ncols = std::min<int64_t>(c_hi * WD_, pc.width) - c_lo * WD_;
         if (M <= 0 || ncols <= 0) continue;
         DevShape sh;
-        sh.mode = 2;
-        sh.g0 = pc.nb ? (int)(own_[pc.b0] - c_lo) : 0;
-        sh.G = G_;
-        sh.nstair = tpb_ * pc.nb;
-        sh.tpb = tpb_;
+        if (G_ == 1) {
+            // one rank: the shard IS the matrix — the plain lower region in tiles (column tile <= row tile + g0), which is the shape
+            // the 256 x 128 update kernel takes (update256.hip); the staircase below would also keep the upper tiles of every
+            // diagonal block
+            sh.mode = 1;
+            sh.g0 = pc.nb ? (int)(own_[pc.b0] - c_lo) * tpb_ : (int)(nblk_ - c_lo) * tpb_;
+        } else {
+            sh.mode = 2;
+            sh.g0 = pc.nb ? (int)(own_[pc.b0] - c_lo) : 0;
+            sh.G = G_;
+            sh.nstair = tpb_ * pc.nb;
+            sh.tpb = tpb_;
+        }
         dev_->gemm(pc.p + c_lo * WD_ * es_, pc.ld, pc.p + k * WD_ * es_, pc.ld, panel_rows(k, c_lo), ldP_, M, ncols, WD_, sh, 0);
     }
 }

@@ -170,7 +170,7 @@ inline void factor_panel_below(gpmi_ctx* c, T* A, int64_t ld, const T* linv, int
 //      stored inverses) — chip-wide launches;
 //   3. the trailing matrix gets ONE update with K = W.
 // Every trailing element is read and written once per W columns instead of once per 256: the update kernel's C traffic per
-// flop (25 % of its time at K = 256) drops by W / 256, and the bulk of the n^3 / 3 flops runs at the K = 1024
+// flop (25 % of its time at K = 256, LABBOOK.md 3.2) drops by W / 256, and the bulk of the n^3 / 3 flops runs at the K = 1024
 // rate of gemm_nt_kernel (63 instead of 47 TFLOP/s isolated).  The skinny products of step 2 are (W / M) of the flops.
 //
 // LOOK-AHEAD at the super-panel level: step 1 of the NEXT super-panel — every latency-bound launch of the factorisation —

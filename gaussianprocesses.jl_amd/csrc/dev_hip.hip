@@ -168,6 +168,7 @@ struct HipDev : Dev {
     }
     void use(DevStream s) override {
         c->beside_update = false;
+        c->side_one_per_xcd = false;
         c->gemm_reserve = 0;
         c->num_cus = full_cus();
         switch (s) {
@@ -184,6 +185,10 @@ struct HipDev : Dev {
             case DS_SIDE:
                 c->stream = masked() ? c->side_masked : (c->side_stream ? c->side_stream : main_s);
                 c->beside_update = c->stream != main_s;
+                // free slots beside an update that will run in 256 x 128 tiles (one workgroup per CU: the free slots are whole CUs, one
+                // per XCD): no chain launch of more than one workgroup per XCD (chol.h / common.h side_slots).  The driver only stays in
+                // this mode while the update is long enough for that kernel (blocked.cpp kWholeCusBelow).
+                c->side_one_per_xcd = !masked() && c->update256 != 0 && c->beside_update;
                 break;
             // the exchange: the main stream is idle while a factorisation runs on UPD / SIDE, so with whole CUs reserved the
             // collectives go there (their kernels find the reserved CUs free); with free slots they follow the chain

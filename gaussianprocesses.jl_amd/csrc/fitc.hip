@@ -17,7 +17,7 @@
 //   mll = -(r'alpha + logdet B + sum log Lambda + n log 2 pi) / 2     (logdet SigmaQR - logdet Kuu = logdet B, :80)
 // This is the reference's mathematics (both make_posdef! nuggets included) in the numerically stable order: SigmaQR
 // itself has a condition number ~ n / (sigma^2 1e-10) and its small pivots are rounding noise in ANY fp64 Cholesky
-// (LAPACK's included — tools/illcond_check.py), while B is conditioned like 1 + n k / sigma^2.
+// (LAPACK's included — tools/illcond_check.py, LABBOOK.md 3.6), while B is conditioned like 1 + n k / sigma^2.
 // Kuu is regularised only by the nugget, so every product with a stored block inverse of Luu carries one step of
 // iterative refinement (rows64, panel.hip).  Memory: two n x m matrices (W and U'), 32.8 GB each at n = 1e6, m = 4096.
 #include <math.h>

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __rest
     // the 16x16x4 instruction they advance at the same rate and PHASE-LOCK (both load C, then both compute: the one that
     // is behind has the MFMA pipe to itself while the leader loads, and catches up).  Start delays, s_setprio for one of
     // the pair, C fetched inside the K loop and a per-CU load token were all measured neutral
-    // (profiles/r01_gemm_c_traffic_experiments.log), so none of them is done.
+    // (profiles/r01_gemm_c_traffic_experiments.log, LABBOOK.md 3.2), so none of them is done.
     if constexpr (VARIANT & 32) {  // experiment: spread the CUs' tile phases over one tile period (C traffic bursts)
         const unsigned half = gridDim.x >> 1;
         const unsigned c = blockIdx.x % half;  // CU pair index

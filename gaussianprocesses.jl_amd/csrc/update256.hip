@@ -2,7 +2,7 @@
 // make_posdef!, src/GP.jl:110) in 256 x 128 output tiles: the round-3 form of the roofline kernel.
 //
 // What round 2's 128 x 128 kernel (gemm.hip, two 256-thread workgroups per CU) still lost at K = 1024 / 2048 was not C traffic any
-// more but the K loop itself: its ablation puts the operand DMA at 8 % and the LDS fragment reads at 6 % of the kernel, because
+// more but the K loop itself: its ablation puts the operand DMA at 8 % and the LDS fragment reads at 6 % of the kernel (LABBOOK 3.2), because
 // with TWO slab buffers a workgroup can read the fragments of slab k + 1 only after the barrier that publishes it — every slab
 // starts with an LDS round trip during which that workgroup's waves issue no MFMA, and co-resident workgroups phase-lock.
 // This kernel removes the round trip instead of hiding it behind a second workgroup:
@@ -24,7 +24,7 @@
 //   * the C tile is read in the EPILOGUE, into the then-free fragment registers (four batches of four fragments, two in flight),
 //     while the next tile's first two slabs are already on their way (its index comes from the queue pull issued under the last
 //     slab), and the tile's 32 stores per lane drain under the next tile's first slab.  (C inside the K loop — one fragment per
-//     slab during the first 16 — was built first; hipcc's register allocation does not survive it: DESIGN.md 3.2b.)
+//     slab during the first 16 — was built first; hipcc's register allocation does not survive it: LABBOOK.md 3.2b.)
 // Tile order: tile_order.h mode 3 (the lower region in tiles twice as tall as wide), per-XCD persistent queues as in gemm.hip.
 // Used for the dense path's big updates only (launch_update256 says when); everything else stays on gemm_nt_kernel.
 #include <algorithm>

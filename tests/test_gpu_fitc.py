@@ -3,7 +3,7 @@ src/sparse/fully_indep_train_conditional.jl — SURVEY §8f rank 2.
 
 Which oracle: ΣQR = Kuf Λ⁻¹ Kfu + Kuu has a condition number ~ n / (σ² · 1e-10); for smooth kernels its small pivots are
 rounding noise in any fp64 Cholesky, so the fp64 (LAPACK) evaluation of the reference's statements is itself off by up to
-1.4e-4 relative in mll on the SE cases below (tools/fitc_probe.py).  mll / alpha / alpha_u are therefore
+1.4e-4 relative in mll on the SE cases below (tools/fitc_probe.py, LABBOOK.md §3.6).  mll / alpha / alpha_u are therefore
 checked against the SAME statements evaluated in 80-bit arithmetic (oracle.fitc_update_mll_extended), where the device path
 (which factors the well-conditioned whitened matrix B instead of ΣQR) agrees to ~1e-8; predictions are checked against the
 fp64 oracle at the north-star's rtol 1e-5."""
@@ -146,7 +146,7 @@ def test_fitc_gradient_matches_the_oracle(name, spec, d, m):
 
 def test_fitc_gradient_when_kuu_is_ill_conditioned():
     """40 inducing points under a smooth kernel: cond(Kuu) = 7e9, and the reference's statements evaluated literally in
-    fp64 (LAPACK) are off by 5e-3 — like its mll.  The device path works in the coordinates whitened by
+    fp64 (LAPACK) are off by 5e-3 — like its mll (LABBOOK.md 3.6).  The device path works in the coordinates whitened by
     Luu and is checked against central differences of the 80-bit evaluation of the mll."""
     spec0 = [math.log(0.3), math.log(0.45), 0.1]
     x, xu, y, _ = _case(1500, 2, 40, 41)
