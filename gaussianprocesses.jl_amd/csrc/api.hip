@@ -751,6 +751,7 @@ static int create_one_context(int dev_code, gpmi_ctx** out) {
     }
     if (const char* e = getenv("GPMI_UPDATE256")) c->update256 = atoi(e) != 0;
     if (const char* e = getenv("GPMI_UPDATE256_MIN")) c->update256_min_tiles = std::max<long long>(1, atoll(e));
+    if (const char* e = getenv("GPMI_UPDATE256_RECT")) c->update256_rect_min_m = std::max<long long>(1, atoll(e));  // test hook: rows from which tall products take the 256 x 128 kernel
     if (const char* e = getenv("GPMI_GRAD_CHUNK")) c->grad_chunk = std::max<long long>(0, atoll(e) / NB * NB);
     if (const char* e = getenv("GPMI_SUPER_INV")) c->super_inverse = atoi(e) != 0;
     if (const char* e = getenv("GPMI_WHITEN_INV")) c->whiten_by_super_inverse = atoi(e) != 0;

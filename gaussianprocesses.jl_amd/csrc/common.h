@@ -151,6 +151,7 @@ struct gpmi_ctx {
                                          // GPMI_UPDATE256=0: round 2's 128 x 128 kernel everywhere)
     bool side_one_per_xcd = false;       // set around a look-ahead chain whose update will run as update256_kernel (chol.h, side_slots)
     int update256_ablation = 0;         // tools builds: ABL bits of update256_kernel for gpmi_bench_gemm (variant 256 + bits)
+    int64_t update256_rect_min_m = 8192; // rectangular / batched products go to the 256 x 128 kernel from this many rows on (GPMI_UPDATE256_RECT: test hook)
     int64_t update256_min_tiles = 1024;  // ... from this many 256 x 128 tiles on (GPMI_UPDATE256_MIN: test hook)
     hipStream_t own_stream = nullptr;    // the stream created with the context
     bool beside_update = false;          // launches made now run in the reserved slots beside the persistent update: no whole-CU kernels
@@ -302,7 +303,7 @@ void launch_gemm_shape(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda
 // the trailing update in 256 x 128 tiles (update256.hip): true when it took the launch
 template <typename T>
 bool launch_update256(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
-                      TileShape shape, const int* info);
+                      TileShape shape, const int* info, int flags, const GemmBatch* batch);
 // ... and whether it WOULD take it (no launch): the look-ahead sizes the chain's launches by it (chol.h)
 template <typename T>
 bool update256_applies(const gpmi_ctx* ctx, const T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M, int64_t N, int64_t K,

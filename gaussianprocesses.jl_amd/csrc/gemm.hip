@@ -547,6 +547,10 @@ void launch_gemm_shape(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda
     // launches run as narrow tiles and are accounted with the panel), <T, 64, *> every other product.
     const bool narrow = use_narrow_tiles(ctx, M, N, shape, batch);
     const bool trailing = shape.mode && !flags && !narrow;
+    // FITC's tall products (n x m matrices, n ~ 1e6) in 256 x 128 tiles as well: rectangular or overwriting or split-K batched
+    // (update256.hip decides: plain or GEMM_OVERWRITE launches only, M >= update256_rect_min_m for rectangles)
+    const bool tall = !trailing && !narrow && !(flags & ~(GEMM_OVERWRITE | GEMM_AUX)) && (shape.mode == 0 || shape.mode == 1) &&
+                      (batch || M >= ctx->update256_rect_min_m);
     // the trailing update with a long K: phase-lock the tiles of an XCD (operand panels of 128 x K exceed the 4 MB L2 16 at a time)
     if (trailing && K >= ctx->phase_lock_min_k && ctx->phase_lock_min_k > 0) flags |= GEMM_PHASE_LOCK;
     // algorithmic bytes: every output entry read and written once, the operand panels once (B inside A for the SYRK shape)
@@ -557,8 +561,10 @@ void launch_gemm_shape(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda
     ProfScope ps(ctx, trailing ? GPMI_PROF_SYRK : GPMI_PROF_PANEL, 2.0 * entries * (double)K, abytes, /*attach_to_launch=*/true);
     if (trailing) {
         // the big updates of the dense path go in 256 x 128 tiles (update256.hip); everything else in 128 x 128 / 128 x 64
-        if (!batch && !flags && launch_update256<T>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info)) return;
+        if (!batch && !flags && launch_update256<T>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, 0, nullptr)) return;
         launch_persistent<T, 0>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags, batch, false);
+    } else if (tall && launch_update256<T>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags & GEMM_OVERWRITE, batch)) {
+        return;
     } else
         launch_persistent<T, 64>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags, batch, narrow);
 }
@@ -630,7 +636,7 @@ int gemm_bench(gpmi_ctx* ctx, int64_t M, int64_t N, int64_t K, int lower, int va
             case 0: launch_variant<T, 0>(ctx, C, ld, A, M, N, K, lower); break;
             case 256: case 257: case 259: case 261: case 263: case 271:  // the 256 x 128 form of the trailing update (update256.hip; + ablation bits in tools builds)
                 ctx->update256_ablation = variant - 256;
-                if (!lower || !launch_update256<T>(ctx, C, ld, A, ld, A, ld, M, N, K, TileShape{0, 0, 1, 0, 1, 0}, nullptr))
+                if (!lower || !launch_update256<T>(ctx, C, ld, A, ld, A, ld, M, N, K, TileShape{0, 0, 1, 0, 1, 0}, nullptr, 0, nullptr))
                     launch_variant<T, 0>(ctx, C, ld, A, M, N, K, lower);
                 break;
 #ifdef GPMI_TOOLS  // ablations of tools/gemm_ablate.py / gemm_phases.py: not instantiated in the product library

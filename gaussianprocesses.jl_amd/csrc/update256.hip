@@ -74,7 +74,10 @@ __device__ __forceinline__ void slab_wait(Vec (&a)[4], Vec (&b)[4]) {  // own DM
 
 // ABL (tools builds only, gpmi_bench_gemm variants 257 ...): 1 no epilogue (no C read, no store)  2 no operand DMA after the first two
 // slabs  4 no fragment reads after the first  8 no slab barrier (with 2 | 4: the bare MFMA stream of the loop)
-template <typename T, int ABL>
+// OVW: C = A B' (GEMM_OVERWRITE: the C tile is not read) instead of C -= A B'.  Batched launches (QueueArgs::tiles_per / stride*: split-K
+// with separate outputs) and rectangular regions (tile_order mode 0) take the same path: round 4 widened the kernel from the Cholesky
+// trailing update to FITC's n m^2 products (W = Kfu Luu^-T over 10^6 rows, U' U'' in 16 K-chunks).
+template <typename T, int ABL, bool OVW>
 __global__ __launch_bounds__(512, 2) void update256_kernel(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int64_t lda,
                                                            const T* __restrict__ B, int64_t ldb, int64_t M, int64_t N, int64_t K,
                                                            TileShape shape, unsigned long long* __restrict__ queue, QueueArgs qa,
@@ -170,17 +173,19 @@ __global__ __launch_bounds__(512, 2) void update256_kernel(T* __restrict__ C, in
     // a tile's operand rows and extent (wave-uniform)
     struct Tile {
         const char *Ab, *Bb;
-        int64_t m0, n0;
-        int mrem, nrem;  // last valid local row / column
+        int64_t m0, n0, coff;  // coff: the batch's offset into C (elements)
+        int mrem, nrem;        // last valid local row / column
     };
     auto locate = [&](int64_t t) __attribute__((always_inline)) -> Tile {
         int ti, tj;
-        tile_decode(t, shape, &ti, &tj);
+        const int64_t bt = t / qa.tiles_per;  // batch index (0 for plain launches: tiles_per = the tile count)
+        tile_decode(t - bt * qa.tiles_per, shape, &ti, &tj);
         Tile w;
         w.m0 = (int64_t)ti * U_BM;
         w.n0 = (int64_t)tj * U_BN;
-        w.Ab = reinterpret_cast<const char*>(A + w.m0 * lda);
-        w.Bb = reinterpret_cast<const char*>(B + w.n0 * ldb);
+        w.coff = bt * qa.strideC;
+        w.Ab = reinterpret_cast<const char*>(A + bt * qa.strideA + w.m0 * lda);
+        w.Bb = reinterpret_cast<const char*>(B + bt * qa.strideB + w.n0 * ldb);
         w.mrem = (int)((M - w.m0 < U_BM ? M - w.m0 : U_BM) - 1);
         w.nrem = (int)((N - w.n0 < U_BN ? N - w.n0 : U_BN) - 1);
         return w;
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void update256_kernel(T* __restrict__ C, in
         // The NEXT tile's first two slabs start now (every wave left its last fragment read before the K loop's final barrier): their
         // latency runs under this tile's epilogue.
         const bool interior = mrem == U_BM - 1 && nrem == U_BN - 1;
-        T* __restrict__ const Cw = C + (cur_t.m0 + wm * 64) * ldc + cur_t.n0 + wn * 64;  // this wave's corner of the C tile (wave-uniform)
+        T* __restrict__ const Cw = C + cur_t.coff + (cur_t.m0 + wm * 64) * ldc + cur_t.n0 + wn * 64;  // this wave's corner of the C tile (wave-uniform)
         const int lrow = wm * 64, lcol = wn * 64;
         const bool more = t_next < cend;
         if (more) {
@@ -318,19 +323,26 @@ __global__ __launch_bounds__(512, 2) void update256_kernel(T* __restrict__ C, in
 #pragma unroll
                         for (int q = 0; q < 2; ++q) dst[ni][q] = *reinterpret_cast<const V2*>(pc + (int64_t)(mi * 16 + 8 * q) * ld2 + ni * 16);
                 };
-                fetch(0, cv[0]);
+                if constexpr (!OVW) fetch(0, cv[0]);
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) {
-                    if (mi + 1 < 4) fetch(mi + 1, cv[(mi + 1) & 1]);
+                    if constexpr (!OVW)
+                        if (mi + 1 < 4) fetch(mi + 1, cv[(mi + 1) & 1]);
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
                             const double a0 = acc[mi][ni].v[2 * q], a1 = acc[mi][ni].v[2 * q + 1];
                             const double recv = dpp_rot<0xB1>(odd2 ? a0 : a1);
-                            V2 v = cv[mi & 1][ni][q];
-                            v[0] += odd2 ? recv : a0;
-                            v[1] += odd2 ? a1 : recv;
+                            V2 v;
+                            if constexpr (OVW) {  // acc = -A B' (neg MFMA): the product itself is its negative
+                                v[0] = -(odd2 ? recv : a0);
+                                v[1] = -(odd2 ? a1 : recv);
+                            } else {
+                                v = cv[mi & 1][ni][q];
+                                v[0] += odd2 ? recv : a0;
+                                v[1] += odd2 ? a1 : recv;
+                            }
                             *reinterpret_cast<V2*>(pc + (int64_t)(mi * 16 + 8 * q) * ld2 + ni * 16) = v;
                         }
                 }
@@ -344,7 +356,7 @@ __global__ __launch_bounds__(512, 2) void update256_kernel(T* __restrict__ C, in
 #pragma unroll
                         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) cv[m2][ni][r] = pc[(int64_t)((2 * half + m2) * 16 + r * MF::RSTEP) * ld2 + ni * 16];
+                            for (int r = 0; r < 4; ++r) cv[m2][ni][r] = OVW ? T(0) : pc[(int64_t)((2 * half + m2) * 16 + r * MF::RSTEP) * ld2 + ni * 16];
 #pragma unroll
                     for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
@@ -353,7 +365,8 @@ __global__ __launch_bounds__(512, 2) void update256_kernel(T* __restrict__ C, in
                             for (int r = 0; r < 4; ++r) {
                                 const int mi = 2 * half + m2;
                                 const T v = acc[mi][ni].v[r];
-                                pc[(int64_t)(mi * 16 + r * MF::RSTEP) * ld2 + ni * 16] = MF::NEG ? cv[m2][ni][r] + v : cv[m2][ni][r] - v;
+                                pc[(int64_t)(mi * 16 + r * MF::RSTEP) * ld2 + ni * 16] =
+                                    OVW ? (MF::NEG ? -v : v) : (MF::NEG ? cv[m2][ni][r] + v : cv[m2][ni][r] - v);
                             }
                 }
             }
@@ -368,7 +381,7 @@ __global__ __launch_bounds__(512, 2) void update256_kernel(T* __restrict__ C, in
                         if (lrow + row <= mrem && lcol + col <= nrem) {
                             T* const pc = Cw + (int64_t)row * ld2 + col;
                             const T v = acc[mi][ni].v[r];
-                            *pc = MF::NEG ? *pc + v : *pc - v;
+                            *pc = OVW ? (MF::NEG ? -v : v) : (MF::NEG ? *pc + v : *pc - v);
                         }
                     }
         }
@@ -377,13 +390,13 @@ __global__ __launch_bounds__(512, 2) void update256_kernel(T* __restrict__ C, in
     }
 }
 
-template <typename T, int ABL>
+template <typename T, int ABL, bool OVW>
 bool prepare(gpmi_ctx* ctx) {
     // 144 KiB of dynamic LDS need the attribute once per device and instantiation
     static bool done[64] = {false};
     const int dev = ctx->device & 63;
     if (done[dev]) return true;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&update256_kernel<T, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&update256_kernel<T, ABL, OVW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             U_NBUF * (U_BM + U_BN) * 128) != hipSuccess) {
         (void)hipGetLastError();
         return false;
@@ -402,9 +415,17 @@ bool prepare(gpmi_ctx* ctx) {
 // 16 of them, a plain stream, operands aligned for 16-byte accesses, enough tiles to fill the chip for several rounds)
 template <typename T>
 static bool update256_plan(const gpmi_ctx* ctx, const T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M, int64_t N,
-                           int64_t K, TileShape shape, TileShape* out, int64_t* ntiles_out) {
+                           int64_t K, TileShape shape, TileShape* out, int64_t* ntiles_out, int flags = 0, const GemmBatch* batch = nullptr) {
     constexpr int BK = Mfma<T>::BK;
-    if (!ctx->update256 || shape.mode != 1 || (shape.g0 & 1) || ctx->beside_update) return false;
+    if (!ctx->update256 || (shape.mode != 1 && shape.mode != 0) || (shape.g0 & 1) || ctx->beside_update) return false;
+    if (flags & ~GEMM_OVERWRITE) return false;  // (K-loop bounds per tile, negated output: the 128 x 128 kernel's)
+    // rectangles: the tall products only (FITC's n x m matrices; predict_f's P x N updates stay on the 128 x 128 kernel, whose tile
+    // count fills the chip in more even rounds at M = 1024)
+    if (shape.mode == 0 && M < ctx->update256_rect_min_m) return false;
+    if (batch) {
+        const int64_t a16 = 16 / (int64_t)sizeof(T);
+        if (batch->count <= 0 || (batch->strideA % a16) || (batch->strideB % a16) || (batch->strideC % a16)) return false;
+    }
     // on the CU-masked update stream the kernel measured 10 % slower than the 128 x 128 one (profiles/r03_r_update256.log)
 #ifdef GPMI_TOOLS
     static const bool on_masked_too = getenv("GPMI_UPDATE256_ON_MASKED") != nullptr;  // tools: measure it there (tools/update256_streams.py)
@@ -417,32 +438,37 @@ static bool update256_plan(const gpmi_ctx* ctx, const T* C, int64_t ldc, const T
     if (sizeof(T) == 8 && ((ldc & 1) || (reinterpret_cast<uintptr_t>(C) & 15))) return false;  // fp64: 16-byte accesses to the C tile
     if (lda * (int64_t)sizeof(T) >= (1 << 24) || ldb * (int64_t)sizeof(T) >= (1 << 24)) return false;  // 32-bit staging offsets: 256 rows x stride
     TileShape s = shape;
-    s.mode = 3;
-    s.g0 = shape.g0 / 2;
+    if (shape.mode == 1) {
+        s.mode = 3;
+        s.g0 = shape.g0 / 2;
+    }
     s.ntm = (int)((M + U_BM - 1) / U_BM);
     s.ntn = (int)((N + U_BN - 1) / U_BN);
     const int64_t ntiles = tile_count(s);
-    if (ntiles < ctx->update256_min_tiles) return false;
+    if (ntiles * (batch ? batch->count : 1) < ctx->update256_min_tiles) return false;
     *out = s;
     *ntiles_out = ntiles;
     return true;
 }
 
-template <typename T, int ABL>
+template <typename T, int ABL, bool OVW = false>
 static bool launch_update256_abl(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
-                                 TileShape shape, const int* info) {
+                                 TileShape shape, const int* info, int flags = 0, const GemmBatch* batch = nullptr) {
     TileShape s;
-    int64_t ntiles;
-    if (!update256_plan<T>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, &s, &ntiles)) return false;
-    if (!prepare<T, ABL>(ctx)) return false;
+    int64_t tiles_per;
+    if (!update256_plan<T>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, &s, &tiles_per, flags, batch)) return false;
+    if (!prepare<T, ABL, OVW>(ctx)) return false;
+    const int64_t ntiles = tiles_per * (batch ? batch->count : 1);
     // one workgroup per CU; the look-ahead's free slots (two per CU in the 128 x 128 kernel's terms) become whole free CUs
     const int cus = (ctx->num_cus - (ctx->gemm_reserve + 1) / 2) / 8 * 8;
     const int grid = (int)std::min<int64_t>(cus, (ntiles + 7) / 8 * 8);
     if (grid <= 0) return false;
     QueueArgs qa;
     qa.use_queue = ntiles > grid;
-    qa.tiles_per = ntiles;
-    qa.strideA = qa.strideB = qa.strideC = 0;
+    qa.tiles_per = tiles_per;
+    qa.strideA = batch ? batch->strideA : 0;
+    qa.strideB = batch ? batch->strideB : 0;
+    qa.strideC = batch ? batch->strideC : 0;
     for (int x = 0; x <= 8; ++x) qa.start[x] = ntiles * x / 8;
     for (int x = 0; x < 8; ++x) {
         qa.base[x] = ctx->queue_base[x];
@@ -453,17 +479,19 @@ static bool launch_update256_abl(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, i
     if (ctx->attach_a) {  // profiled launch: the dispatch carries its own start / stop events (ProfScope attach mode)
         hipEvent_t ea = ctx->attach_a, eb = ctx->attach_b;
         ctx->attach_a = ctx->attach_b = nullptr;
-        hipExtLaunchKernelGGL((update256_kernel<T, ABL>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, ea, eb, 0, C, ldc, A, lda, B, ldb, M, N, K, s,
+        hipExtLaunchKernelGGL((update256_kernel<T, ABL, OVW>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, ea, eb, 0, C, ldc, A, lda, B, ldb, M, N, K, s,
                               ctx->d_queue, qa, info);
         return true;
     }
-    hipLaunchKernelGGL((update256_kernel<T, ABL>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, C, ldc, A, lda, B, ldb, M, N, K, s, ctx->d_queue,
+    hipLaunchKernelGGL((update256_kernel<T, ABL, OVW>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, C, ldc, A, lda, B, ldb, M, N, K, s, ctx->d_queue,
                        qa, info);
     return true;
 }
 template <typename T>
 bool launch_update256(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
-                      TileShape shape, const int* info) {
+                      TileShape shape, const int* info, int flags, const GemmBatch* batch) {
+    if (flags & GEMM_OVERWRITE) return launch_update256_abl<T, 0, true>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags, batch);
+    if (batch) return launch_update256_abl<T, 0, false>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags, batch);
 #ifdef GPMI_TOOLS
     switch (ctx->update256_ablation) {
         case 1: return launch_update256_abl<T, 1>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info);
@@ -488,8 +516,8 @@ template bool update256_applies<double>(const gpmi_ctx*, const double*, int64_t,
 template bool update256_applies<float>(const gpmi_ctx*, const float*, int64_t, const float*, int64_t, const float*, int64_t, int64_t, int64_t, int64_t,
                                        TileShape);
 template bool launch_update256<double>(gpmi_ctx*, double*, int64_t, const double*, int64_t, const double*, int64_t, int64_t, int64_t, int64_t,
-                                       TileShape, const int*);
+                                       TileShape, const int*, int, const GemmBatch*);
 template bool launch_update256<float>(gpmi_ctx*, float*, int64_t, const float*, int64_t, const float*, int64_t, int64_t, int64_t, int64_t,
-                                      TileShape, const int*);
+                                      TileShape, const int*, int, const GemmBatch*);
 
 }  // namespace gpmi

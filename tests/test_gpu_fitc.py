@@ -326,3 +326,31 @@ def test_fitc_c5_full_size_n1e6_m4096_woodbury_and_determinant_lemma():
           f"Woodbury residual {resid_max:.2e} (|y| max {np.abs(y).max():.2f})")
     assert resid_max <= 1e-6 * np.abs(y).max()
     assert abs(mll_dev - mll) <= 1e-6 * abs(mll)
+
+
+def test_fitc_tall_products_in_256x128_tiles_match_the_128_kernel(monkeypatch):
+    """Round 4: FITC's n m^2 products (W = Kfu Luu^-T's updates, the split-K U'U'' batches, the gradient's overwriting rectangles) run
+    on update256_kernel (rectangular / GEMM_OVERWRITE / batched forms) from 8192 rows on.  The same model through both kernels —
+    fit, predict, gradient — agrees to rounding (n = 20 000, m = 1500: K = 1024 whitening updates, ragged edge tiles in both
+    directions, 16-way split-K), and the result still satisfies the Woodbury identity."""
+    n, m, d = 20000, 1500, 4
+    rng = np.random.default_rng(5)
+    x = rng.uniform(size=(d, n))
+    xu = rng.uniform(size=(d, m))
+    y = np.sin(2.0 * x.sum(axis=0)) + 0.1 * rng.standard_normal(n)
+    xs = rng.uniform(size=(d, 50))
+    kern = lambda: g.SEArd([math.log(0.4) + 0.05 * j for j in range(d)], 0.1)
+    out = []
+    for u256 in ("1", "0"):
+        monkeypatch.setenv("GPMI_UPDATE256", u256)
+        gp = g.FITC(x, xu, y, g.MeanZero(), kern(), math.log(0.15), ctx=g.Context(0))
+        mu, var = gp.predict_f(xs)
+        gp.update_dmll()
+        out.append((gp.mll, np.array(gp.alpha), mu, var, np.array(gp.dmll)))
+        del gp
+    a, b = out
+    assert abs(a[0] - b[0]) <= 1e-10 * abs(b[0])
+    np.testing.assert_allclose(a[1], b[1], rtol=0, atol=1e-8 * np.abs(b[1]).max())
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(a[3], b[3], rtol=1e-7, atol=1e-11)
+    np.testing.assert_allclose(a[4], b[4], rtol=1e-7, atol=1e-8 * np.abs(b[4]).max())
