@@ -29,7 +29,7 @@ static const int64_t kWholeCusBelow = 20480;  // rows left below which a step re
 // chain (and the exposed tail) short below that
 static int64_t default_block(int64_t n, int world) {
     if (world == 1 && n >= 131072) return 2048;  // one rank, very large n: K = 2048 updates (N = 200 000 fp32: 20.9 instead of 22.0 s); below that the 2048-block chain outlasts the shrinking updates (N = 50 000: 790 instead of 760 ms, profiles/r03_h_*)
-    return n >= 32768 ? 1024 : (n >= 4096 ? 512 : 256);
+    return n >= 16384 ? 1024 : (n >= 4096 ? 512 : 256);  // (N = 20 000 on one rank: 82.9 ms with 1024-row blocks, 86.1 with 512: profiles/r04_g_*)
 }
 
 BlockedGP::BlockedGP(Dev* dev, Comm* comm, int d, int64_t n, BlockedOpts o)

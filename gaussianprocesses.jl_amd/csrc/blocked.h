@@ -14,7 +14,7 @@
 namespace gpmi {
 
 struct BlockedOpts {
-    int64_t block = 0;      // rows per distributed block (0: 1024 from 32 768 points — 2048 from 131 072 on one rank —, 512 from 4096, 256 below)
+    int64_t block = 0;      // rows per distributed block (0: 1024 from 16 384 points — 2048 from 131 072 on one rank —, 512 from 4096, 256 below)
     int stripe_blocks = 0;  // local blocks per storage stripe (0: one stripe = the plain rows x npad matrix)
 };
 

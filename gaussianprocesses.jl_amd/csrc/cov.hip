@@ -127,10 +127,9 @@ struct ScaleW {
 
 // amax (may be null): running maximum of |x| over everything scaled so far, as the bit pattern of a non-negative IEEE number
 // (ordered like the number itself) — the Noise prefilter's scale
-// pairs != 0: rows stored in pairs, [row / 2][k][row % 2] (cov_leaf_kernel's row operand; the buffer holds an even number of rows)
 template <typename T, int DMAX>
 __global__ __launch_bounds__(256) void scale_inputs_kernel(const T* __restrict__ x, int64_t n, int d, ScaleW<DMAX> w, T* __restrict__ out,
-                                                           unsigned long long* __restrict__ amax, int pairs) {
+                                                           unsigned long long* __restrict__ amax) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     T av = T(0);
     if (i < n * DMAX) {
@@ -138,8 +137,7 @@ __global__ __launch_bounds__(256) void scale_inputs_kernel(const T* __restrict__
         const int k = (int)(i - row * DMAX);
         const T v = k < d ? x[row * d + k] : T(0);
         av = fabs(v);
-        const int64_t o = pairs ? ((row >> 1) * DMAX + k) * 2 + (row & 1) : i;
-        out[o] = (T)((double)v * w.sw[k]);
+        out[i] = (T)((double)v * w.sw[k]);
     }
     if (amax) {
 #pragma unroll
@@ -153,7 +151,7 @@ __global__ __launch_bounds__(256) void scale_inputs_kernel(const T* __restrict__
                 bits = (unsigned long long)__double_as_longlong((double)av);
             else
                 bits = (unsigned long long)__float_as_uint((float)av);
-            atomicMax(amax, bits);
+            if (bits > *amax) atomicMax(amax, bits);  // (6250 waves on one word otherwise: 73 us per call)
         }
     }
 }
@@ -219,31 +217,25 @@ __global__ __launch_bounds__(256) void cov_leaf_kernel(const T* __restrict__ xas
             for (int j = 0; j < VEC; ++j) xbr[k + j][q] = v[j];
         }
     }
-    // The row operand is stored in ROW PAIRS ([row / 2][k][row % 2], scale_inputs_kernel): the two rows of a pass are adjacent scalar
-    // registers, and each (k, column) step is one packed subtract and one packed fma over the pair — v_pk_add_f32 / v_pk_fma_f32 in
-    // fp32 (half the VALU instructions of the distance loop; fp64 has no packed form and compiles to the same code as before)
-    using T2 = T __attribute__((ext_vector_type(2)));
-    const T2* __restrict__ ap = reinterpret_cast<const T2*>(xas) + ((row0 + wave * (TR / 4)) >> 1) * DMAX;
+    // (Measured and not kept, GPU call G: the row operand in row PAIRS so that fp32 runs the distance loop as v_pk_add_f32 / v_pk_fma_f32 over
+    //  two rows — 16 instead of 24 VALU instructions per entry, but the pre-splatted column registers double (164 VGPRs at d = 16,
+    //  3 waves per SIMD instead of 6): 1.59 against 1.40 ms in fp32, 2.09 against 1.98 ms in fp64.)
+    const T* __restrict__ ar = xas + (row0 + wave * (TR / 4)) * DMAX;
     T* __restrict__ crow = C + (row0 + wave * (TR / 4)) * ldc + col0 + (int64_t)lane * VEC;
 #pragma unroll 1
     for (int rr = 0; rr < TR / 4; rr += 2) {
-        T2 rp[VEC];
-#pragma unroll
-        for (int q = 0; q < VEC; ++q) rp[q] = T(0);
-#pragma unroll
-        for (int k = 0; k < DMAX; ++k) {
-            const T2 a = ap[(rr >> 1) * DMAX + k];  // wave-uniform address: scalar load of (row rr, row rr + 1)
-#pragma unroll
-            for (int q = 0; q < VEC; ++q) {
-                const T2 dd = a - xbr[k][q];
-                rp[q] = __builtin_elementwise_fma(dd, dd, rp[q]);
-            }
-        }
         T r0[VEC], r1[VEC];
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) {
-            r0[q] = rp[q][0];
-            r1[q] = rp[q][1];
+        for (int q = 0; q < VEC; ++q) r0[q] = r1[q] = T(0);
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) {
+            const T a0 = ar[rr * DMAX + k], a1 = ar[(rr + 1) * DMAX + k];  // wave-uniform addresses: scalar loads
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                const T d0 = a0 - xbr[k][q], d1 = a1 - xbr[k][q];
+                r0[q] = Tr<T>::fma_(d0, d0, r0[q]);
+                r1[q] = Tr<T>::fma_(d1, d1, r1[q]);
+            }
         }
         VT o0, o1;
 #pragma unroll
@@ -751,7 +743,7 @@ void launch_cov_t(gpmi_ctx* ctx, const T* xa, int64_t na, const T* xb, int64_t n
         multi = hp->n_ops > 1 && hp->fast_class >= 0;
         // both specialised kernels work on zero-padded (single leaf: also pre-scaled) copies of the two input blocks, 16 bytes of header
         // (max |x|) in front: without the scratch the interpreter takes every tile
-        if ((single_leaf || multi) && grow(ctx, &ctx->cov_scaled, &ctx->cov_scaled_cap, 16 + (na + 1 + nb) * DMAX * (int64_t)sizeof(T)) != GPMI_OK) {
+        if ((single_leaf || multi) && grow(ctx, &ctx->cov_scaled, &ctx->cov_scaled_cap, 16 + (na + nb) * DMAX * (int64_t)sizeof(T)) != GPMI_OK) {
             (void)hipGetLastError();
             single_leaf = multi = false;
             flags |= COV_NO_FAST;
@@ -759,7 +751,7 @@ void launch_cov_t(gpmi_ctx* ctx, const T* xa, int64_t na, const T* xb, int64_t n
         if (single_leaf || multi) {
             amax = (unsigned long long*)ctx->cov_scaled;
             xas = (T*)((char*)ctx->cov_scaled + 16);
-            xbs = xas + (na + (na & 1)) * DMAX;  // (the row operand may be stored in row pairs: an even number of rows)
+            xbs = xas + na * DMAX;
         }
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, xa, na, xb, nb, d, C, ldc, nrows_total, ncols_total,
@@ -782,9 +774,9 @@ void launch_cov_t(gpmi_ctx* ctx, const T* xa, int64_t na, const T* xb, int64_t n
             {
                 if (na > 0)
                     hipLaunchKernelGGL((scale_inputs_kernel<T, DMAX>), dim3((unsigned)((na * DMAX + 255) / 256)), dim3(256), 0, ctx->stream, xa, na, d, sw, xas,
-                                       (unsigned long long*)nullptr, 1);
+                                       (unsigned long long*)nullptr);
                 hipLaunchKernelGGL((scale_inputs_kernel<T, DMAX>), dim3((unsigned)((nb * DMAX + 255) / 256)), dim3(256), 0, ctx->stream, xb, nb, d, sw, xbs,
-                                   (unsigned long long*)nullptr, 0);
+                                   (unsigned long long*)nullptr);
                 auto go = [&](auto lk) {
                     hipLaunchKernelGGL(lk, grid, dim3(256), 0, ctx->stream, (const T*)xas, na, (const T*)xbs, nb, C, ldc, nrows_total, ncols_total,
                                        ctx->d_prog, flags, row_off, (T)lf.s2, (T)lf.p1);
@@ -802,8 +794,8 @@ void launch_cov_t(gpmi_ctx* ctx, const T* xa, int64_t na, const T* xb, int64_t n
             for (int k = 0; k < DMAX; ++k) one.sw[k] = 1.0;
             (void)hipMemsetAsync(amax, 0, 16, ctx->stream);
             if (na > 0)
-                hipLaunchKernelGGL((scale_inputs_kernel<T, DMAX>), dim3((unsigned)((na * DMAX + 255) / 256)), dim3(256), 0, ctx->stream, xa, na, d, one, xas, amax, 0);
-            hipLaunchKernelGGL((scale_inputs_kernel<T, DMAX>), dim3((unsigned)((nb * DMAX + 255) / 256)), dim3(256), 0, ctx->stream, xb, nb, d, one, xbs, amax, 0);
+                hipLaunchKernelGGL((scale_inputs_kernel<T, DMAX>), dim3((unsigned)((na * DMAX + 255) / 256)), dim3(256), 0, ctx->stream, xa, na, d, one, xas, amax);
+            hipLaunchKernelGGL((scale_inputs_kernel<T, DMAX>), dim3((unsigned)((nb * DMAX + 255) / 256)), dim3(256), 0, ctx->stream, xb, nb, d, one, xbs, amax);
             auto go = [&](auto mk) {
                 hipLaunchKernelGGL(mk, grid, dim3(256), 0, ctx->stream, (const T*)xas, na, (const T*)xbs, nb, C, ldc, nrows_total, ncols_total, ctx->d_prog,
                                    flags, row_off, (const unsigned long long*)amax);

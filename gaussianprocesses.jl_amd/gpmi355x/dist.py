@@ -27,7 +27,7 @@ from .gpe import GPE, HIPPDMat
 
 
 def default_block(n):
-    """Rows per distributed block (0 lets the library choose: 1024 from 32 768 points (2048 from 131 072 on one rank), 512 from 4096, 256 below)."""
+    """Rows per distributed block (0 lets the library choose: 1024 from 16 384 points (2048 from 131 072 on one rank), 512 from 4096, 256 below)."""
     e = os.environ.get("GPMI_DIST_WD")
     return int(e) if e else 0
 

@@ -177,7 +177,7 @@ GPMI_API int gpmi_fitc_grad(gpmi_fitc*, const gpmi_kernel*, double log_noise, do
 
 /* ---- blocked model object: packed storage on one device, row-block sharding over several ---------
  * The same gpmi_gp handle type and the same gpmi_fit / gpmi_predict / gpmi_grad / gpmi_logdet / gpmi_factor_diag, with the
- * factor of K + noise held as block-rows of block_rows = 256 * 2^s rows (0: 1024 from 32 768 points — 2048 from 131 072 on one rank —, 512 from 4096, 256 below)
+ * factor of K + noise held as block-rows of block_rows = 256 * 2^s rows (0: 1024 from 16 384 points — 2048 from 131 072 on one rank —, 512 from 4096, 256 below)
  *   - dealt round-robin over the ranks of `comm` (one process per GPU; every rank makes the same calls with the same
  *     arguments and receives the same results: mll, alpha, mu, var, gradient are replicated), and
  *   - per rank, in stripes of stripe_blocks local blocks that stop at their own diagonal (0: one stripe = full rows), so the

@@ -27,3 +27,7 @@ for w in seard c3 f32d16; do
   python "$R/tools/pmc_cov_valu.py" "$P" > "$R/$O/r04_cov_pmc_$w.json" 2>&1
   rm -rf "$P"
 done
+cd /tmp
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof_fitc" -- python "$R/tools/fitc_bench.py" 1000000x4096 > "$R/$O/r04_fitc_c5.log" 2>&1
+grep -v amdgpu "$R/$O/r04_fitc_c5.log" | grep "N=" ; (head -1 $(find "$R/$O/prof_fitc" -name "*kernel_stats.csv"); grep -h "gpmi" $(find "$R/$O/prof_fitc" -name "*kernel_stats.csv") | head -16) | cut -c1-90,150-240 | tee "$R/$O/r04_fitc_c5_kernel_stats.csv"
+rm -rf "$R/$O/prof_fitc"
