@@ -6,7 +6,7 @@
 //   U1   own rows below block k  x  block column k+1          -= X_k P_k[k+1]'      (narrow; makes column k+1 current)
 //   chain (owner of block k+1, stream DS_SIDE)                 dpotrf of the diagonal block + its explicit inverse LW_{k+1}
 //   bcast LW_{k+1} (DS_SIDE)
-//   U2a  own rows  x  block columns [k+2, m)                   under the chain and the broadcast
+//   U2a  own rows  x  block columns [k+2, m)                   under the chain and the broadcast (half of what is left)
 //   solve next panel: X_{k+1} <- X_{k+1} LW_{k+1}'  (out of place into S = the send buffer, copied back)
 //   all-gather of S into P_{k+1} (DS_SIDE)                     under U2b
 //   U2b  own rows  x  block columns [m, nblk)
@@ -16,6 +16,7 @@
 #include "blocked.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -44,6 +45,7 @@ BlockedGP::BlockedGP(Dev* dev, Comm* comm, int d, int64_t n, BlockedOpts o)
     nown_ = (int)own_.size();
     maxown_ = (int)((nblk_ + G_ - 1) / G_);
     per_ = (o.stripe_blocks <= 0 || o.stripe_blocks >= nown_) ? std::max(nown_, 1) : o.stripe_blocks;
+    if (const char* e = getenv("GPMI_BLOCKED_U2A")) u2a_div_ = std::max(1, atoi(e));  // tuning knob: U2a = 1 / u2a_div_ of the remaining block columns
 }
 
 BlockedGP::~BlockedGP() {
@@ -343,11 +345,13 @@ int BlockedGP::fit(const gpmi_kernel* kern, const double* log_noise, int64_t n_n
         DevShape rect, lower;
         lower.mode = 1;
         bool first_piece = true;
+        DevEvent ev_diag = nullptr;  // the next diagonal block is current: all the chain waits for (the rest of U1 runs beside it)
         for (const Piece& pc : pieces(nle, true)) {
             int64_t M = (int64_t)pc.nb * WD_ + (pc.carried ? 1 : 0);
             char* rows = pc.p;
             if (first_piece && mine_next && pc.nb > 0) {  // the next diagonal block itself: its lower tiles only
                 dev_->gemm(rows + k1 * es_, pc.ld, rows + k0 * es_, pc.ld, panel_rows(k, k + 1), ldP_, WD_, WD_, WD_, lower, 0);
+                ev_diag = dev_->record();
                 rows += WD_ * pc.ld * es_;
                 M -= WD_;
             }
@@ -361,7 +365,7 @@ int BlockedGP::fit(const gpmi_kernel* kern, const double* log_noise, int64_t n_n
             int64_t ld, width;
             char* blk = block_ptr(li, &ld, &width) + k1 * es_;
             dev_->use(DS_SIDE);
-            dev_->wait(ev_u1);
+            dev_->wait(ev_diag ? ev_diag : ev_u1);
             dev_->super_factor(blk, ld, WD_, linv_ + (int64_t)li * WD_ * 64 * es_, invd_ + (int64_t)li * WD_ * es_, LW_ + (k + 1) * WD_ * WD_ * es_,
                                k1);
             chain = dev_->record();
@@ -370,7 +374,7 @@ int BlockedGP::fit(const gpmi_kernel* kern, const double* log_noise, int64_t n_n
         // U2a: enough block columns to cover the chain and the broadcast, then the next panel, then the rest under the exchange
         // (one rank: nothing to exchange — the whole update hides the chain, the next panel is solved after it, as chol.h does)
         const int64_t rest = nblk_ - (k + 2);
-        const int64_t m = G_ == 1 ? nblk_ : std::min<int64_t>(nblk_, k + 2 + std::max<int64_t>(rest > 0 ? 1 : 0, (rest + 3) / 4));
+        const int64_t m = G_ == 1 ? nblk_ : std::min<int64_t>(nblk_, k + 2 + std::max<int64_t>(rest > 0 ? 1 : 0, (rest + u2a_div_ - 1) / u2a_div_));
         dev_->use(DS_UPD);
         if (G_ == 1)
             update_cols(k, k + 1, nblk_, k + 2);  // everything but the next diagonal block, in one launch per stripe

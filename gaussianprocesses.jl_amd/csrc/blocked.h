@@ -108,6 +108,9 @@ class BlockedGP {
     double* dfull_ = nullptr;
     int64_t dfull_cap_ = 0;
     int comm_rc_ = 0;
+    int u2a_div_ = 2;  // U2a (the part of a step's update that hides the chain and the inverse broadcast) = 1 / u2a_div_ of the remaining block
+                       // columns; the panel exchange hides under the rest.  Two CU partitions, N = 32 768: 367 / 362 / 344 ms for 4 / 3 / 2
+                       // (profiles/r04_i_partitions.log)
 };
 
 }  // namespace gpmi
