@@ -384,8 +384,8 @@ def test_cu_partitions_and_injected_collective_latency():
     peer-copy communicator); a test hook (GPMI_TEST_COMM_DELAY_US / _ON) puts D ms of extra latency — a spin kernel on the stream the
     collective is given — in front of every panel exchange, or of every inverse broadcast.  A serial exchange would lengthen the fit by
     the whole injected total; the pipeline of csrc/blocked.cpp must absorb the delays that fit under the update they run beside: step
-    k's update lasts t_k ~ (rows left)^2; the exchange has U2b = 3 t_k / 4 to hide under, the broadcast only U2a = t_k / 4 minus the
-    chain that produces the inverse.  Timing-sensitive, so it runs in a process of its own (a long-lived pytest process that has
+    k's update lasts t_k ~ (rows left)^2; the exchange has U2b = t_k / 2 to hide under, the broadcast U2a = t_k / 2 minus the chain
+    that produces the inverse.  Timing-sensitive, so it runs in a process of its own (a long-lived pytest process that has
     created dozens of contexts shares hardware queues between their streams)."""
     import json
 
@@ -403,7 +403,7 @@ def test_cu_partitions_and_injected_collective_latency():
         name, D = key.split("+")[0], float(key.split("+")[1][:-2])
         count = nblk - 1 if name == "panel_exchange" else nblk     # per fit
         injected = D * count
-        share = 0.75 * tk if name == "panel_exchange" else np.concatenate(([0.0], 0.25 * tk - 3.0))   # (~3 ms: the 1024-block chain)
+        share = 0.5 * tk if name == "panel_exchange" else np.concatenate(([0.0], 0.5 * tk - 3.0))   # (~3 ms: the 1024-block chain)
         uncover = float(np.sum(D * (D > share[:count])))
         r["delays"][key] = {"fit_ms": t, "injected_ms": injected, "extra_ms": t - t0, "exposed_fraction": (t - t0) / injected,
                             "model_uncoverable_ms": uncover, "model_coverable_ms": injected - uncover}
