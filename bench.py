@@ -23,8 +23,11 @@ Prints ONE JSON line (rank 0).  Extra objects:
                  launch / mean launch duration, measured live with HIP events on the library's
                  stream over the timed region (gpmi_profile_*).
   cpu_baseline — the CPU oracle (a port: the Julia reference cannot run here) MEASURED on this host at the bench size
-                 (one fit + predict; cov! single-threaded C like the reference's loop, LAPACK on the host's cores),
-                 with the CPU model, core count and BLAS thread count recorded.
+                 (one fit + predict; cov! single-threaded C like the reference's loop — and, beside it, a vectorised-NumPy
+                 cov! figure —, LAPACK on the host's cores), with the CPU model, core count and BLAS threads.
+  parity       — the device fit + predict_f at the base hyper-parameters against that oracle run (exit code 3 above 1e-5).
+Secondary objects carry their own `parity`: c4_single_gpu (solve residual on 512 oracle-rebuilt rows), grad and c5 (analytic
+directional derivative against a central difference of the device mll).
 """
 import argparse
 import json
@@ -44,13 +47,13 @@ for p in (ROOT, os.path.join(ROOT, "gaussianprocesses.jl_amd")):
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (v_mfma_f64_16x16x4_f64): 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: Peak FP32 (matrix)
-PMC_RECORD = os.path.join("profiles", "r03_bench_pmc_hbm.json")
+PMC_RECORD = os.path.join("profiles", "r04_bench_pmc_hbm.json")
 
 
 def _pmc_traffic(args, n, d, p):
     """HBM bytes per launch of the roofline kernel.  PMC counters cannot be read from inside the timed process, so the
     number comes from the committed summary of the separate rocprofv3 --pmc passes over THIS command
-    (tools/gpu_pmc_bench.sh -> profiles/r02_bench_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE in their own passes, the
+    (tools/gpu_pmc_bench.sh -> profiles/r04_bench_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE in their own passes, the
     gfx950 x2 read correction of MI355X_MICROARCH.md applied).  It only applies to the default workload; anything
     else reports null."""
     path = os.path.join(ROOT, PMC_RECORD)
