@@ -5,8 +5,9 @@ libgpmi.so ships behind gpmi_gp_create_blocked) compiled with g++ against a host
   * as world_size-2 / -3 process groups under real torch.distributed collectives (gloo),
 checked against the oracle: mll, alpha, logdet, diag(U), predict_f (variance and full covariance), update_dmll! (kernel and
 noise parts) and the PosDefException contract.  The stand-in honours the tile shapes the driver requests exactly, so the
-block-cyclic ownership, the staircase bookkeeping, the look-ahead split of every update (U1 / U2a / U2b), the padded
-all-gather + scatter into global row order, the distributed backward solve and the order of the collectives are all pinned."""
+block-cyclic ownership, the staircase bookkeeping, the look-ahead split of every update (U1 / U2a / U2b), the per-group
+all-gathers straight into global row order, the distributed backward solve, the AbstractPDMat surface (solve / whiten / inv_diag /
+factor_to_host) and the order of the collectives are all pinned."""
 import math
 import os
 import socket

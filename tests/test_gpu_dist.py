@@ -5,9 +5,13 @@
   (c) as TWO PROCESSES on the one GPU under real torch.distributed collectives (gloo on device buffers, through the product's
       TorchDistComm) at N = 12 288 — stream ordering between asynchronous collectives and gpmi kernels across processes,
   (d) RCCL itself in a group of one: libgpmi's own RCCL communicator (gpmi_comm_create_rccl) and torch's "nccl" backend behind
-      the callbacks, each through gpmi_comm_selftest.
+      the callbacks, each through gpmi_comm_selftest,
+  (e) (round 4) as an in-process device group over the two CU PARTITIONS of the GPU (device ids 256 / 512: disjoint halves of
+      every XCD — two logical devices that run side by side), incl. the injected-latency measurement of what the look-ahead
+      pipeline hides, and the AbstractPDMat surface (solve / whiten / inv_diag / cholfactors) on every blocked configuration.
 Together with tests/test_blocked_cpu.py (the same orchestration source on a host stand-in: thread ranks and gloo process groups
-of 2 and 3) this covers the multi-GPU path as far as one GPU allows; what cannot run here is RCCL between >= 2 devices."""
+of 2 and 3) this covers the multi-GPU path as far as one GPU allows; what cannot run here is RCCL between >= 2 devices
+(tools/multidev_check.py is the functional check for a box that shows more than one)."""
 import math
 import os
 import subprocess
