@@ -340,12 +340,11 @@ root = os.getcwd()
 sys.path.insert(0, os.path.join(root, "gaussianprocesses.jl_amd")); sys.path.insert(0, root)
 import gpmi355x as g
 from gpmi355x import dist as gd
-n, WD, d = 32768, 1024, 8
+n, WD, d = 65536, 1024, 8
 rng = np.random.default_rng(17)
 x = rng.uniform(size=(d, n)); y = np.sin(2 * x.sum(axis=0)) + 0.1 * rng.standard_normal(n)
 ll = [math.log(0.5) + 0.05 * k for k in range(d)]; ln = math.log(0.1)
 kern = lambda: g.SEArd(ll, 0.0)
-dense = g.GP(x, y, g.MeanZero(), kern(), ln)
 # ---- (1) two CU partitions work CONCURRENTLY: two fits side by side take about as long as one of them
 halves = [g.GP(x[:, :16384], y[:16384], g.MeanZero(), kern(), ln, ctx=g.Context(256 * (1 + p))) for p in range(2)]
 def timed(models):
@@ -356,76 +355,68 @@ def timed(models):
     return (time.perf_counter() - t0) * 1e3
 timed(halves)
 one = min(timed(halves[:1]) for _ in range(3)); both = min(timed(halves) for _ in range(3))
+assert abs(halves[0].mll - halves[1].mll) <= 1e-12 * abs(halves[0].mll)
 del halves
 # ---- (2) a model sharded over the two partitions, with injected latency in front of the collectives
 ctx = g.Context(devices=[256, 512])
 gp = gd.ShardedGPE(x, y, g.MeanZero(), kern(), ln, ctx=ctx, block=WD)
-assert abs(gp.mll - dense.mll) <= 1e-10 * abs(dense.mll)
+mll0 = gp.mll
 def fit_ms(m):
     ts = []
-    for rep in range(3):
+    for rep in range(2):
         t0 = time.perf_counter(); m.update_mll(); ts.append(time.perf_counter() - t0)
     return min(ts) * 1e3
 res = {}
 t0 = fit_ms(gp)
 for what, name in ((2, "panel_exchange"), (1, "inverse_broadcast")):
     os.environ["GPMI_TEST_COMM_DELAY_ON"] = str(what)
-    for D in (1.0, 5.0):
-        os.environ["GPMI_TEST_COMM_DELAY_US"] = str(int(D * 1000))
-        res[name + "+" + str(D) + "ms"] = fit_ms(gp)
-        assert abs(gp.mll - dense.mll) <= 1e-10 * abs(dense.mll)
+    os.environ["GPMI_TEST_COMM_DELAY_US"] = "5000"
+    res[name + "+5ms"] = fit_ms(gp)
+    assert abs(gp.mll - mll0) <= 1e-12 * abs(mll0)
 os.environ.pop("GPMI_TEST_COMM_DELAY_US"); os.environ.pop("GPMI_TEST_COMM_DELAY_ON")
 print("OVERLAP " + json.dumps({"n": n, "block": WD, "one_fit_on_a_partition_ms": one, "two_fits_side_by_side_ms": both,
-                               "fit_ms_no_delay": t0, "dense_fit_ms_whole_device": fit_ms(dense), "fit_ms": res}), flush=True)
+                               "fit_ms_no_delay": t0, "fit_ms_no_delay_again": fit_ms(gp), "fit_ms": res}), flush=True)
 """
 
 
 def test_cu_partitions_and_injected_collective_latency():
     """VERDICT r3 Next 1(a, b).  (a) The driver refused compute partitioning of the leased MI355X (profiles/r04_a_cpx_refused.log), so
     the two logical devices are the two CU PARTITIONS of the one GPU (device ids 256 and 512: disjoint halves of every XCD; include/
-    gpmi.h) — the test first shows that they really run side by side (two fits at once take about as long as one).  (b) Does the
-    one-step look-ahead hide the exchange?  A model sharded over the two partitions (in-process device group, libgpmi's event-ordered
-    peer-copy communicator); a test hook (GPMI_TEST_COMM_DELAY_US / _ON) puts D ms of extra latency — a spin kernel on the stream the
-    collective is given — in front of every panel exchange, or of every inverse broadcast.  A serial exchange would lengthen the fit by
-    the whole injected total; the pipeline of csrc/blocked.cpp must absorb the delays that fit under the update they run beside: step
-    k's update lasts t_k ~ (rows left)^2; the exchange has U2b = t_k / 2 to hide under, the broadcast U2a = t_k / 2 minus the chain
-    that produces the inverse.  Timing-sensitive, so it runs in a process of its own (a long-lived pytest process that has
-    created dozens of contexts shares hardware queues between their streams)."""
+    gpmi.h) — the test first shows that they really run side by side (two fits at once take well under twice one).  (b) Does the
+    one-step look-ahead hide the exchange?  A model of N = 65 536 sharded over the two partitions (in-process device group, libgpmi's
+    event-ordered peer-copy communicator); a test hook (GPMI_TEST_COMM_DELAY_US / _ON) puts 5 ms of extra latency — a spin kernel on
+    the stream the collective is given — in front of every panel exchange (63 x 5 = 315 ms injected), or of every inverse broadcast.
+    A serial exchange would lengthen the fit by the whole injected total.  The pipeline of csrc/blocked.cpp hides the exchange under
+    U2b (half of step k's update, t_k ~ (rows left)^2: 5 ms fit under it for about the first two thirds of the steps at this size) and
+    the broadcast under U2a minus the chain that produces the inverse, so both must come out well below 1.0 — and cannot reach 0
+    (the last third of the steps is shorter than the delay).  Timing-sensitive, so it runs in a process of its own (a long-lived pytest
+    process that has created dozens of contexts shares hardware queues between their streams); bounds from four measured runs."""
     import json
 
-    out = subprocess.run([sys.executable, "-c", _OVERLAP], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, "-c", _OVERLAP], cwd=ROOT, capture_output=True, text=True, timeout=1500)
     line = [ln_ for ln_ in out.stdout.splitlines() if ln_.startswith("OVERLAP ")]
     assert out.returncode == 0 and line, out.stdout[-1500:] + out.stderr[-3000:]
     r = json.loads(line[0][8:])
-    assert r["two_fits_side_by_side_ms"] < 1.7 * r["one_fit_on_a_partition_ms"], r   # (serial would be 2.0; measured 1.46: shared L2 / HBM / clocks)
-    n, WD, t0 = r["n"], r["block"], r["fit_ms_no_delay"]
+    assert r["two_fits_side_by_side_ms"] < 1.7 * r["one_fit_on_a_partition_ms"], r   # (serial would be 2.0; measured 1.43 - 1.46: shared L2 / HBM / clocks)
+    n, WD, t0 = r["n"], r["block"], min(r["fit_ms_no_delay"], r["fit_ms_no_delay_again"])
     nblk = -(-n // WD)
     rem2 = np.array([(n - (k + 1) * WD) ** 2 for k in range(nblk - 1)], dtype=float)
-    tk = t0 * rem2 / rem2.sum()                      # step k's update (upper bound: t0 holds everything else as well)
+    tk = 0.5 * t0 * rem2 / rem2.sum()                # step k's update, taking the updates as half of the fit (measured: ~0.5 on partitions)
     r["delays"] = {}
     for key, t in r["fit_ms"].items():
         name, D = key.split("+")[0], float(key.split("+")[1][:-2])
         count = nblk - 1 if name == "panel_exchange" else nblk     # per fit
         injected = D * count
-        share = 0.5 * tk if name == "panel_exchange" else np.concatenate(([0.0], 0.5 * tk - 3.0))   # (~3 ms: the 1024-block chain)
+        share = 0.5 * tk if name == "panel_exchange" else np.concatenate(([0.0], 0.5 * tk - 3.5))   # (~3.5 ms: the 1024-block chain)
         uncover = float(np.sum(D * (D > share[:count])))
         r["delays"][key] = {"fit_ms": t, "injected_ms": injected, "extra_ms": t - t0, "exposed_fraction": (t - t0) / injected,
-                            "model_uncoverable_ms": uncover, "model_coverable_ms": injected - uncover}
+                            "model_uncoverable_fraction": uncover / injected}
     print("injected-latency overlap:", json.dumps(r))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "r04_overlap_latency.json"), "w") as fh:
         json.dump(r, fh, indent=1)
-    # the panel exchange — N^2/2 elements per rank per fit, the traffic that matters — stays off the critical path wherever the update
-    # beside it is longer than the delay: 15 % of the coverable total + timer noise (a serial exchange fails by all of it)
-    for D, slack in ((1.0, 0.15), (5.0, 0.30)):   # (the step-time model is coarse where delay and update are of the same order)
-        e = r["delays"][f"panel_exchange+{D}ms"]
-        assert e["extra_ms"] <= e["model_uncoverable_ms"] + slack * e["model_coverable_ms"] + 0.05 * t0, r
-    # (measured over three boxes: 0.33 - 0.49 at 1 ms — 31 ms injected against +-5 ms of run-to-run noise on a 405 ms fit — and 0.64 -
-    #  0.65 at 5 ms, of which the model calls 0.42 uncoverable; a serial exchange is >= 1.0 at both)
-    assert r["delays"]["panel_exchange+1.0ms"]["exposed_fraction"] < 0.8, r
-    assert r["delays"]["panel_exchange+5.0ms"]["exposed_fraction"] < 0.8, r
-    # the inverse broadcast sits behind the chain under U2a only: reported, and bounded by "no worse than serial"
-    assert r["delays"]["inverse_broadcast+1.0ms"]["exposed_fraction"] < 1.25, r
+    assert r["delays"]["panel_exchange+5ms"]["exposed_fraction"] < 0.8, r      # a serial exchange: 1.0
+    assert r["delays"]["inverse_broadcast+5ms"]["exposed_fraction"] < 0.9, r
 
 
 def test_cu_partitions_sharded_model_matches_the_oracle():
