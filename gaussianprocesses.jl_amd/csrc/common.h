@@ -151,6 +151,7 @@ struct gpmi_ctx {
                                          // GPMI_UPDATE256=0: round 2's 128 x 128 kernel everywhere)
     bool side_one_per_xcd = false;       // set around a look-ahead chain whose update will run as update256_kernel (chol.h, side_slots)
     int update256_ablation = 0;         // tools builds: ABL bits of update256_kernel for gpmi_bench_gemm (variant 256 + bits)
+    int update256_atomic = 0;            // the C tile of a subtracting launch goes out as no-return atomic adds instead of load / add / store (GPMI_UPDATE256_ATOMIC)
     int64_t update256_rect_min_m = 8192; // rectangular / batched products go to the 256 x 128 kernel from this many rows on (GPMI_UPDATE256_RECT: test hook)
     int64_t update256_min_tiles = 1024;  // ... from this many 256 x 128 tiles on (GPMI_UPDATE256_MIN: test hook)
     hipStream_t own_stream = nullptr;    // the stream created with the context

@@ -32,6 +32,7 @@
 #include <utility>
 
 #include <hip/hip_ext.h>
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include "common.h"
 #include "gemm_queue.h"
@@ -77,7 +78,11 @@ __device__ __forceinline__ void slab_wait(Vec (&a)[4], Vec (&b)[4]) {  // own DM
 // OVW: C = A B' (GEMM_OVERWRITE: the C tile is not read) instead of C -= A B'.  Batched launches (QueueArgs::tiles_per / stride*: split-K
 // with separate outputs) and rectangular regions (tile_order mode 0) take the same path: round 4 widened the kernel from the Cholesky
 // trailing update to FITC's n m^2 products (W = Kfu Luu^-T over 10^6 rows, U' U'' in 16 K-chunks).
-template <typename T, int ABL, bool OVW>
+// ATOM (interior tiles of a subtracting launch): the epilogue does not read C at all — every accumulator element goes out as ONE
+// no-return global_atomic_add (the L2 does the read-modify-write; exactly one add per element, so the result is bit-identical and
+// deterministic): no load latency left in the epilogue (LABBOOK 3.2b: the epilogue was 2.4 % of the kernel at K = 2048, 5.5 % at
+// K = 1024 — four dependent load batches per tile, not bytes).
+template <typename T, int ABL, bool OVW, bool ATOM = false>
 __global__ __launch_bounds__(512, 2) void update256_kernel(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int64_t lda,
                                                            const T* __restrict__ B, int64_t ldb, int64_t M, int64_t N, int64_t K,
                                                            TileShape shape, unsigned long long* __restrict__ queue, QueueArgs qa,
@@ -309,6 +314,17 @@ __global__ __launch_bounds__(512, 2) void update256_kernel(T* __restrict__ C, in
 #pragma unroll
                     for (int r = 0; r < 4; ++r) sacc += acc[mi][ni].v[r];
             if (sacc == T(-1.2345e30)) C[0] = sacc;
+        } else if (ATOM && !OVW && interior) {
+            T* const pc = Cw + (int64_t)MF::row_of(ln2, 0) * ld2 + MF::col_of(ln2, 0);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const T v = acc[mi][ni].v[r];
+                        unsafeAtomicAdd(pc + (int64_t)(mi * 16 + r * MF::RSTEP) * ld2 + ni * 16, MF::NEG ? v : -v);
+                    }
         } else if (interior) {
             if constexpr (PAIR16) {
                 // fp64, 16-byte accesses (gemm.hip): the even lane of a pair moves (c, c + 1) of the row of register 2q, the odd lane
@@ -386,17 +402,17 @@ __global__ __launch_bounds__(512, 2) void update256_kernel(T* __restrict__ C, in
                     }
         }
         if (!more) break;
-        prev_stores32 = PAIR16 && interior && !(ABL & 1);
+        prev_stores32 = PAIR16 && interior && !(ABL & 1) && !(ATOM && !OVW);  // (the atomic epilogue has 64 operations per lane in flight: full wait)
     }
 }
 
-template <typename T, int ABL, bool OVW>
+template <typename T, int ABL, bool OVW, bool ATOM>
 bool prepare(gpmi_ctx* ctx) {
     // 144 KiB of dynamic LDS need the attribute once per device and instantiation
     static bool done[64] = {false};
     const int dev = ctx->device & 63;
     if (done[dev]) return true;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&update256_kernel<T, ABL, OVW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&update256_kernel<T, ABL, OVW, ATOM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             U_NBUF * (U_BM + U_BN) * 128) != hipSuccess) {
         (void)hipGetLastError();
         return false;
@@ -451,13 +467,13 @@ static bool update256_plan(const gpmi_ctx* ctx, const T* C, int64_t ldc, const T
     return true;
 }
 
-template <typename T, int ABL, bool OVW = false>
+template <typename T, int ABL, bool OVW = false, bool ATOM = false>
 static bool launch_update256_abl(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
                                  TileShape shape, const int* info, int flags = 0, const GemmBatch* batch = nullptr) {
     TileShape s;
     int64_t tiles_per;
     if (!update256_plan<T>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, &s, &tiles_per, flags, batch)) return false;
-    if (!prepare<T, ABL, OVW>(ctx)) return false;
+    if (!prepare<T, ABL, OVW, ATOM>(ctx)) return false;
     const int64_t ntiles = tiles_per * (batch ? batch->count : 1);
     // one workgroup per CU; the look-ahead's free slots (two per CU in the 128 x 128 kernel's terms) become whole free CUs
     const int cus = (ctx->num_cus - (ctx->gemm_reserve + 1) / 2) / 8 * 8;
@@ -479,11 +495,11 @@ static bool launch_update256_abl(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, i
     if (ctx->attach_a) {  // profiled launch: the dispatch carries its own start / stop events (ProfScope attach mode)
         hipEvent_t ea = ctx->attach_a, eb = ctx->attach_b;
         ctx->attach_a = ctx->attach_b = nullptr;
-        hipExtLaunchKernelGGL((update256_kernel<T, ABL, OVW>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, ea, eb, 0, C, ldc, A, lda, B, ldb, M, N, K, s,
+        hipExtLaunchKernelGGL((update256_kernel<T, ABL, OVW, ATOM>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, ea, eb, 0, C, ldc, A, lda, B, ldb, M, N, K, s,
                               ctx->d_queue, qa, info);
         return true;
     }
-    hipLaunchKernelGGL((update256_kernel<T, ABL, OVW>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, C, ldc, A, lda, B, ldb, M, N, K, s, ctx->d_queue,
+    hipLaunchKernelGGL((update256_kernel<T, ABL, OVW, ATOM>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, C, ldc, A, lda, B, ldb, M, N, K, s, ctx->d_queue,
                        qa, info);
     return true;
 }
@@ -492,6 +508,7 @@ bool launch_update256(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda,
                       TileShape shape, const int* info, int flags, const GemmBatch* batch) {
     if (flags & GEMM_OVERWRITE) return launch_update256_abl<T, 0, true>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags, batch);
     if (batch) return launch_update256_abl<T, 0, false>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags, batch);
+    if (ctx->update256_atomic) return launch_update256_abl<T, 0, false, true>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags, batch);
 #ifdef GPMI_TOOLS
     switch (ctx->update256_ablation) {
         case 1: return launch_update256_abl<T, 1>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info);
