@@ -15,7 +15,8 @@ using GaussianProcesses
 using GaussianProcesses: GPE, GPBase, Kernel, Mean, KernelData, EmptyData, CovarianceStrategy,
     SEIso, SEArd, Mat12Iso, Mat12Ard, Mat32Iso, Mat32Ard, Mat52Iso, Mat52Ard, RQIso, RQArd,
     Noise, Const, SumKernel, ProdKernel, Masked, FixedKernel, get_value, log2π
-import GaussianProcesses: alloc_cK, update_cK!, update_mll!, update_dmll!, grad_stack, num_params, get_alpha_u, predictMVN, predict_f, mat, cholfactors, wrap_cK
+import GaussianProcesses: alloc_cK, update_cK!, update_mll!, grad_stack, num_params, get_alpha_u, predictMVN, predict_f, mat, cholfactors, wrap_cK,
+    init_precompute, precompute!, dmll_kern!, dmll_noise, AbstractGradientPrecompute
 using PDMats
 import PDMats: dim, whiten!, whiten, unwhiten!
 using LinearAlgebra
@@ -206,8 +207,7 @@ function update_mll!(gp::GPE{X,Y,M,K,HIPCovariance}; noise::Bool=true, domean::B
     gp
 end
 
-# update_dmll! (src/GPE.jl:298-324): kernel and noise parts from the device in one pass over ααᵀ − K⁻¹
-# (no N×N ααinvcKI on the host, no per-parameter N² loops); the mean part stays here (src/GPE.jl:282-288).
+# slots of the free parameters inside the kernel tree's full parameter list (FixedKernel hides some: fixed_kernel.jl:63-66)
 full_slots(k::Kernel) = collect(1:num_params(k))
 full_slots(k::FixedKernel) = full_slots(k.kernel)[k.free]
 full_slots(k::Masked) = full_slots(k.kernel)
@@ -215,25 +215,33 @@ full_slots(k::Union{SumKernel,ProdKernel}) = [full_slots(k.kleft); full_nparams(
 full_nparams(k::Kernel) = num_params(k)
 full_nparams(k::Union{FixedKernel,Masked}) = full_nparams(k.kernel)
 full_nparams(k::Union{SumKernel,ProdKernel}) = full_nparams(k.kleft) + full_nparams(k.kright)
-function update_dmll!(gp::GPE{X,Y,M,K,HIPCovariance}; noise::Bool=true, domean::Bool=true, kern::Bool=true) where {X,Y,M,K}
+# The gradient goes through the reference's own SEAM (src/GPE.jl:245-324), not around it: optimize!, mcmc and vi call
+# update_dmll!(gp, precomp) / update_target_and_dtarget!(gp, precomp) with precomp = init_precompute(gp) (src/GPE.jl:260,298,382-391,
+# src/mcmc.jl:10-17), and the generic update_dmll! then asks precompute!, dmll_noise, dmll_mean!, dmll_kern! in turn.  For the exact
+# path the reference's precompute is the N x N matrix alpha alpha' - K^-1 (FullCovariancePrecompute, get_ααinvcKI!) that dmll_kern!
+# re-walks once per parameter; here precompute! IS the whole device pass (ONE gpmi_grad call: K^-1 block by block, the fused dK/dtheta
+# trace for all parameters, the noise trace) and dmll_kern! / dmll_noise hand out its results.  dmll_mean! stays the generic one.
+struct HIPGradientPrecompute <: AbstractGradientPrecompute
+    dkern::Vector{Float64}            # d mll / d theta_p for every parameter of the kernel TREE (fixed ones included), get_params order
+    dnoise::Base.RefValue{Float64}
+end
+init_precompute(::HIPCovariance, X, y, k::Kernel) = HIPGradientPrecompute(Vector{Float64}(undef, max(full_nparams(k), 1)), Ref(0.0))
+function precompute!(p::HIPGradientPrecompute, gp::GPBase)
     nfull = full_nparams(gp.kernel)
-    dk = Vector{Float64}(undef, max(nfull, 1)); dn = Ref{Float64}(0.0)
+    length(p.dkern) >= max(nfull, 1) || resize!(p.dkern, max(nfull, 1))
     ln = Float64[get_value(gp.logNoise)]
     rc = withkernel(descriptor(gp.kernel)) do ck
         ccall((:gpmi_grad, libgpmi), Cint, (Ptr{Cvoid}, Ref{CKernel}, Ptr{Float64}, Int64, Ptr{Float64}, Int32, Ref{Float64}),
-              gp.cK.handle, ck, ln, 1, dk, nfull, dn)
+              gp.cK.handle, ck, ln, 1, p.dkern, nfull, p.dnoise)
     end
     check(context(), rc)
-    n_mean = num_params(gp.mean)
-    gp.dmll = Vector{Float64}(undef, noise + domean * n_mean + kern * num_params(gp.kernel))
-    i = 1
-    noise && (gp.dmll[i] = dn[]; i += 1)
-    if domean && n_mean > 0
-        gp.dmll[i:i+n_mean-1] = grad_stack(gp.mean, gp.x)' * gp.alpha; i += n_mean
-    end
-    kern && (gp.dmll[i:end] = dk[full_slots(gp.kernel)])
-    gp
+    p
 end
+function dmll_kern!(dmll::AbstractVector, gp::GPBase, p::HIPGradientPrecompute, ::HIPCovariance)       # src/GPE.jl:265-267
+    dmll .= @view p.dkern[full_slots(gp.kernel)]
+    dmll
+end
+dmll_noise(gp::GPE, p::HIPGradientPrecompute, ::HIPCovariance) = p.dnoise[]                               # src/GPE.jl:279-281
 
 function \(a::HIPPDMat, b::DenseVecOrMat{Float64})                      # PDMats `\`  (src/GPE.jl:208)
     out = copy(b)
@@ -353,25 +361,21 @@ function predict_f(gp::GPE{X,Y,M,K,<:HIPFITC}, x::AbstractMatrix; full_cov::Bool
     end
     check(context(), rc); μ, Σ
 end
-# update_dmll! (src/GPE.jl:298-324) with dmll_kern! / dmll_noise of the FITC strategy (fully_indep…:200-257) from the device
-function update_dmll!(gp::GPE{X,Y,M,K,<:HIPFITC}; noise::Bool=true, domean::Bool=true, kern::Bool=true) where {X,Y,M,K}
+# the same seam for the FITC strategy: precompute! = gpmi_fitc_grad (dmll_kern!(…, ::FullyIndepStrat) fully_indep…:200-234 over
+# subsetofregressors.jl:219-256, dmll_noise :243-257, precompute! subsetofregressors.jl:141-151 — all of it in one device pass)
+init_precompute(::HIPFITC, X, y, k::Kernel) = HIPGradientPrecompute(Vector{Float64}(undef, max(full_nparams(k), 1)), Ref(0.0))
+function precompute!(p::HIPGradientPrecompute, gp::GPE{X,Y,M,K,<:HIPFITC}) where {X,Y,M,K}
     nfull = full_nparams(gp.kernel)
-    dk = Vector{Float64}(undef, max(nfull, 1)); dn = Ref{Float64}(0.0)
+    length(p.dkern) >= max(nfull, 1) || resize!(p.dkern, max(nfull, 1))
     rc = withkernel(descriptor(gp.kernel)) do ck
         ccall((:gpmi_fitc_grad, libgpmi), Cint, (Ptr{Cvoid}, Ref{CKernel}, Float64, Ptr{Float64}, Int32, Ref{Float64}),
-              gp.cK.handle, ck, Float64(get_value(gp.logNoise)), dk, nfull, dn)
+              gp.cK.handle, ck, Float64(get_value(gp.logNoise)), p.dkern, nfull, p.dnoise)
     end
     check(context(), rc)
-    n_mean = num_params(gp.mean)
-    gp.dmll = Vector{Float64}(undef, noise + domean * n_mean + kern * num_params(gp.kernel))
-    i = 1
-    noise && (gp.dmll[i] = dn[]; i += 1)
-    if domean && n_mean > 0
-        gp.dmll[i:i+n_mean-1] = grad_stack(gp.mean, gp.x)' * gp.alpha; i += n_mean
-    end
-    kern && (gp.dmll[i:end] = dk[full_slots(gp.kernel)])
-    gp
+    p
 end
+dmll_kern!(dmll::AbstractVector, gp::GPBase, p::HIPGradientPrecompute, ::HIPFITC) = (dmll .= @view p.dkern[full_slots(gp.kernel)]; dmll)
+dmll_noise(gp::GPE, p::HIPGradientPrecompute, ::HIPFITC) = p.dnoise[]
 function get_alpha_u(a::HIPFITCPDMat, args...)                           # fully_indep…:279-286
     au = Vector{Float64}(undef, size(a.inducing, 2))
     check(context(), ccall((:gpmi_fitc_alpha_u, libgpmi), Cint, (Ptr{Cvoid}, Ptr{Float64}), a.handle, au)); au

@@ -161,6 +161,26 @@ def test_update_in_256x128_tiles_small(monkeypatch, n, dtype, cumask):
     np.testing.assert_allclose(var, rvar, rtol=0, atol=(1e-8 if dtype == np.float64 else 2e-3))
 
 
+def test_update_in_256x128_tiles_atomic_epilogue(monkeypatch):
+    """GPMI_UPDATE256_ATOMIC=1: the C tile of a subtracting launch leaves as no-return global_atomic_add (one add per element: the same
+    numbers as load / add / store).  Same factorisation with and without: mll, alpha and the factor's diagonal agree to rounding."""
+    x, y, _ = G.synthetic_inputs(6000, 5, p=4)
+    kern = lambda: g.SEArd([math.log(0.6)] * 5, 0.0)
+    monkeypatch.setenv("GPMI_UPDATE256_MIN", "1")
+    monkeypatch.setenv("GPMI_CUMASK", "0")
+    monkeypatch.setenv("GPMI_SUPER", "1024,2048,100000")
+    out = []
+    for atom in ("1", "0"):
+        monkeypatch.setenv("GPMI_UPDATE256_ATOMIC", atom)
+        gp = g.GP(x, y, g.MeanZero(), kern(), math.log(0.1), ctx=g.Context(0))
+        out.append((gp.mll, np.array(gp.alpha), np.array(gp.cK.factor_diag())))
+    ref = G.update_mll(("se_ard", [math.log(0.6)] * 5, 0.0), x, y, math.log(0.1))
+    assert abs(out[0][0] - ref["mll"]) <= 1e-9 * abs(ref["mll"])
+    assert abs(out[0][0] - out[1][0]) <= 1e-12 * abs(out[1][0])
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=0, atol=1e-10 * np.abs(out[1][1]).max())
+    np.testing.assert_allclose(out[0][2], out[1][2], rtol=1e-12)
+
+
 def test_update_in_256x128_tiles_matches_the_128_kernel_n12000(monkeypatch):
     """Same factorisation through both update kernels at a size where the look-ahead is active: the factor's
     diagonal, alpha and mll agree to rounding; a failing pivot is reported identically."""
