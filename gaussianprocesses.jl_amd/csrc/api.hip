@@ -742,11 +742,10 @@ static int create_one_context(int dev_code, gpmi_ctx** out) {
     // and five TEST HOOKS select the alternative code paths (NB-block substitution instead of the stored super-block inverses,
     // the one-product K^-1, the 256 x 128 update for small launches) at sizes a test can afford — tests/test_gpu_twolevel.py:
     //   GPMI_SUPER_INV=0  GPMI_WHITEN_INV=0  GPMI_WHITEN_SUPER=w  GPMI_GRAD_CHUNK=k  GPMI_UPDATE256_MIN=tiles
-    //   (round 4) GPMI_UPDATE256_RECT=rows  (tall rectangular / batched products take the 256 x 128 kernel from this many rows on)
-    //             GPMI_UPDATE256_ATOMIC=1   (its C tile as no-return atomic adds: measured +0.3 %, off by default)
-    //             GPMI_BLOCKED_U2A=q        (blocked.cpp: the share 1 / q of a step's update that hides the chain and the broadcast)
+    //   (round 4) GPMI_UPDATE256_ATOMIC=1   (update256's C tile as no-return atomic adds: measured +0.3 %, off by default; tested)
     //             GPMI_TEST_COMM_DELAY_US / GPMI_TEST_COMM_DELAY_ON  (dev_hip.hip: latency injected in front of the in-process
     //             communicator's collectives — the overlap measurement of tests/test_gpu_dist.py)
+    //   tools builds only: GPMI_UPDATE256_RECT=rows, GPMI_BLOCKED_U2A=q (blocked.cpp) besides the older ones below
     // Everything else (tile-shape overrides, the phase lock, refinement everywhere, C access width) is bring-up tooling and only
     // exists in a GPMI_TOOLS build (make TOOLS=1).
     if (const char* e = getenv("GPMI_SUPER")) {  // "min512,min1024,min2048" (remaining rows from which each width is used)
@@ -757,12 +756,13 @@ static int create_one_context(int dev_code, gpmi_ctx** out) {
     if (const char* e = getenv("GPMI_UPDATE256")) c->update256 = atoi(e) != 0;
     if (const char* e = getenv("GPMI_UPDATE256_MIN")) c->update256_min_tiles = std::max<long long>(1, atoll(e));
     if (const char* e = getenv("GPMI_UPDATE256_ATOMIC")) c->update256_atomic = atoi(e) != 0;
-    if (const char* e = getenv("GPMI_UPDATE256_RECT")) c->update256_rect_min_m = std::max<long long>(1, atoll(e));  // test hook: rows from which tall products take the 256 x 128 kernel
+
     if (const char* e = getenv("GPMI_GRAD_CHUNK")) c->grad_chunk = std::max<long long>(0, atoll(e) / NB * NB);
     if (const char* e = getenv("GPMI_SUPER_INV")) c->super_inverse = atoi(e) != 0;
     if (const char* e = getenv("GPMI_WHITEN_INV")) c->whiten_by_super_inverse = atoi(e) != 0;
     if (const char* e = getenv("GPMI_WHITEN_SUPER")) c->whiten_super = std::max<long long>(NB, atoll(e) / NB * NB);
 #ifdef GPMI_TOOLS
+    if (const char* e = getenv("GPMI_UPDATE256_RECT")) c->update256_rect_min_m = std::max<long long>(1, atoll(e));  // rows from which tall products take the 256 x 128 kernel
     if (const char* e = getenv("GPMI_CUMASK_BELOW")) c->whole_cus_below = atoll(e);
     if (const char* e = getenv("GPMI_PHASE_LOCK")) c->phase_lock_min_k = atoll(e);
     if (const char* e = getenv("GPMI_REFINE")) c->refine_default = atoi(e) != 0;

@@ -45,7 +45,9 @@ BlockedGP::BlockedGP(Dev* dev, Comm* comm, int d, int64_t n, BlockedOpts o)
     nown_ = (int)own_.size();
     maxown_ = (int)((nblk_ + G_ - 1) / G_);
     per_ = (o.stripe_blocks <= 0 || o.stripe_blocks >= nown_) ? std::max(nown_, 1) : o.stripe_blocks;
-    if (const char* e = getenv("GPMI_BLOCKED_U2A")) u2a_div_ = std::max(1, atoi(e));  // tuning knob: U2a = 1 / u2a_div_ of the remaining block columns
+#ifdef GPMI_TOOLS  // tuning knob of the bring-up build (make TOOLS=1): U2a = 1 / u2a_div_ of the remaining block columns
+    if (const char* e = getenv("GPMI_BLOCKED_U2A")) u2a_div_ = std::max(1, atoi(e));
+#endif
 }
 
 BlockedGP::~BlockedGP() {
