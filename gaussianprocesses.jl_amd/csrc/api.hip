@@ -315,6 +315,10 @@ static int fit_t(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int
     GPMI_HIP(c, hipMemcpyAsync(gp->ymu, y_minus_mu, (size_t)n * sizeof(T), hipMemcpyHostToDevice, c->stream));
     GPMI_HIP(c, hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
 
+    // (Measured and not kept, GPU call P: cov! split in two launches so that the first diagonal block — the one chain with nothing to hide
+    //  behind — is factored on the side stream under the second: correct, but 701 against 697 ms at N = 50 000 and 70.5 against 68.6 at
+    //  N = 20 000: beside a launch that saturates every CU with short workgroups the chain's single-workgroup kernels crawl, and what was
+    //  3.4 ms alone costs more than it hides.  profiles/r04_p_first_block_under_cov.log)
     launch_cov<T>(c, (const T*)gp->x, n, (const T*)gp->x, n, gp->d, A, ld, npad, npad,
                   COV_LOWER | COV_NUGGET | COV_PAD_IDENTITY, nugget, d_noise);
     GPMI_HIP(c, hipMemcpyAsync(A + npad * ld, gp->ymu, (size_t)npad * sizeof(T), hipMemcpyDeviceToDevice, c->stream));

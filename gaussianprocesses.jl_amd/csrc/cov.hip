@@ -817,8 +817,13 @@ void launch_cov(gpmi_ctx* ctx, const T* xa, int64_t na, const T* xb, int64_t nb,
                 int64_t nrows_total, int64_t ncols_total, int flags, double nugget, const double* nugget_vec,
                 int64_t row_off) {
     // algorithmic bytes: one write per generated entry (lower-triangle tiles only when COV_LOWER)
-    double entries = (flags & COV_LOWER) ? 0.5 * (double)nrows_total * ((double)ncols_total + 1.0)
-                                         : (double)nrows_total * (double)ncols_total;
+    // (rows [row_off, row_off + nrows) of the lower region: row i keeps its first min(i + 1, ncols) columns)
+    double entries = (double)nrows_total * (double)ncols_total;
+    if (flags & COV_LOWER) {
+        const double r0 = (double)row_off, nr = (double)nrows_total, nc = (double)ncols_total;
+        const double tri = std::max(0.0, std::min(nr, nc - r0));  // rows still under the diagonal
+        entries = tri * (r0 + 0.5 * (tri + 1.0)) + (nr - tri) * nc;
+    }
     ProfScope ps(ctx, GPMI_PROF_COV, entries * sizeof(T));
     if (d <= 4)
         launch_cov_t<T, 4>(ctx, xa, na, xb, nb, d, C, ldc, nrows_total, ncols_total, flags, nugget, nugget_vec, row_off);
