@@ -338,22 +338,29 @@ int BlockedGP::fit(const gpmi_kernel* kern, const double* log_noise, int64_t n_n
             }
         }
         dev_->use(DS_UPD);
-        dev_->wait(ev_p_);
         // U1: block column k+1 of every own row below block k
         const bool mine_next = (k + 1) % G_ == rank_;
+        // The next diagonal block FIRST, and from the owner's OWN solved rows (X X' with both operands in the factor: the rows of block
+        // k+1 in panel k are the owner's, solved and copied back by this stream): it does not wait for the panel exchange, so the chain
+        // starts while the gather is still on its way — the exchange is off the chain's critical path altogether.
         // (one rank: only the next diagonal block goes first — the chain needs nothing else — and the rest of block column k+1
         //  is part of the one big update below, as in chol.h; with an exchange to hide, the whole column goes first so that the
         //  next panel can be solved and sent early)
         DevShape rect, lower;
         lower.mode = 1;
-        bool first_piece = true;
         DevEvent ev_diag = nullptr;  // the next diagonal block is current: all the chain waits for (the rest of U1 runs beside it)
-        for (const Piece& pc : pieces(nle, true)) {
+        const std::vector<Piece> below = pieces(nle, true);
+        if (mine_next && !below.empty() && below[0].nb > 0) {
+            const Piece& pc = below[0];
+            dev_->gemm(pc.p + k1 * es_, pc.ld, pc.p + k0 * es_, pc.ld, pc.p + k0 * es_, pc.ld, WD_, WD_, WD_, lower, 0);
+            ev_diag = dev_->record();
+        }
+        dev_->wait(ev_p_);
+        bool first_piece = true;
+        for (const Piece& pc : below) {
             int64_t M = (int64_t)pc.nb * WD_ + (pc.carried ? 1 : 0);
             char* rows = pc.p;
-            if (first_piece && mine_next && pc.nb > 0) {  // the next diagonal block itself: its lower tiles only
-                dev_->gemm(rows + k1 * es_, pc.ld, rows + k0 * es_, pc.ld, panel_rows(k, k + 1), ldP_, WD_, WD_, WD_, lower, 0);
-                ev_diag = dev_->record();
+            if (first_piece && mine_next && pc.nb > 0) {  // the diagonal block went ahead
                 rows += WD_ * pc.ld * es_;
                 M -= WD_;
             }
