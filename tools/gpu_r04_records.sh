@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4 records (what profiles/r04_* was made with): smoke, the default bench line (cpu_baseline + parity + secondary objects with their
 # parity fields), kernel stats + critical path of the bench command, the PMC passes over the bench command (HBM traffic / MFMA busy of the
-# trailing update), timings and instruction counters of the covariance kernels.  The full -m gpu suite is tools/gpu_r04_f.sh.
+# trailing update), timings and instruction counters of the covariance kernels.  The full -m gpu suite is tools/gpu_r04_n.sh.
 mkdir -p gpurun_out; O=gpurun_out
 timeout 300 python __graft_entry__.py smoke 2>&1 | grep -v amdgpu | tail -2 | tee $O/r04_smoke.log
 timeout 1200 python bench.py > $O/r04_bench.json 2> $O/r04_bench.err; echo "bench rc $?"; cut -c1-700 $O/r04_bench.json; tail -3 $O/r04_bench.err | grep -v amdgpu
