@@ -38,6 +38,20 @@ def test_param_roundtrip_and_ordering():
         g.SEArd([0.0, 0.0], 0.0).flat(3)  # wrong number of length scales for d = 3
 
 
+def test_descriptor_has_no_dimension_or_parameter_limit():
+    """round 4: the library sizes its kernel-program tables from the descriptor (include/gpmi.h: only the number of tree nodes is
+    bounded) — the serialiser must not cap d or the parameter count either: d = 300 ARD leaves, a Masked leaf over 150 of them"""
+    d = 300
+    k = g.SEArd([0.01 * i for i in range(d)], 0.2) + g.Masked(g.Mat32Ard([0.1] * 150, 0.0), list(range(0, d, 2)))
+    kd, keep = k.descriptor(d)
+    assert kd.n_ops == 3 and kd.n_params == (d + 1) + (150 + 1) and k.num_params() == kd.n_params
+    ops, dims_off, dims, params = k.flat(d)
+    assert len(dims) == 150 and dims_off[-1] == 150 and len(params) == kd.n_params
+    o = c_oracle.flatten(("sum", ("se_ard", [0.01 * i for i in range(d)], 0.2), ("masked", ("mat32_ard", [0.1] * 150, 0.0), list(range(0, d, 2)))), d)
+    np.testing.assert_allclose(params, o[3], rtol=0, atol=0)
+    del keep
+
+
 def test_shortcut_constructors():
     # test/kernels.jl:184-205
     assert type(g.SE(0.0, 0.0)) is g.SEIso and type(g.SE([0.0, 1.0], 0.0)) is g.SEArd
