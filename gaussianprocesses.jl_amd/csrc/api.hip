@@ -37,7 +37,7 @@ int digest_kernel(const gpmi_kernel* k, int d, std::vector<unsigned char>* buf, 
         return GPMI_EARG;
     }
     if (d <= 0 || d > (1 << 20)) {
-        *err = "input dimension must be positive";
+        *err = "input dimension must be in 1 .. 2^20";
         return GPMI_EARG;
     }
     int64_t nleaf = 0;
@@ -825,7 +825,7 @@ int gpmi_ctx_synchronize(gpmi_ctx* c) {
 int gpmi_gp_create(gpmi_ctx* c, int dtype, int d, int64_t n, const void* x, gpmi_gp** out) {
     if (!c) return earg(c, "gpmi_gp_create: bad argument");
     if (!out || !x || (dtype != 64 && dtype != 32) || d <= 0 || n <= 0) {
-        c->err = "gpmi_gp_create: bad argument (dtype must be 64|32, 1 <= d <= 64, n >= 1)";
+        c->err = "gpmi_gp_create: bad argument (dtype must be 64|32, 1 <= d <= 2^20, n >= 1)";
         return GPMI_EARG;
     }
     *out = nullptr;
@@ -955,6 +955,8 @@ int gpmi_grad(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int64_
             c->err = err.empty() ? "gpmi_grad: dkern_out length differs from the kernel's number of parameters" : err;
             return GPMI_EARG;
         }
+        if (n_kern > GPMI_GRAD_MAX_PARAMS)
+            return earg(c, "gpmi_grad: more than GPMI_GRAD_MAX_PARAMS (5000) kernel hyper-parameters: the trace kernel's per-wave table does not fit the LDS");
     }
     GPMI_HIP(c, hipSetDevice(c->device));
     return gp->dtype == 64 ? grad_t<double>(gp, k, log_noise, dkern_out, dnoise_out)
@@ -1004,6 +1006,37 @@ int gpmi_solve(gpmi_gp* gp, int64_t nrhs, void* b) {
         return rcb;
     }
     return gp->dtype == 64 ? solve_t<double>(gp, nrhs, b, true) : solve_t<float>(gp, nrhs, b, true);
+}
+
+// update_mll!(gp; noise = false, kern = false), src/GPE.jl:203-211 with update_cK! skipped: the factor is kept
+int gpmi_update_alpha(gpmi_gp* gp, const void* y_minus_mu, double* mll_out, void* alpha_out) {
+    int rc = need_fit(gp, "gpmi_update_alpha", true);
+    if (rc) return rc;
+    if (!y_minus_mu) return earg(gp->ctx, "gpmi_update_alpha: bad argument");
+    gpmi_ctx* c = gp->ctx;
+    GPMI_HIP(c, hipSetDevice(c->device));
+    if (gp->group) return group_update_alpha(gp, y_minus_mu, mll_out, alpha_out);
+    if (BlockedGP* bl = blocked_of(gp)) {
+        const int rcb = bl->update_alpha(y_minus_mu, mll_out, alpha_out);
+        if (rcb != GPMI_OK) c->err = bl->error();
+        return rcb;
+    }
+    const size_t es = gp->dtype == 64 ? 8 : 4, bytes = (size_t)gp->n * es;
+    std::vector<char> b(bytes);
+    memcpy(b.data(), y_minus_mu, bytes);
+    rc = gp->dtype == 64 ? solve_t<double>(gp, 1, b.data(), true) : solve_t<float>(gp, 1, b.data(), true);
+    if (rc) return rc;
+    // the device copies gpmi_predict / gpmi_grad read (entries n .. npad stay zero: identity padding)
+    GPMI_HIP(c, hipMemcpy(gp->ymu, y_minus_mu, bytes, hipMemcpyHostToDevice));
+    GPMI_HIP(c, hipMemcpy(gp->alpha, b.data(), bytes, hipMemcpyHostToDevice));
+    double dot = 0.0;
+    for (int64_t i = 0; i < gp->n; ++i)
+        dot += gp->dtype == 64 ? ((const double*)y_minus_mu)[i] * ((const double*)b.data())[i]
+                               : (double)((const float*)y_minus_mu)[i] * (double)((const float*)b.data())[i];
+    gp->mll = -(dot + gp->logdet + 1.8378770664093453 * (double)gp->n) / 2.0;  // GPE.jl:210
+    if (mll_out) *mll_out = gp->mll;
+    if (alpha_out) memcpy(alpha_out, b.data(), bytes);
+    return GPMI_OK;
 }
 
 int gpmi_whiten(gpmi_gp* gp, int64_t nrhs, void* b) {

@@ -15,6 +15,8 @@
 // ("carried") row on every rank: when the loop ends it holds z = L^-1 (y - mu).
 #include "blocked.h"
 
+#include <cstring>
+
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -663,6 +665,26 @@ int BlockedGP::solve(int64_t nrhs, void* b_host, bool backward) {
     return check_dev(backward ? "gpmi_solve" : "gpmi_whiten");
 }
 
+int BlockedGP::update_alpha(const void* ymu_host, double* mll_out, void* alpha_out) {
+    if (!fitted_) return fail(GPMI_EARG, "gpmi_update_alpha: no valid factorisation (call gpmi_fit first)");
+    if (!ymu_host) return fail(GPMI_EARG, "gpmi_update_alpha: bad argument");
+    std::vector<char> b((size_t)(n_ * es_));
+    std::memcpy(b.data(), ymu_host, b.size());
+    const int rc = solve(1, b.data(), true);  // every rank receives the same alpha
+    if (rc) return rc;
+    dev_->begin_call();
+    dev_->use(DS_MAIN);
+    dev_->zero(ymu_, npad_ * es_);
+    dev_->upload(ymu_, ymu_host, n_ * es_);
+    dev_->zero(alpha_, npad_ * es_);
+    dev_->upload(alpha_, b.data(), n_ * es_);
+    const double dot = dev_->dot(ymu_, alpha_, n_);
+    dev_->sync();
+    if (alpha_out) std::memcpy(alpha_out, b.data(), b.size());
+    if (mll_out) *mll_out = -(dot + logdet_ + LOG2PI * (double)n_) / 2.0;  // GPE.jl:210
+    return check_dev("gpmi_update_alpha");
+}
+
 int BlockedGP::inv_diag(void* out_host) {
     if (!fitted_) return fail(GPMI_EARG, "gpmi_inv_diag: no valid factorisation (call gpmi_fit first)");
     comm_rc_ = 0;
@@ -744,6 +766,8 @@ int BlockedGP::grad(const gpmi_kernel* kern, const double* log_noise, int64_t n_
     int n_hyp = 0, rc;
     if ((rc = dev_->set_kernel(kern, d_, &kdiag_, &n_hyp)) != GPMI_OK) return fail(rc, dev_->err);
     if (n_hyp != n_kern) return fail(GPMI_EARG, "gpmi_grad: dkern_out length differs from the kernel's number of parameters");
+    if (n_hyp > GPMI_GRAD_MAX_PARAMS)
+        return fail(GPMI_EARG, "gpmi_grad: more than GPMI_GRAD_MAX_PARAMS (5000) kernel hyper-parameters: the trace kernel's per-wave table does not fit the LDS");
     const int64_t ldG = padded(npad_);
     const int64_t own_rows = (int64_t)std::max(nown_, 1) * WD_;
     if ((rc = grow(&Vb_, &Vb_cap_, WD_ * ldG * es_))) return rc;

@@ -31,6 +31,9 @@ class BlockedGP {
     // AbstractPDMat surface (PDMats `\`, whiten!; GPE.jl:208, GP.jl:27,136, GPE.jl:162).  b: n x nrhs column-major on the host, overwritten
     // with L^-1 b (backward = false) or (K + noise)^-1 b (true); every rank passes the same b and receives the same result
     int solve(int64_t nrhs, void* b_inout_host, bool backward);
+    // update_mll!(noise = false, kern = false), GPE.jl:203-211: alpha = cK \ (y - mu) through the kept factor; replaces the device copies of
+    // alpha and y - mu (predict / grad read them) and returns the mll from the stored logdet
+    int update_alpha(const void* ymu_host, double* mll_out, void* alpha_out);
     int inv_diag(void* out_host);        // diag((K + noise)^-1), n elements (crossvalidation.jl:8-13); needs the gradient's own-rows x N scratch
     int factor_to_host(void* U_out_host);  // n x n column-major upper factor, zeros below (GPE.jl:60); every rank receives all of it
     bool fitted() const { return fitted_; }

@@ -242,6 +242,7 @@ int group_predict(gpmi_gp* gp, const gpmi_kernel* k, int64_t p, const void* xpre
 int group_grad(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int64_t n_noise, double* dkern_out, int n_kern, double* dnoise_out);
 int group_factor_diag(gpmi_gp* gp, void* out);
 int group_solve(gpmi_gp* gp, int64_t nrhs, void* b_inout, bool backward);
+int group_update_alpha(gpmi_gp* gp, const void* ymu, double* mll_out, void* alpha_out);
 int group_inv_diag(gpmi_gp* gp, void* out);
 int group_factor_to_host(gpmi_gp* gp, void* U_out);
 

@@ -127,9 +127,13 @@ struct ScaleW {
 
 // amax (may be null): running maximum of |x| over everything scaled so far, as the bit pattern of a non-negative IEEE number
 // (ordered like the number itself) — the Noise prefilter's scale
+// shift (may be null): ONE point subtracted from every row before scaling — the same point for both blocks of a call.  The reference's
+// distance loops difference the raw inputs (distance.jl:41-106: (x_k - y_k)^2 w_k), whose rounding error is relative to |x - y|; scaling
+// first would make it relative to |x| (inputs with a large common offset — years, timestamps — lose digits in r).  With both blocks
+// centred on a common data point the rounding of (x_k - c_k) is relative to the data's SPREAD, and (x_k - c_k) - (y_k - c_k) = x_k - y_k.
 template <typename T, int DMAX>
 __global__ __launch_bounds__(256) void scale_inputs_kernel(const T* __restrict__ x, int64_t n, int d, ScaleW<DMAX> w, T* __restrict__ out,
-                                                           unsigned long long* __restrict__ amax) {
+                                                           unsigned long long* __restrict__ amax, const T* __restrict__ shift) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     T av = T(0);
     if (i < n * DMAX) {
@@ -137,7 +141,8 @@ __global__ __launch_bounds__(256) void scale_inputs_kernel(const T* __restrict__
         const int k = (int)(i - row * DMAX);
         const T v = k < d ? x[row * d + k] : T(0);
         av = fabs(v);
-        out[i] = (T)((double)v * w.sw[k]);
+        const T c = (shift && k < d) ? shift[k] : T(0);
+        out[i] = (T)((double)(v - c) * w.sw[k]);
     }
     if (amax) {
 #pragma unroll
@@ -774,9 +779,9 @@ void launch_cov_t(gpmi_ctx* ctx, const T* xa, int64_t na, const T* xb, int64_t n
             {
                 if (na > 0)
                     hipLaunchKernelGGL((scale_inputs_kernel<T, DMAX>), dim3((unsigned)((na * DMAX + 255) / 256)), dim3(256), 0, ctx->stream, xa, na, d, sw, xas,
-                                       (unsigned long long*)nullptr);
+                                       (unsigned long long*)nullptr, nb > 0 ? xb : (const T*)nullptr /* both blocks centred on the first point of xb */);
                 hipLaunchKernelGGL((scale_inputs_kernel<T, DMAX>), dim3((unsigned)((nb * DMAX + 255) / 256)), dim3(256), 0, ctx->stream, xb, nb, d, sw, xbs,
-                                   (unsigned long long*)nullptr);
+                                   (unsigned long long*)nullptr, xb);
                 auto go = [&](auto lk) {
                     hipLaunchKernelGGL(lk, grid, dim3(256), 0, ctx->stream, (const T*)xas, na, (const T*)xbs, nb, C, ldc, nrows_total, ncols_total,
                                        ctx->d_prog, flags, row_off, (T)lf.s2, (T)lf.p1);
@@ -794,8 +799,8 @@ void launch_cov_t(gpmi_ctx* ctx, const T* xa, int64_t na, const T* xb, int64_t n
             for (int k = 0; k < DMAX; ++k) one.sw[k] = 1.0;
             (void)hipMemsetAsync(amax, 0, 16, ctx->stream);
             if (na > 0)
-                hipLaunchKernelGGL((scale_inputs_kernel<T, DMAX>), dim3((unsigned)((na * DMAX + 255) / 256)), dim3(256), 0, ctx->stream, xa, na, d, one, xas, amax);
-            hipLaunchKernelGGL((scale_inputs_kernel<T, DMAX>), dim3((unsigned)((nb * DMAX + 255) / 256)), dim3(256), 0, ctx->stream, xb, nb, d, one, xbs, amax);
+                hipLaunchKernelGGL((scale_inputs_kernel<T, DMAX>), dim3((unsigned)((na * DMAX + 255) / 256)), dim3(256), 0, ctx->stream, xa, na, d, one, xas, amax, (const T*)nullptr);
+            hipLaunchKernelGGL((scale_inputs_kernel<T, DMAX>), dim3((unsigned)((nb * DMAX + 255) / 256)), dim3(256), 0, ctx->stream, xb, nb, d, one, xbs, amax, (const T*)nullptr);
             auto go = [&](auto mk) {
                 hipLaunchKernelGGL(mk, grid, dim3(256), 0, ctx->stream, (const T*)xas, na, (const T*)xbs, nb, C, ldc, nrows_total, ncols_total, ctx->d_prog,
                                    flags, row_off, (const unsigned long long*)amax);

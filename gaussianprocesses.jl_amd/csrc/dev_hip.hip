@@ -95,7 +95,7 @@ __global__ __launch_bounds__(1024) void qtrace_kernel(const T* __restrict__ Wt, 
     }
     if (threadIdx.x == 0) trace_acc[0] += sh[0];
 }
-// host scalar all-reduces carry at most this many doubles (the gradient sends n_hyp + 1 <= GRAD_MAX_HYP + 1)
+// host scalar all-reduces carry at most this many doubles (the gradient sends its n_hyp + 1 sums in chunks of 64, blocked.cpp)
 constexpr int HOST_RED_CAP = 256;
 __global__ void acc_add_kernel(double* __restrict__ out, const double* __restrict__ add, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] += add[i];
@@ -428,6 +428,9 @@ struct LocalGroup {
     std::vector<const void*> ptr[2];
     std::vector<hipEvent_t> ready[2], done[2];
     std::vector<double> hv[2];
+    // test hook (see LocalComm::inject_delay): read ONCE per API call by the calling thread (group_run), never by the worker threads
+    long long delay_us = 0;
+    int delay_on = 3;
     bool barrier() {  // false: the group was aborted (a member failed outside a collective)
         std::unique_lock<std::mutex> lk(mu);
         if (aborted) return false;
@@ -523,17 +526,15 @@ struct LocalComm : Comm {
                 if (hipStreamWaitEvent(s, g->done[par][q], 0) != hipSuccess) return 1;
         return 0;
     }
-    // GPMI_TEST_COMM_DELAY_US (read per call, so a test can change it between fits): extra latency in front of every inverse broadcast and
-    // every panel exchange (its per-group gathers are one exchange: the delay goes in front of the first) — how tests measure what the
-    // look-ahead pipeline of blocked.cpp really hides
+    // GPMI_TEST_COMM_DELAY_US / _ON (read once per API call by the calling thread — group_run —, so a test can change them between
+    // fits and no worker thread ever calls getenv): extra latency in front of every inverse broadcast and every panel exchange (its
+    // per-group gathers are one exchange: the delay goes in front of the first) — how tests measure what the look-ahead pipeline of
+    // blocked.cpp really hides.  Only the in-process communicator of a device group has the hook.
     long long delayed = 0;
     bool in_group = false, group_delayed = false;
     void inject_delay(void* stream, int what /* 1 broadcast, 2 panel exchange */) {
-        const char* e = getenv("GPMI_TEST_COMM_DELAY_US");
-        const long long us = e ? atoll(e) : 0;
-        if (us <= 0) return;
-        const char* on = getenv("GPMI_TEST_COMM_DELAY_ON");  // 1: broadcasts only, 2: panel exchanges only, default both
-        if (on && !(atoi(on) & what)) return;
+        const long long us = g->delay_us;
+        if (us <= 0 || !(g->delay_on & what)) return;
         hipLaunchKernelGGL(comm_delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, us * 100);
         ++delayed;
     }
@@ -659,6 +660,12 @@ template <typename F>
 static int group_run(GroupHandle* h, F f) {
     LocalGroup* g = h->g;
     g->reset();
+    {   // the injected-latency test hook, sampled here on the caller's thread (not per collective, not on worker threads)
+        const char* e = getenv("GPMI_TEST_COMM_DELAY_US");
+        g->delay_us = e ? atoll(e) : 0;
+        const char* on = g->delay_us > 0 ? getenv("GPMI_TEST_COMM_DELAY_ON") : nullptr;  // 1: broadcasts only, 2: panel exchanges only, default both
+        g->delay_on = on ? atoi(on) : 3;
+    }
     // a member that left the previous call early (EDEVICE / EARG -> abort) has issued fewer collectives than the others: every
     // call starts from the same slot parity again (all streams were drained when the previous call returned)
     for (auto& cm : h->comms) cm->seq = 0;
@@ -777,6 +784,13 @@ int group_solve(gpmi_gp* gp, int64_t nrhs, void* b, bool backward) {
     std::vector<std::vector<char>> tmp((size_t)h->g->n);
     for (int r = 1; r < h->g->n; ++r) tmp[(size_t)r].assign((const char*)b, (const char*)b + bytes);
     return group_run(h, [&](int r) { return h->ranks[(size_t)r]->gp->solve(nrhs, r == 0 ? b : (void*)tmp[(size_t)r].data(), backward); });
+}
+int group_update_alpha(gpmi_gp* gp, const void* ymu, double* mll_out, void* alpha_out) {
+    GroupHandle* h = (GroupHandle*)gp->group;
+    std::vector<double> mll((size_t)h->g->n, 0.0);
+    const int rc = group_run(h, [&](int r) { return h->ranks[(size_t)r]->gp->update_alpha(ymu, &mll[(size_t)r], r == 0 ? alpha_out : nullptr); });
+    if (mll_out) *mll_out = mll[0];
+    return rc;
 }
 int group_inv_diag(gpmi_gp* gp, void* out) {
     GroupHandle* h = (GroupHandle*)gp->group;
@@ -933,7 +947,7 @@ int gpmi_gp_create_blocked(gpmi_ctx* c, gpmi_comm* comm, int dtype, int d, int64
                            gpmi_gp** out) {
     if (!c) return GPMI_EARG;
     if (!out || !x || (dtype != 64 && dtype != 32) || d <= 0 || n <= 0 || block_rows < 0 || stripe_blocks < 0) {
-        c->err = "gpmi_gp_create_blocked: bad argument (dtype must be 64|32, 1 <= d <= 64, n >= 1)";
+        c->err = "gpmi_gp_create_blocked: bad argument (dtype must be 64|32, 1 <= d <= 2^20, n >= 1)";
         return GPMI_EARG;
     }
     *out = nullptr;

@@ -511,6 +511,10 @@ int fitc_grad_t(gpmi_fitc* f, const gpmi_kernel* k, double log_noise, double* dk
         c->err = "gpmi_fitc_grad: n_kern does not match the kernel's number of hyper-parameters";
         return GPMI_EARG;
     }
+    if (n_hyp > GPMI_GRAD_MAX_PARAMS) {
+        c->err = "gpmi_fitc_grad: more than GPMI_GRAD_MAX_PARAMS (5000) kernel hyper-parameters: the trace kernel's per-wave table does not fit the LDS";
+        return GPMI_EARG;
+    }
     // The per-point term sum_i q_i dk(x_i, x_i)/dtheta of fully_indep_train_conditional.jl:218 is evaluated as
     // (sum_i q_i) * dk/dtheta at r = 0: valid because every leaf of include/gpmi.h is STATIONARY (k(x, x) does not depend
     // on x).  A non-stationary leaf (Lin, Poly, ...) added to gpmi_op must be weighted per point here: refuse it until then.
@@ -623,7 +627,7 @@ int gpmi_fitc_create(gpmi_ctx* c, int dtype, int d, int64_t n, const void* x, in
     using namespace gpmi;
     if (!c) return GPMI_EARG;
     if (!out || !x || !xu || (dtype != 64 && dtype != 32) || d <= 0 || n <= 0 || m <= 0) {
-        c->err = "gpmi_fitc_create: bad argument (dtype must be 64|32, 1 <= d <= 64, n >= 1, m >= 1)";
+        c->err = "gpmi_fitc_create: bad argument (dtype must be 64|32, 1 <= d <= 2^20, n >= 1, m >= 1)";
         return GPMI_EARG;
     }
     *out = nullptr;

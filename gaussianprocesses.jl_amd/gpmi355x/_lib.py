@@ -25,7 +25,7 @@ SYMBOLS = [
     "gpmi_solve", "gpmi_whiten", "gpmi_logdet", "gpmi_factor_to_host", "gpmi_factor_diag",
     "gpmi_profile_enable", "gpmi_profile_get", "gpmi_profile_get_bytes", "gpmi_mfma_peak", "gpmi_bench_gemm",
     "gpmi_comm_create_callbacks", "gpmi_comm_unique_id", "gpmi_comm_create_rccl", "gpmi_comm_destroy", "gpmi_comm_selftest", "gpmi_gp_create_blocked",
-    "gpmi_gp_blocked_info",
+    "gpmi_gp_blocked_info", "gpmi_update_alpha",
 ]
 
 
@@ -106,6 +106,7 @@ def load():
     lib.gpmi_gp_destroy.argtypes = [vp]
     lib.gpmi_gp_destroy.restype = None
     lib.gpmi_fit.argtypes = [vp, C.POINTER(GpmiKernel), C.POINTER(dbl), i64, vp, C.POINTER(dbl), vp, C.POINTER(i64)]
+    lib.gpmi_update_alpha.argtypes = [vp, vp, C.POINTER(dbl), vp]
     lib.gpmi_predict.argtypes = [vp, C.POINTER(GpmiKernel), i64, vp, vp, C.c_int, vp, vp]
     lib.gpmi_cov.argtypes = [vp, C.POINTER(GpmiKernel), C.c_int, C.c_int, i64, vp, i64, vp, vp]
     lib.gpmi_fitc_create.argtypes = [vp, C.c_int, C.c_int, i64, vp, i64, vp, C.POINTER(vp)]

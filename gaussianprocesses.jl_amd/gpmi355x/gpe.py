@@ -146,10 +146,13 @@ class GPE:
         mu = self.mean.mean(self.x)
         ymu = np.ascontiguousarray(self.y - mu, dtype=dt)
         if not (kern or noise) and self.alpha is not None:
-            # GPE.jl:203-211: only the mean changed — the factor is kept: alpha = cK \ (y - mu), mll from the stored logdet
-            self.alpha = self.cK.solve(ymu)
-            self.mll = -0.5 * (float(np.dot(np.asarray(ymu, dtype=np.float64), np.asarray(self.alpha, dtype=np.float64))) + self.cK.logdet()
-                               + self.nobs * 1.8378770664093453)
+            # GPE.jl:203-211: only the mean changed — the factor is kept: alpha = cK \ (y - mu), mll from the stored logdet.  The device copy
+            # of alpha (what predict_f and update_dmll read) is replaced by the same call.
+            alpha = np.empty(self.nobs, dtype=dt)
+            mll = C.c_double()
+            self.ctx.check(_lib.load().gpmi_update_alpha(self.cK.h, ymu.ctypes.data, C.byref(mll), alpha.ctypes.data))
+            self.alpha = alpha
+            self.mll = mll.value
             return self
         ln = np.atleast_1d(np.asarray(self.logNoise, dtype=np.float64))
         if ln.shape[0] not in (1, self.nobs):

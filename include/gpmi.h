@@ -126,6 +126,12 @@ GPMI_API void gpmi_gp_destroy(gpmi_gp*);
 GPMI_API int gpmi_fit(gpmi_gp*, const gpmi_kernel*, const double* log_noise, int64_t n_noise,
              const void* y_minus_mu, double* mll_out, void* alpha_out, int64_t* info_out);
 
+/* ---- update_mll!(gp; noise = false, kern = false): only the mean changed (src/GPE.jl:203-211 with update_cK! skipped) ----
+ * The factor of the last gpmi_fit is KEPT:  alpha = cK \ (y - mu)  through it,  mll = -(y'alpha + logdet + n log 2pi)/2  from the
+ * stored logdet.  The DEVICE copy of alpha (what gpmi_predict and gpmi_grad read) is replaced too, on dense, blocked and
+ * device-group handles alike (every rank of a sharded model passes the same y_minus_mu).  alpha_out: n elements, may be NULL.  */
+GPMI_API int gpmi_update_alpha(gpmi_gp*, const void* y_minus_mu, double* mll_out, void* alpha_out);
+
 /* ---- predict: replaces predict_f / predictMVN (src/GP.jl:25-84) ----------
  * xpred: d x p col-major.  mean_pred: mean(m, xpred), p elements.
  * full_cov == 0: var_out[p] = max(k(x*,x*) - |L^-1 k*|^2, 0)   (GP.jl:69-77, batched)
@@ -141,8 +147,10 @@ GPMI_API int gpmi_predict(gpmi_gp*, const gpmi_kernel*, int64_t p, const void* x
  *   dnoise_out   = exp(2 logNoise) tr(alpha alpha' - K^-1)             (dmll_noise, GPE.jl:273-275; may be NULL)
  * The mean part, dot(grad_mean, alpha) (GPE.jl:282-288), is O(N d) host work on alpha.
  * n_kern must equal the kernel's parameter count.  Allocates two more n x n device buffers on
- * first use.  No limit on d or on the number of parameters (beyond d = 32 / 64 parameters a slower,
- * limit-free form of the trace kernel runs; cov! reads its operands from global memory beyond d = 64). */
+ * first use.  No limit on d (up to 2^20; cov! reads its operands from global memory beyond d = 64); beyond d = 32 / 64 parameters
+ * a slower form of the trace kernel runs whose per-wave table of (n_kern + 1) x 4 doubles lives in LDS: kernels with more than
+ * GPMI_GRAD_MAX_PARAMS hyper-parameters are refused with GPMI_EARG (also by gpmi_fitc_grad and on blocked handles).          */
+#define GPMI_GRAD_MAX_PARAMS 5000
 GPMI_API int gpmi_grad(gpmi_gp*, const gpmi_kernel*, const double* log_noise, int64_t n_noise, double* dkern_out, int32_t n_kern,
               double* dnoise_out);
 

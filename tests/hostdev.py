@@ -308,6 +308,7 @@ class HostBlockedGP:
         L.hostdev_factor_diag.argtypes = [vp, vp]
         L.hostdev_solve.argtypes = [vp, i64, vp, ci]
         L.hostdev_inv_diag.argtypes = [vp, vp]
+        L.hostdev_update_alpha.argtypes = [vp, vp, pd, vp]
         L.hostdev_factor_to_host.argtypes = [vp, vp]
         L.hostdev_logdet.restype = dbl
         L.hostdev_logdet.argtypes = [vp]
@@ -351,6 +352,16 @@ class HostBlockedGP:
         rc = self.lib.hostdev_fit(self.h, ln.ctypes.data_as(pd), len(ln), ymu.ctypes.data, C.byref(mll), alpha.ctypes.data, C.byref(info))
         self._check(rc, info.value)
         self.mll, self.alpha, self.logdet = mll.value, alpha, self.lib.hostdev_logdet(self.h)
+        return self
+
+    def update_alpha(self, mean_const):
+        """update_mll!(kern = false, noise = false) after a change of the mean (GPE.jl:203-211): the factor is kept"""
+        self.mean_const = mean_const
+        ymu = np.ascontiguousarray(self.y - self.mean_const)
+        mll = dbl()
+        alpha = np.empty(self.n)
+        self._check(self.lib.hostdev_update_alpha(self.h, ymu.ctypes.data, C.byref(mll), alpha.ctypes.data))
+        self.mll, self.alpha = mll.value, alpha
         return self
 
     def predict_f(self, xs, full_cov=False):

@@ -171,6 +171,7 @@ int hostdev_grad(void* p, const double* log_noise, int64_t n_noise, double* dker
 }
 int hostdev_factor_diag(void* p, double* out) { return ((HostGP*)p)->gp->factor_diag(out); }
 int hostdev_solve(void* p, int64_t nrhs, double* b, int backward) { return ((HostGP*)p)->gp->solve(nrhs, b, backward != 0); }
+int hostdev_update_alpha(void* p, const double* ymu, double* mll, double* alpha) { return ((HostGP*)p)->gp->update_alpha(ymu, mll, alpha); }
 int hostdev_inv_diag(void* p, double* out) { return ((HostGP*)p)->gp->inv_diag(out); }
 int hostdev_factor_to_host(void* p, double* U) { return ((HostGP*)p)->gp->factor_to_host(U); }
 double hostdev_logdet(void* p) { return ((HostGP*)p)->gp->logdet(); }

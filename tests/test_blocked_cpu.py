@@ -58,6 +58,26 @@ def _check_all(gp, x, y, xs, spec=SPEC, ln=LN, grad=True):
         np.testing.assert_allclose(gp.dkern, d["dkern"], rtol=1e-8, atol=1e-9 * np.abs(d["dkern"]).max())
         assert abs(gp.dnoise - d["dnoise"]) <= 1e-8 * abs(d["dnoise"])
         _check_pdmat(gp, ref, y)
+        _check_mean_only_update(gp, x, y, xs, spec, ln)
+
+
+def _check_mean_only_update(gp, x, y, xs, spec, ln):
+    """ update_mll!(kern = false, noise = false) after a change of the mean keeps the factor but must replace the DEVICE alpha too:
+    predict_f and update_dmll! read it.  Compared with a full oracle fit at the new mean, then the old mean is restored."""
+    m2 = ("const", 0.55)
+    gp.update_alpha(m2[1])
+    ref2 = G.update_mll(spec, x, y, ln, m2)
+    assert abs(gp.mll - ref2["mll"]) <= 1e-10 * abs(ref2["mll"]), (gp.mll, ref2["mll"])
+    np.testing.assert_allclose(gp.alpha, ref2["alpha"], rtol=1e-7, atol=1e-9)
+    mu, s2 = gp.predict_f(xs)
+    mu_o, s2_o = G.predict_f(spec, x, ref2, xs, m2)
+    np.testing.assert_allclose(mu, mu_o, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(s2, s2_o, rtol=1e-6, atol=1e-10)
+    gp.update_dmll()
+    d2 = G.update_dmll(spec, x, y, ln, m2, fit=ref2)
+    np.testing.assert_allclose(gp.dkern, d2["dkern"], rtol=1e-8, atol=1e-9 * np.abs(d2["dkern"]).max())
+    assert abs(gp.dnoise - d2["dnoise"]) <= 1e-8 * abs(d2["dnoise"])
+    gp.update_alpha(MEAN[1])
 
 
 def _check_pdmat(gp, ref, y):

@@ -61,6 +61,22 @@ def test_cov_fp32(spec):
     _close(K, G.cov(spec, X32.astype(np.float64), X232.astype(np.float64)), 2e-4, 2e-6, "cov fp32")
 
 
+@pytest.mark.parametrize("spec", [LEAVES[1], LEAVES[4], LEAVES[7], LEAVES[9], COMPOSITES[2]], ids=["se_ard", "mat32_iso", "mat52_ard", "rq_ard", "sum+noise"])
+def test_cov_offset_inputs(spec):
+    """ inputs with a large common offset (years, timestamps): the reference differences the RAW inputs (distance.jl:41-106), so
+    its rounding error is relative to |x - y|; the single-leaf interior-tile kernel works on pre-scaled copies and must not make it relative to
+    |x| — both blocks are centred on a common data point before scaling.  n large enough for interior tiles (64 x 128 / 64 x 256)."""
+    X, X2 = _data(700, 450)
+    X6, X26 = X + 1e6, X2 + 1e6
+    k = g.from_spec(spec)
+    _close(g.cov(k, X6, X26), G.cov(spec, X6, X26), 1e-11, 1e-13, "cov(k, X + 1e6, X2 + 1e6)")
+    _close(g.cov(k, X6), G.cov(spec, X6), 1e-11, 1e-13, "cov(k, X + 1e6)")
+    X3 = (X + 1e3).astype(np.float32)
+    X23 = (X2 + 1e3).astype(np.float32)
+    K32 = g.cov(k, X3, X23, dtype="float32")
+    _close(K32, G.cov(spec, X3.astype(np.float64), X23.astype(np.float64)), 2e-4, 2e-6, "cov fp32 (X + 1e3)")
+
+
 @pytest.mark.parametrize("d", [1, 2, 5, 8, 13, 16, 20, 40])
 def test_cov_dimension_sweep(d):
     """d <= 16 takes the register-resident path, larger d the LDS-streaming path."""
@@ -164,6 +180,43 @@ def test_means_and_refit_after_param_change():
     ref2 = G.update_mll(spec2, x, y, -0.9, ("lin", [1.1, -1.9, 0.6]))
     assert gp.mll == pytest.approx(ref2["mll"], rel=1e-10)
     assert gp.target == gp.mll
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["fp64", "fp32"])
+def test_mean_only_update_replaces_the_device_alpha(dtype):
+    """ update_mll!(gp; kern = false, noise = false) after a change of the mean (GPE.jl:203-211 with update_cK! skipped) keeps
+    the factor; predict_f and update_dmll! read the DEVICE copy of alpha, which gpmi_update_alpha must replace: compared with a full
+    oracle fit at the new mean, then with the device's own full refit."""
+    rng = np.random.default_rng(21)
+    n = 900
+    x = rng.uniform(size=(3, n))
+    y = 2.0 + x.T @ np.array([1.0, -2.0, 0.5]) + 0.1 * rng.standard_normal(n)
+    xs = rng.uniform(size=(3, 40))
+    spec = ("sum", ("se_ard", [0.1, 0.0, -0.1], 0.3), ("mat52_iso", -0.2, -0.3))
+    gp = g.GP(x, y, g.MeanLin([1.0, -2.0, 0.5]), g.from_spec(spec), -1.0, dtype=dtype)
+    b2 = [0.6, -1.5, 0.9]
+    gp.mean.set_params(b2)
+    gp.update_mll(kern=False, noise=False)
+    x64 = np.asarray(gp.x, dtype=np.float64)
+    ref = G.update_mll(spec, x64, y, -1.0, ("lin", b2))
+    tol = 1e-10 if dtype == np.float64 else 1e-2
+    assert gp.mll == pytest.approx(ref["mll"], rel=tol)
+    ra, aa = (1e-7, 1e-8) if dtype == np.float64 else (2e-2, 2e-2)
+    _close(gp.alpha, ref["alpha"], ra, aa * np.abs(ref["alpha"]).max(), "alpha after the mean-only update")
+    mu, s2 = gp.predict_f(xs)
+    mu_o, s2_o = G.predict_f(spec, x64, ref, np.asarray(xs, dtype=dtype).astype(np.float64), ("lin", b2))
+    rm = 1e-7 if dtype == np.float64 else 1e-2
+    _close(mu, mu_o, rm, rm, "predict_f mean after the mean-only update")
+    gp.update_dmll()
+    d1 = np.array(gp.dmll)
+    if dtype == np.float64:
+        d_o = G.update_dmll(spec, x64, y, -1.0, ("lin", b2), fit=ref)["dmll"]
+        _close(d1, d_o, 1e-6, 1e-8 * np.abs(d_o).max(), "update_dmll after the mean-only update")
+    gp.update_mll()  # the full refit must agree with the shortcut
+    mu_r, _ = gp.predict_f(xs)
+    gp.update_dmll()
+    _close(mu, mu_r, rm, rm, "shortcut vs refit: predict_f")
+    _close(d1, gp.dmll, 1e-6 if dtype == np.float64 else 5e-2, (1e-8 if dtype == np.float64 else 5e-2) * np.abs(gp.dmll).max(), "shortcut vs refit: dmll")
 
 
 def test_heteroscedastic_noise():
