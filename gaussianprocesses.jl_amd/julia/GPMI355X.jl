@@ -4,24 +4,29 @@
 # STATUS: written against include/gpmi.h, NOT executed — the build container has no Julia
 # (SURVEY.md header).  The same ABI is exercised end-to-end by the Python/ctypes host mirror
 # (gaussianprocesses.jl_amd/gpmi355x) and the GPU parity tests, so this file only has to be a
-# thin, reviewable marshaling layer.  It plugs in exactly where the reference's own alternative
-# strategies do (SoR/DTC/FITC/FSA: src/sparse/subsetofregressors.jl:82-113,302-327):
+# thin, reviewable marshaling layer.  Because it has never been parsed, every method below was
+# audited by eye against the reference methods of the same name it competes with in dispatch
+# (INTEGRATION.md "Dispatch audit": ambiguity, keyword and type-parameter mismatches); the test
+# a maintainer runs on day one is julia/runtests.jl.
+# It plugs in exactly where the reference's own alternative strategies do (SoR/DTC/FITC/FSA: src/sparse/subsetofregressors.jl:82-113,302-327):
 #   * a CovarianceStrategy subtype selected through the 6-argument GPE constructor (src/GPE.jl:68-71)
 #   * an AbstractPDMat subtype returned by alloc_cK (src/GP.jl:14-20)
 #   * methods for update_cK!, \, logdet, whiten!, predictMVN, predict_f (src/GPE.jl:169-212, src/GP.jl:25-84)
 module GPMI355X
 
 using GaussianProcesses
-using GaussianProcesses: GPE, GPBase, Kernel, Mean, KernelData, EmptyData, CovarianceStrategy,
+using GaussianProcesses: GPE, GPBase, Kernel, Mean, EmptyData, CovarianceStrategy,
     SEIso, SEArd, Mat12Iso, Mat12Ard, Mat32Iso, Mat32Ard, Mat52Iso, Mat52Ard, RQIso, RQArd,
-    Noise, Const, SumKernel, ProdKernel, Masked, FixedKernel, get_value, log2π
-import GaussianProcesses: alloc_cK, update_cK!, update_mll!, grad_stack, num_params, get_alpha_u, predictMVN, predict_f, mat, cholfactors, wrap_cK,
-    init_precompute, precompute!, dmll_kern!, dmll_noise, AbstractGradientPrecompute
+    Noise, Const, SumKernel, ProdKernel, Masked, FixedKernel, get_value, AbstractGradientPrecompute, SparseStrategy, SparsePDMat
+import GaussianProcesses: alloc_cK, update_cK!, update_mll!, num_params, get_alpha_u, predictMVN, predict_f, mat, cholfactors,
+    init_precompute, precompute!, dmll_kern!, dmll_noise, predict_LOO, KernelData
+using Statistics: mean                 # GaussianProcesses extends Statistics.mean for mean(m::Mean, X)  (src/GaussianProcesses.jl:8)
 using PDMats
 import PDMats: dim, whiten!, whiten, unwhiten!
 using LinearAlgebra
 import LinearAlgebra: logdet, \, ldiv!, tr
 
+const LOG2PI = log(2π)                 # StatsFuns.log2π inside the reference (src/GPE.jl:210)
 const libgpmi = get(ENV, "LIBGPMI", "libgpmi.so")
 
 # ---- return codes -> Julia exceptions (include/gpmi.h "Conventions") ----------------------
@@ -129,7 +134,9 @@ function rccl_comm(rank::Integer, world::Integer, exchange::Function)
     check(context(), ccall((:gpmi_comm_selftest, libgpmi), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), context(), h[]))   # fail here, not inside a fit
     h[]
 end
-GaussianProcesses.KernelData(k::Kernel, X1::AbstractMatrix, X2::AbstractMatrix, ::HIPCovariance) = EmptyData()
+# (the generic method for ::CovarianceStrategy, src/GP.jl:12, already returns EmptyData(); spelled out so that the "nothing N x N is
+#  cached" decision is visible here)
+KernelData(k::Kernel, X1::AbstractMatrix, X2::AbstractMatrix, ::HIPCovariance) = EmptyData()
 
 mutable struct HIPPDMat <: AbstractPDMat{Float64}
     handle::Ptr{Cvoid}   # gpmi_gp*
@@ -146,6 +153,11 @@ mutable struct HIPPDMat <: AbstractPDMat{Float64}
 end
 alloc_cK(s::HIPCovariance, nobs) = HIPPDMat(nobs, s)                  # replaces src/GP.jl:14-20
 Base.size(a::HIPPDMat) = (a.n, a.n); Base.size(a::HIPPDMat, i::Int) = a.n; dim(a::HIPPDMat) = a.n
+# an AbstractPDMat is an AbstractMatrix: without these the REPL's display of a gp (or of gp.cK) would walk getindex over a matrix
+# that lives on the device
+Base.show(io::IO, a::HIPPDMat) = print(io, "HIPPDMat(", a.n, " x ", a.n, a.handle == C_NULL ? ", no device handle yet)" : ", factor resident on the device)")
+Base.show(io::IO, ::MIME"text/plain", a::HIPPDMat) = show(io, a)
+Base.getindex(a::HIPPDMat, i::Int, j::Int) = error("HIPPDMat: elementwise access is not supported (the matrix is never resident); use Matrix(a) / cholfactors(a)")
 
 # The handle is keyed on the IDENTITY of the caller's x (gp.x, whatever its array type): the dense Float64 copy the C ABI
 # needs is made only when x actually has to be uploaded, so repeated update_cK! / update_mll! calls with the same gp.x
@@ -174,7 +186,9 @@ function ensure_handle!(a::HIPPDMat, x::AbstractMatrix)
     a
 end
 
-function fit!(a::HIPPDMat, x, kernel, logNoise, ymμ::Vector{Float64}, alpha::Union{Vector{Float64},Nothing})
+# (not called fit!: GaussianProcesses exports its own fit!(gp, x, y), src/GPE.jl:128, and a second function of that name in this module
+#  would shadow or — once the exported one has been referenced — refuse to be defined)
+function device_fit!(a::HIPPDMat, x, kernel, logNoise, ymμ::Vector{Float64}, alpha::Union{Vector{Float64},Nothing})
     ensure_handle!(a, x)
     ln = logNoise isa Real ? Float64[logNoise] : Vector{Float64}(logNoise)
     mll = Ref{Float64}(NaN); info = Ref{Int64}(0)
@@ -187,22 +201,34 @@ function fit!(a::HIPPDMat, x, kernel, logNoise, ymμ::Vector{Float64}, alpha::Un
     mll[]
 end
 
-# update_cK! alone (src/GPE.jl:169-195; callers: GPA with logNoise = -20, ElasticGPE): factor only
-function update_cK!(cK::HIPPDMat, x::AbstractMatrix, kernel::Kernel, logNoise, data::KernelData, ::HIPCovariance)
-    fit!(cK, x, kernel, logNoise, zeros(size(x, 2)), nothing)
+# update_cK! alone (src/GPE.jl:169-195; callers: update_cK!(gp) :193-195, GPA with logNoise = -20, ElasticGPE): factor only.
+# TWO methods typed like the reference's two (logNoise::Real :169, ::AbstractVector :177): an untyped logNoise would be ambiguous with both
+# (neither signature more specific), and update_cK!(gp) would throw a MethodError.
+function update_cK!(cK::HIPPDMat, x::AbstractMatrix, kernel::Kernel, logNoise::Real, data::KernelData, ::HIPCovariance)
+    device_fit!(cK, x, kernel, logNoise, zeros(size(x, 2)), nothing)
+    cK
+end
+function update_cK!(cK::HIPPDMat, x::AbstractMatrix, kernel::Kernel, logNoise::AbstractVector, data::KernelData, ::HIPCovariance)
+    device_fit!(cK, x, kernel, logNoise, zeros(size(x, 2)), nothing)
     cK
 end
 
-# update_mll! (src/GPE.jl:202-212) fused: cov! + nugget + Cholesky + alpha + logdet + mll in one device pass
+# update_mll! (src/GPE.jl:202-212) fused: cov! + nugget + Cholesky + alpha + logdet + mll in one device pass.
+# gp.alpha is #undef when the inner constructor's initialise_target! makes the first call (src/GPE.jl:42-44 leaves the fields after cK
+# unassigned; the reference's own update_mll! only ever ASSIGNS gp.alpha), so it is tested with isdefined before it is read.
 function update_mll!(gp::GPE{X,Y,M,K,HIPCovariance}; noise::Bool=true, domean::Bool=true, kern::Bool=true) where {X,Y,M,K}
     μ = mean(gp.mean, gp.x)
     ymμ = Vector{Float64}(gp.y - μ)
+    (isdefined(gp, :alpha) && length(gp.alpha) == gp.nobs) || (gp.alpha = Vector{Float64}(undef, gp.nobs))
     if kern | noise
-        length(gp.alpha) == gp.nobs || (gp.alpha = Vector{Float64}(undef, gp.nobs))
-        gp.mll = fit!(gp.cK, gp.x, gp.kernel, get_value(gp.logNoise), ymμ, gp.alpha)
+        gp.mll = device_fit!(gp.cK, gp.x, gp.kernel, get_value(gp.logNoise), ymμ, gp.alpha)
     else
-        gp.alpha = gp.cK \ ymμ
-        gp.mll = -(dot(ymμ, gp.alpha) + logdet(gp.cK) + log2π * gp.nobs) / 2
+        # only the mean changed (src/GPE.jl:203-211 with update_cK! skipped): the factor is kept, alpha = cK \ (y - mu), and the DEVICE copy of
+        # alpha — what gpmi_predict and gpmi_grad read — is replaced by the same call
+        mll = Ref{Float64}(NaN)
+        check(context(), ccall((:gpmi_update_alpha, libgpmi), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ref{Float64}, Ptr{Float64}),
+                               gp.cK.handle, ymμ, mll, gp.alpha))
+        gp.mll = mll[]
     end
     gp
 end
@@ -229,10 +255,15 @@ init_precompute(::HIPCovariance, X, y, k::Kernel) = HIPGradientPrecompute(Vector
 function precompute!(p::HIPGradientPrecompute, gp::GPBase)
     nfull = full_nparams(gp.kernel)
     length(p.dkern) >= max(nfull, 1) || resize!(p.dkern, max(nfull, 1))
-    ln = Float64[get_value(gp.logNoise)]
+    # a heteroscedastic model (VectorParam logNoise) has kernel and mean gradients but no noise gradient — in the reference too
+    # (src/GPE.jl:276-278 is commented out, update_dmll! asserts num_params(gp.logNoise) == 1 when noise = true, :313): the vector is
+    # passed through and the noise output is not requested
+    lnv = get_value(gp.logNoise)
+    ln = lnv isa Real ? Float64[lnv] : Vector{Float64}(lnv)
+    p.dnoise[] = NaN
     rc = withkernel(descriptor(gp.kernel)) do ck
-        ccall((:gpmi_grad, libgpmi), Cint, (Ptr{Cvoid}, Ref{CKernel}, Ptr{Float64}, Int64, Ptr{Float64}, Int32, Ref{Float64}),
-              gp.cK.handle, ck, ln, 1, p.dkern, nfull, p.dnoise)
+        ccall((:gpmi_grad, libgpmi), Cint, (Ptr{Cvoid}, Ref{CKernel}, Ptr{Float64}, Int64, Ptr{Float64}, Int32, Ptr{Float64}),
+              gp.cK.handle, ck, ln, length(ln), p.dkern, nfull, length(ln) == 1 ? p.dnoise : Ptr{Float64}(C_NULL))
     end
     check(context(), rc)
     p
@@ -247,6 +278,7 @@ function \(a::HIPPDMat, b::DenseVecOrMat{Float64})                      # PDMats
     out = copy(b)
     check(context(), ccall((:gpmi_solve, libgpmi), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}), a.handle, size(out, 2), out)); out
 end
+\(a::HIPPDMat, b::AbstractVecOrMat{<:Real}) = a \ Array{Float64}(b)     # views, adjoints, integer right-hand sides
 ldiv!(a::HIPPDMat, b::DenseVecOrMat{Float64}) =
     (check(context(), ccall((:gpmi_solve, libgpmi), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}), a.handle, size(b, 2), b)); b)
 whiten!(a::HIPPDMat, b::DenseVecOrMat{Float64}) =                       # src/GP.jl:27
@@ -261,7 +293,7 @@ function cholfactors(a::HIPPDMat)                                       # src/GP
     check(context(), ccall((:gpmi_factor_to_host, libgpmi), Cint, (Ptr{Cvoid}, Ptr{Float64}), a.handle, U)); U
 end
 # predict_LOO(Σ, alpha, y) (src/crossvalidation.jl:8-13) needs only diag(inv(Σ)): n^3/3 on the device instead of inv(Σ)
-function GaussianProcesses.predict_LOO(a::HIPPDMat, alpha::AbstractVector{<:Real}, y::AbstractVector{<:Real})
+function predict_LOO(a::HIPPDMat, alpha::AbstractVector{<:Real}, y::AbstractVector{<:Real})
     d = Vector{Float64}(undef, a.n)
     check(context(), ccall((:gpmi_inv_diag, libgpmi), Cint, (Ptr{Cvoid}, Ptr{Float64}), a.handle, d))
     σi2 = 1 ./ d
@@ -303,10 +335,10 @@ GP_hip(x::AbstractMatrix, y::AbstractVector, m::Mean, k::Kernel, logNoise=-2.0; 
 # ---- FITC (src/sparse/fully_indep_train_conditional.jl) on the device ------------------------------------
 # HIPFITC plays FullyIndepStrat's role (:111-113); HIPFITCPDMat the FullyIndepPDMat's (:8-19): the n x m matrices,
 # Lambda and both factors stay in HBM (gpmi_fitc_*), only alpha / mll / predictions cross the bus.
-struct HIPFITC{M<:AbstractMatrix} <: GaussianProcesses.SparseStrategy
+struct HIPFITC{M<:AbstractMatrix} <: SparseStrategy
     inducing::M
 end
-mutable struct HIPFITCPDMat <: GaussianProcesses.SparsePDMat{Float64}
+mutable struct HIPFITCPDMat <: SparsePDMat{Float64}
     handle::Ptr{Cvoid}   # gpmi_fitc*
     n::Int
     inducing::Matrix{Float64}
@@ -320,8 +352,12 @@ mutable struct HIPFITCPDMat <: GaussianProcesses.SparsePDMat{Float64}
     end
 end
 alloc_cK(s::HIPFITC, nobs) = HIPFITCPDMat(nobs, s.inducing)             # replaces fully_indep…:118-132
-GaussianProcesses.KernelData(k::Kernel, X1::AbstractMatrix, X2::AbstractMatrix, ::HIPFITC) = EmptyData()
+# more specific than KernelData(k, X1, X2, ::SparseStrategy) (src/sparse/sparsekerneldata.jl:18), which would build three host distance caches
+KernelData(k::Kernel, X1::AbstractMatrix, X2::AbstractMatrix, ::HIPFITC) = EmptyData()
 Base.size(a::HIPFITCPDMat) = (a.n, a.n); Base.size(a::HIPFITCPDMat, i::Int) = a.n; dim(a::HIPFITCPDMat) = a.n
+Base.show(io::IO, a::HIPFITCPDMat) = print(io, "HIPFITCPDMat(n = ", a.n, ", m = ", size(a.inducing, 2), ")")
+Base.show(io::IO, ::MIME"text/plain", a::HIPFITCPDMat) = show(io, a)
+Base.getindex(a::HIPFITCPDMat, i::Int, j::Int) = error("HIPFITCPDMat: elementwise access is not supported (the n x m factors live on the device)")
 function ensure_handle!(a::HIPFITCPDMat, x::AbstractMatrix)
     if a.handle == C_NULL || a.xref !== x || size(x, 2) != a.n || xchecksum(x) != a.xsum
         a.handle == C_NULL || ccall((:gpmi_fitc_destroy, libgpmi), Cvoid, (Ptr{Cvoid},), a.handle)
@@ -336,35 +372,54 @@ function ensure_handle!(a::HIPFITCPDMat, x::AbstractMatrix)
     a
 end
 # update_mll! (src/GPE.jl:202-212) over update_cK!(::FullyIndepPDMat) (:134-156), its `\` (:38-41) and logdet (:80)
-function update_mll!(gp::GPE{X,Y,M,K,<:HIPFITC}; noise::Bool=true, domean::Bool=true, kern::Bool=true) where {X,Y,M,K}
-    ensure_handle!(gp.cK, gp.x)
-    ymμ = Vector{Float64}(gp.y - mean(gp.mean, gp.x))
-    length(gp.alpha) == gp.nobs || (gp.alpha = Vector{Float64}(undef, gp.nobs))
+function fitc_fit!(a::HIPFITCPDMat, x, kernel, logNoise::Real, ymμ::Vector{Float64}, alpha::Union{Vector{Float64},Nothing})
+    ensure_handle!(a, x)
     mll = Ref{Float64}(NaN); info = Ref{Int64}(0)
-    rc = withkernel(descriptor(gp.kernel)) do ck
+    rc = withkernel(descriptor(kernel)) do ck
         ccall((:gpmi_fitc_fit, libgpmi), Cint,
               (Ptr{Cvoid}, Ref{CKernel}, Float64, Ptr{Float64}, Ref{Float64}, Ptr{Float64}, Ref{Int64}),
-              gp.cK.handle, ck, Float64(get_value(gp.logNoise)), ymμ, mll, gp.alpha, info)
+              a.handle, ck, Float64(logNoise), ymμ, mll, alpha === nothing ? Ptr{Float64}(C_NULL) : alpha, info)
     end
-    check(context(), rc, info[]); gp.mll = mll[]; gp
+    check(context(), rc, info[]); mll[]
+end
+function update_mll!(gp::GPE{X,Y,M,K,<:HIPFITC}; noise::Bool=true, domean::Bool=true, kern::Bool=true) where {X,Y,M,K}
+    lnv = get_value(gp.logNoise)
+    lnv isa Real || throw(ArgumentError("HIPFITC takes a scalar logNoise (as FITC(...) does, fully_indep_train_conditional.jl:333)"))
+    ymμ = Vector{Float64}(gp.y - mean(gp.mean, gp.x))
+    (isdefined(gp, :alpha) && length(gp.alpha) == gp.nobs) || (gp.alpha = Vector{Float64}(undef, gp.nobs))
+    gp.mll = fitc_fit!(gp.cK, gp.x, gp.kernel, lnv, ymμ, gp.alpha)   # (a mean-only update refits: 2nm^2, no kept-factor shortcut)
+    gp
+end
+# update_cK!(gp) (src/GPE.jl:193-195) on a FITC model: without this method the call would fall to the exact-path update_cK! (:169), which asks
+# mat(cK) of a matrix that does not exist
+function update_cK!(cK::HIPFITCPDMat, x::AbstractMatrix, kernel::Kernel, logNoise::Real, data::KernelData, ::HIPFITC)
+    fitc_fit!(cK, x, kernel, logNoise, zeros(size(x, 2)), nothing)
+    cK
 end
 # predictMVN(::FullyIndepStrat) (:321-329 -> determ_train_conditional.jl:41-59 -> subsetofregressors.jl:303-321)
-function predict_f(gp::GPE{X,Y,M,K,<:HIPFITC}, x::AbstractMatrix; full_cov::Bool=false) where {X,Y,M,K}
-    size(x, 1) == gp.dim || throw(ArgumentError("Gaussian Process object and input observations do not have consistent dimensions"))
+function fitc_predict(cK::HIPFITCPDMat, kernel::Kernel, meanf::Mean, x::AbstractMatrix, full_cov::Bool)
     xp = Matrix{Float64}(x); P = size(xp, 2)
-    mx = Vector{Float64}(mean(gp.mean, xp)); μ = Vector{Float64}(undef, P)
+    mx = Vector{Float64}(mean(meanf, xp)); μ = Vector{Float64}(undef, P)
     Σ = full_cov ? Matrix{Float64}(undef, P, P) : Vector{Float64}(undef, P)
-    rc = withkernel(descriptor(gp.kernel)) do ck
+    rc = withkernel(descriptor(kernel)) do ck
         ccall((:gpmi_fitc_predict, libgpmi), Cint,
               (Ptr{Cvoid}, Ref{CKernel}, Int64, Ptr{Float64}, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Float64}),
-              gp.cK.handle, ck, P, xp, mx, full_cov ? 1 : 0, μ, Σ)
+              cK.handle, ck, P, xp, mx, full_cov ? 1 : 0, μ, Σ)
     end
     check(context(), rc); μ, Σ
 end
+function predict_f(gp::GPE{X,Y,M,K,<:HIPFITC}, x::AbstractMatrix; full_cov::Bool=false) where {X,Y,M,K}
+    size(x, 1) == gp.dim || throw(ArgumentError("Gaussian Process object and input observations do not have consistent dimensions"))
+    fitc_predict(gp.cK, gp.kernel, gp.mean, x, full_cov)
+end
+# ... and for callers of predict_full (src/GPE.jl:399), which bypasses predict_f: without this method the generic predictMVN (src/GP.jl:39-49)
+# would be chosen and ask whiten! of the device-side factor
+predictMVN(xpred::AbstractMatrix, xtrain::AbstractMatrix, ytrain::AbstractVector, kernel::Kernel, meanf::Mean,
+           alpha::AbstractVector, ::HIPFITC, Ktrain::HIPFITCPDMat) = fitc_predict(Ktrain, kernel, meanf, xpred, true)
 # the same seam for the FITC strategy: precompute! = gpmi_fitc_grad (dmll_kern!(…, ::FullyIndepStrat) fully_indep…:200-234 over
 # subsetofregressors.jl:219-256, dmll_noise :243-257, precompute! subsetofregressors.jl:141-151 — all of it in one device pass)
 init_precompute(::HIPFITC, X, y, k::Kernel) = HIPGradientPrecompute(Vector{Float64}(undef, max(full_nparams(k), 1)), Ref(0.0))
-function precompute!(p::HIPGradientPrecompute, gp::GPE{X,Y,M,K,<:HIPFITC}) where {X,Y,M,K}
+function precompute!(p::HIPGradientPrecompute, gp::GPE{X,Y,M,K,<:HIPFITC}) where {X,Y,M,K}   # more specific than (p, ::GPBase) above
     nfull = full_nparams(gp.kernel)
     length(p.dkern) >= max(nfull, 1) || resize!(p.dkern, max(nfull, 1))
     rc = withkernel(descriptor(gp.kernel)) do ck
