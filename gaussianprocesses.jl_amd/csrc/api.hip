@@ -168,6 +168,7 @@ static hipEvent_t take_event(gpmi_ctx* c) {
 }
 ProfScope::ProfScope(gpmi_ctx* ctx, int cls, double work, double bytes, bool attach_to_launch, bool chain_kernel) : c(ctx), attach(attach_to_launch) {
     if (!c->prof_on || (c->prof_only >= 0 && cls != c->prof_only) || (chain_kernel && c->prof_skip_chain)) return;
+    if (c->prof_phases_only && cls < GPMI_PROF_STEP_U1) return;
     ProfRec r;
     r.a = take_event(c);
     r.b = take_event(c);
@@ -1127,6 +1128,7 @@ int gpmi_profile_enable(gpmi_ctx* c, int on) {
     c->prof_on = on != 0;
     c->prof_only = (on >= 2 && on < 64) ? on - 2 : -1;
     c->prof_skip_chain = on == 64;
+    c->prof_phases_only = on == 65;
     for (int i = 0; i < GPMI_PROF_NCLASS; ++i) {
         c->prof_n[i] = 0;
         c->prof_ms[i] = 0;

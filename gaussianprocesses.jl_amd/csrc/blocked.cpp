@@ -182,7 +182,9 @@ void BlockedGP::bcast_lw(int64_t k, DevEvent after) {
     }
     dev_->use(DS_COMM);
     dev_->wait(after);
+    dev_->phase(GPMI_PROF_STEP_BCAST, true);
     comm_rc_ |= comm_->broadcast(LW_ + k * WD_ * WD_ * es_, WD_ * WD_ * es_, (int)(k % G_), dev_->native_stream());
+    dev_->phase(GPMI_PROF_STEP_BCAST, false);
     ev_lw_ = dev_->record();
 }
 
@@ -197,6 +199,7 @@ void BlockedGP::solve_and_gather(int64_t k, bool from_factor) {
     if (!from_factor) dev_->wait(ev_lw_);
     int64_t srow = 0;
     DevShape rect;
+    if (!from_factor) dev_->phase(GPMI_PROF_STEP_SOLVE, true);
     for (const Piece& pc : pieces(nle, !from_factor)) {
         const int64_t M = (int64_t)pc.nb * WD_ + (pc.carried ? 1 : 0);
         char* X = pc.p + k0 * es_;
@@ -209,6 +212,7 @@ void BlockedGP::solve_and_gather(int64_t k, bool from_factor) {
         }
         srow += M;
     }
+    if (!from_factor) dev_->phase(GPMI_PROF_STEP_SOLVE, false);
     DevEvent ev_sr = dev_->record();
     ev_p_ = ev_sr;
     if (G_ == 1 || k + 1 >= nblk_) return;
@@ -220,6 +224,7 @@ void BlockedGP::solve_and_gather(int64_t k, bool from_factor) {
     // group) or past the end (the last) contributes a block of its send buffer that nobody reads.
     char* P = P_[k & 1];
     const int64_t blk = WD_ * ldP_ * es_;
+    if (!from_factor) dev_->phase(GPMI_PROF_STEP_GATHER, true);
     comm_->group_begin();
     for (int64_t g = (k + 1) / G_; g * G_ < nblk_; ++g) {
         const int64_t b = g * G_ + rank_;  // my block of this group; its local index is g
@@ -227,6 +232,7 @@ void BlockedGP::solve_and_gather(int64_t k, bool from_factor) {
         comm_rc_ |= comm_->all_gather(send, P + g * G_ * blk, blk, dev_->native_stream());
     }
     comm_rc_ |= comm_->group_end();
+    if (!from_factor) dev_->phase(GPMI_PROF_STEP_GATHER, false);
     ev_p_ = dev_->record();
 }
 
@@ -352,6 +358,7 @@ int BlockedGP::fit(const gpmi_kernel* kern, const double* log_noise, int64_t n_n
         lower.mode = 1;
         DevEvent ev_diag = nullptr;  // the next diagonal block is current: all the chain waits for (the rest of U1 runs beside it)
         const std::vector<Piece> below = pieces(nle, true);
+        dev_->phase(GPMI_PROF_STEP_U1, true);
         if (mine_next && !below.empty() && below[0].nb > 0) {
             const Piece& pc = below[0];
             dev_->gemm(pc.p + k1 * es_, pc.ld, pc.p + k0 * es_, pc.ld, pc.p + k0 * es_, pc.ld, WD_, WD_, WD_, lower, 0);
@@ -369,6 +376,7 @@ int BlockedGP::fit(const gpmi_kernel* kern, const double* log_noise, int64_t n_n
             first_piece = false;
             if (G_ > 1 && M > 0) dev_->gemm(rows + k1 * es_, pc.ld, rows + k0 * es_, pc.ld, panel_rows(k, k + 1), ldP_, M, WD_, WD_, rect, 0);
         }
+        dev_->phase(GPMI_PROF_STEP_U1, false);
         DevEvent ev_u1 = dev_->record();
         DevEvent chain = ev_u1;
         if (mine_next) {
@@ -377,8 +385,10 @@ int BlockedGP::fit(const gpmi_kernel* kern, const double* log_noise, int64_t n_n
             char* blk = block_ptr(li, &ld, &width) + k1 * es_;
             dev_->use(DS_SIDE);
             dev_->wait(ev_diag ? ev_diag : ev_u1);
+            dev_->phase(GPMI_PROF_STEP_CHAIN, true);
             dev_->super_factor(blk, ld, WD_, linv_ + (int64_t)li * WD_ * 64 * es_, invd_ + (int64_t)li * WD_ * es_, LW_ + (k + 1) * WD_ * WD_ * es_,
                                k1);
+            dev_->phase(GPMI_PROF_STEP_CHAIN, false);
             chain = dev_->record();
         }
         bcast_lw(k + 1, chain);
@@ -387,13 +397,19 @@ int BlockedGP::fit(const gpmi_kernel* kern, const double* log_noise, int64_t n_n
         const int64_t rest = nblk_ - (k + 2);
         const int64_t m = G_ == 1 ? nblk_ : std::min<int64_t>(nblk_, k + 2 + std::max<int64_t>(rest > 0 ? 1 : 0, (rest + u2a_div_ - 1) / u2a_div_));
         dev_->use(DS_UPD);
+        dev_->phase(GPMI_PROF_STEP_U2A, true);
         if (G_ == 1)
             update_cols(k, k + 1, nblk_, k + 2);  // everything but the next diagonal block, in one launch per stripe
         else
             update_cols(k, k + 2, m, 0);
+        dev_->phase(GPMI_PROF_STEP_U2A, false);
         solve_and_gather(k + 1, false);
         dev_->use(DS_UPD);
-        if (G_ > 1) update_cols(k, m, nblk_, 0);
+        if (G_ > 1) {
+            dev_->phase(GPMI_PROF_STEP_U2B, true);
+            update_cols(k, m, nblk_, 0);
+            dev_->phase(GPMI_PROF_STEP_U2B, false);
+        }
     }
     // join the streams on the main one
     join_on_main();

@@ -160,6 +160,7 @@ struct gpmi_ctx {
     size_t la_next = 0;   // cross-stream dependencies, reused by every factorisation
     bool prof_on = false;
     int prof_only = -1;  // >= 0: bracket the launches of THIS class only (gpmi_profile_enable(ctx, 2 + cls))
+    bool prof_phases_only = false;  // gpmi_profile_enable(ctx, 65): the GPMI_PROF_STEP_* phases of the blocked driver only
     bool prof_skip_chain = false;  // gpmi_profile_enable(ctx, 64): every class, but not the thousands of tiny chain kernels (diag64 / rows64 / rows256)
     hipEvent_t attach_a = nullptr, attach_b = nullptr;  // events the NEXT update-kernel launch carries itself (hipExtLaunchKernelGGL): no
                                                          // marker packets around the persistent kernel (gemm.hip, ProfScope attach mode)

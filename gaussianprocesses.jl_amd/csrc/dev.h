@@ -55,6 +55,9 @@ struct Dev {
     virtual void wait(DevEvent e) = 0;  // the current stream waits for e
     virtual void sync() = 0;         // host waits for every stream; returns after device errors are collected in err
     virtual void* native_stream() = 0;  // the current stream, as the communicator wants it (hipStream_t; nullptr on the host)
+    // measurement: begin / end of phase `cls` (a GPMI_PROF_STEP_* class of include/gpmi.h) on the CURRENT stream — both calls on the same
+    // stream; a back end without timers ignores them
+    virtual void phase(int cls, bool begin) { (void)cls; (void)begin; }
     // ---- kernel program ----
     virtual int set_kernel(const gpmi_kernel* k, int d, double* kdiag, int* n_hyp) = 0;  // GPMI_* status
     // ---- covariance ----

@@ -111,6 +111,17 @@ struct HipDev : Dev {
     ~HipDev() override {
         if (partial) hipFree(partial);
     }
+    ProfScope* open_phase[GPMI_PROF_NCLASS] = {nullptr};
+    void phase(int cls, bool begin) override {  // a marker-event pair on the current stream (gpmi_profile_enable(ctx, 1 | 65))
+        if (cls < GPMI_PROF_STEP_U1 || cls >= GPMI_PROF_NCLASS) return;
+        if (begin) {
+            if (!c->prof_on || open_phase[cls]) return;
+            open_phase[cls] = new ProfScope(c, cls, 0.0);
+        } else if (open_phase[cls]) {
+            delete open_phase[cls];
+            open_phase[cls] = nullptr;
+        }
+    }
     void note(hipError_t e, const char* what) {
         if (e != hipSuccess && err.empty()) err = std::string(what) + ": " + hipGetErrorString(e);
     }

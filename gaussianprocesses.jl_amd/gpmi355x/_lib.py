@@ -16,6 +16,8 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgpmi.so")
 
 GPMI_OK, GPMI_ENOTPD, GPMI_EARG, GPMI_EDEVICE = 0, 1, 2, 3
 PROF_SYRK, PROF_COV, PROF_PANEL, PROF_SOLVE, PROF_PREDICT = range(5)
+# phases of one block step of a blocked / sharded factorisation (include/gpmi.h GPMI_PROF_STEP_*)
+STEP_PHASES = {"U1": 5, "chain": 6, "broadcast": 7, "U2a": 8, "solve": 9, "gather": 10, "U2b": 11}
 
 # every symbol include/gpmi.h declares (tests/test_abi.py checks header == this list == library)
 SYMBOLS = [
@@ -185,10 +187,10 @@ class Context:
         """waits for all work on the context's device(s): the bracket around a timed region"""
         self.check(load().gpmi_ctx_synchronize(self.h))
 
-    def profile_enable(self, on=True, only=None, skip_chain=False):
-        """HIP-event brackets around the profiled launches: every class, one class (only=PROF_SYRK ...), or every class but the
-        thousands of tiny chain kernels (skip_chain)"""
-        code = 0 if not on else ((2 + int(only)) if only is not None else (64 if skip_chain else 1))
+    def profile_enable(self, on=True, only=None, skip_chain=False, phases_only=False):
+        """HIP-event brackets around the profiled launches: every class, one class (only=PROF_SYRK ...), every class but the
+        thousands of tiny chain kernels (skip_chain), or only the per-step phases of a blocked factorisation (phases_only)"""
+        code = 0 if not on else ((2 + int(only)) if only is not None else (65 if phases_only else (64 if skip_chain else 1)))
         self.check(load().gpmi_profile_enable(self.h, code))
 
     def profile_get(self, cls_id):

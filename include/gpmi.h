@@ -251,10 +251,21 @@ enum gpmi_prof_class {
     GPMI_PROF_PANEL = 2, /* potf2 + trsm + in-panel update         */
     GPMI_PROF_SOLVE = 3, /* alpha solves, logdet                   */
     GPMI_PROF_PREDICT = 4,
-    GPMI_PROF_NCLASS = 5
+    /* PHASES of one step of the blocked / sharded factorisation (csrc/blocked.cpp; one event pair per phase and step on the stream
+     * the phase runs on: ~7 pairs per block step).  `launches` counts steps, `total_ms` sums the phase over the steps of the fits
+     * since the last call: what a multi-GPU bench line reports as per-step chain / broadcast / solve / gather / update times.   */
+    GPMI_PROF_STEP_U1 = 5,      /* next diagonal block + block column k+1 (update stream)                                       */
+    GPMI_PROF_STEP_CHAIN = 6,   /* factor + explicit inverse of the next diagonal block (chain stream; its owner only)          */
+    GPMI_PROF_STEP_BCAST = 7,   /* broadcast of that inverse (exchange stream)                                                  */
+    GPMI_PROF_STEP_U2A = 8,     /* the part of the trailing update that hides chain + broadcast                                  */
+    GPMI_PROF_STEP_SOLVE = 9,   /* next panel X LW' + copy back                                                                 */
+    GPMI_PROF_STEP_GATHER = 10, /* all-gather of the solved panel (exchange stream)                                             */
+    GPMI_PROF_STEP_U2B = 11,    /* the rest of the trailing update, which hides the gather                                      */
+    GPMI_PROF_NCLASS = 12
 };
 /* on = 0: off; 1: every class; 2 + cls: the launches of class cls ONLY (a few dozen event pairs per fit for GPMI_PROF_SYRK,
- * against thousands for the panel kernels: what a timing harness leaves on inside its timed region).                       */
+ * against thousands for the panel kernels: what a timing harness leaves on inside its timed region); 64: every class but the
+ * chain's tiny kernels; 65: the GPMI_PROF_STEP_* phases of blocked handles only.                                           */
 GPMI_API int gpmi_profile_enable(gpmi_ctx*, int on);
 /* launches, total milliseconds and algorithmic work (flops for SYRK/PANEL/
  * PREDICT, bytes for COV/SOLVE) accumulated since the last call for `cls`.  */
