@@ -728,6 +728,7 @@ def main():
             "roofline": roofline_object(args, res, n, d, p, args.dtype, args.steps, ctx),
             "stage_ms_per_step": stage_object(res, args.steps),
             "first_fit_incl_upload_s": res["t_build"],
+            **({"per_step_ms": phases_object(res, args.steps)} if sharded else {}),
         }
 
     want = set(args.secondary.split(","))

@@ -1,0 +1,446 @@
+// chain.hip — ONE persistent launch per W x W diagonal super-block: Cholesky factor in place + 64 x 64 diagonal inverses + the explicit
+// inverse LW = L^-1 (chol.h: what factor_diag_block + build_super_inverse did in ~15 dependent launches per 256 columns).
+//
+// The block is cut into 64 x 64 tiles (nb = W / 64 per side).  Every output tile is ONE task, written exactly once:
+//   L(c, c)   potrf:  S = A_cc - sum_{k<c} L_ck L_ck' ;  L_cc = chol(S), Linv_c = L_cc^-1         (potf2.h, one wavefront)
+//   L(i, c)   i > c:  T = A_ic - sum_{k<c} L_ik L_ck' ;  L_ic = T Linv_c'                          (left-looking: dpotrf's TRSM as a product)
+//   X(i, j)   i > j:  X_ij = -Linv_i sum_{k=j}^{i-1} L_ik X_kj ,  X_jj = Linv_j                   (row i of L^-1 by forward substitution)
+// Tasks are handed out by ONE device-scope counter in a fixed topological order — step c: L(c, c), L(c+1 .. nb-1, c), then X(c, 0 .. c-1) —
+// so a workgroup only ever waits for tasks with SMALLER indices, which are finished or held by a workgroup that is running: the launch
+// makes progress with any number of resident workgroups (late or never-scheduled ones simply take no tasks; no grid barrier, no co-residency
+// requirement), and every spin is bounded.  Dependencies are per-tile flags; whole finished columns of L / rows of X are tracked by
+// counters so that the long accumulations over old columns run without polling.
+//
+// Inter-workgroup visibility (MI355X_MICROARCH.md "inter-workgroup visibility", cdna_hip_programming.md §6 G16, form R1): every tile another
+// workgroup will read is stored WRITE-THROUGH (8-byte agent-scope relaxed atomics = global_store_dwordx2 sc1), every storing wave drains
+// (s_waitcnt vmcnt(0)), __syncthreads(), then one lane stores the flag (sc1); readers poll the flag relaxed and read the tile with sc1 loads
+// (L1 bypassed) — no fences, no L2 write-back / invalidate that would disturb the trailing update running beside the chain.
+#include "common.h"
+#include "mfma.h"
+#include "potf2.h"
+
+namespace gpmi {
+
+namespace {
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned int gu32;
+
+__device__ __forceinline__ unsigned long long ld_sc1(const void* p) {
+    return __hip_atomic_load((const gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1(void* p, unsigned long long v) { __hip_atomic_store((gu64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned ld_flag(const unsigned* p) {
+    return __hip_atomic_load((const gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_flag(unsigned* p, unsigned v) { __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// words of the synchronisation area (zeroed by the launcher before every launch)
+constexpr int CH_TASK = 0;    // next task index
+constexpr int CH_ABORT = 1;   // 1: a pivot failed (tasks after it publish without computing), 2: a wait timed out
+constexpr int CH_HDR = 4;
+// then: FL[nb * nb] (L tile final), FX[nb * nb] (X tile final), CL[nb] (finished tiles of L column k), CX[nb] (finished tiles of X row r)
+
+constexpr int LD = 65;  // leading dimension of the 64 x 64 LDS tiles (as the panel kernels)
+
+template <typename T>
+struct Tile {  // a 64 x 64 tile as 8-byte words: WR per row, WPT per thread of a 256-thread workgroup
+    static constexpr int WR = 64 * (int)sizeof(T) / 8;
+    static constexpr int WPT = 64 * WR / 256;
+    static constexpr int EPW = 8 / (int)sizeof(T);  // elements per word
+};
+
+template <typename T>
+__device__ __forceinline__ void unpack(unsigned long long w, T* e);
+template <>
+__device__ __forceinline__ void unpack<double>(unsigned long long w, double* e) { e[0] = __longlong_as_double((long long)w); }
+template <>
+__device__ __forceinline__ void unpack<float>(unsigned long long w, float* e) {
+    e[0] = __uint_as_float((unsigned)(w & 0xffffffffull));
+    e[1] = __uint_as_float((unsigned)(w >> 32));
+}
+template <typename T>
+__device__ __forceinline__ unsigned long long pack(const T* e);
+template <>
+__device__ __forceinline__ unsigned long long pack<double>(const double* e) { return (unsigned long long)__double_as_longlong(e[0]); }
+template <>
+__device__ __forceinline__ unsigned long long pack<float>(const float* e) {
+    return (unsigned long long)__float_as_uint(e[0]) | ((unsigned long long)__float_as_uint(e[1]) << 32);
+}
+
+// global (row-major, leading dimension ld elements) -> registers, coalesced; COHERENT: the tile was (or may have been) written by
+// another workgroup of this launch
+template <typename T, bool COHERENT>
+__device__ __forceinline__ void tile_fetch(unsigned long long (&r)[Tile<T>::WPT], const T* g, int64_t ld) {
+    constexpr int WR = Tile<T>::WR;
+#pragma unroll
+    for (int q = 0; q < Tile<T>::WPT; ++q) {
+        const int e = (int)threadIdx.x + 256 * q;
+        const int row = e / WR, cw = e % WR;
+        const T* p = g + (int64_t)row * ld + cw * Tile<T>::EPW;
+        if constexpr (COHERENT)
+            r[q] = ld_sc1(p);
+        else
+            r[q] = *reinterpret_cast<const unsigned long long*>(p);
+    }
+}
+// registers -> LDS tile (leading dimension LD); TRANSPOSE: buf[col][row] = tile[row][col]
+template <typename T, bool TRANSPOSE>
+__device__ __forceinline__ void tile_publish(T* buf, const unsigned long long (&r)[Tile<T>::WPT]) {
+    constexpr int WR = Tile<T>::WR, EPW = Tile<T>::EPW;
+#pragma unroll
+    for (int q = 0; q < Tile<T>::WPT; ++q) {
+        const int e = (int)threadIdx.x + 256 * q;
+        const int row = e / WR, col = (e % WR) * EPW;
+        T v[EPW];
+        unpack<T>(r[q], v);
+#pragma unroll
+        for (int t = 0; t < EPW; ++t) {
+            if constexpr (TRANSPOSE)
+                buf[(col + t) * LD + row] = v[t];
+            else
+                buf[row * LD + col + t] = v[t];
+        }
+    }
+}
+// LDS tile -> global, coalesced; COHERENT: write-through stores (sc1) for tiles other workgroups of this launch will read.
+// TRANSPOSE: global[row][col] = buf[col][row].  scale multiplies every element (1 or -1).
+template <typename T, bool COHERENT, bool TRANSPOSE>
+__device__ __forceinline__ void tile_store(T* g, int64_t ld, const T* buf) {
+    constexpr int WR = Tile<T>::WR, EPW = Tile<T>::EPW;
+#pragma unroll
+    for (int q = 0; q < Tile<T>::WPT; ++q) {
+        const int e = (int)threadIdx.x + 256 * q;
+        const int row = e / WR, col = (e % WR) * EPW;
+        T v[EPW];
+#pragma unroll
+        for (int t = 0; t < EPW; ++t) v[t] = TRANSPOSE ? buf[(col + t) * LD + row] : buf[row * LD + col + t];
+        T* p = g + (int64_t)row * ld + col;
+        if constexpr (COHERENT)
+            st_sc1(p, pack<T>(v));
+        else
+            *reinterpret_cast<unsigned long long*>(p) = pack<T>(v);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void tile_zero(T* g, int64_t ld) {
+    constexpr int WR = Tile<T>::WR;
+#pragma unroll
+    for (int q = 0; q < Tile<T>::WPT; ++q) {
+        const int e = (int)threadIdx.x + 256 * q;
+        *reinterpret_cast<unsigned long long*>(g + (int64_t)(e / WR) * ld + (e % WR) * Tile<T>::EPW) = 0ull;
+    }
+}
+
+// publish: every storing wave has drained its write-through stores; then ONE lane raises the flag and counts the tile
+__device__ __forceinline__ void publish(unsigned* flag, unsigned* counter) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        st_flag(flag, 1u);
+        __hip_atomic_fetch_add((gu32*)counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+struct ChainShared {
+    int task;
+    int wmL, wmX;  // columns of L [0, wmL) and rows of X [0, wmX) are complete (monotone, per workgroup)
+    int abort;
+};
+
+// Wait (every wave for itself: wave-uniform, no barrier) until *flag is set.  Bounded: after ~4 s of polling the launch is declared dead
+// (CH_ABORT = 2, *info = INT_MIN: gpmi_fit returns GPMI_EDEVICE) and every wait returns at once.
+__device__ __forceinline__ void wait_flag(const unsigned* flag, unsigned* sync, int* info) {
+    if (ld_flag(flag) != 0u) return;
+    for (unsigned spins = 0;; ++spins) {
+        __builtin_amdgcn_s_sleep(4);
+        if (ld_flag(flag) != 0u) return;
+        if ((spins & 63u) == 63u) {
+            if (ld_flag(sync + CH_ABORT) != 0u) return;
+            if (spins > (1u << 22)) {
+                if ((threadIdx.x & 63) == 0) {
+                    st_flag(sync + CH_ABORT, 2u);
+                    __hip_atomic_store((__attribute__((address_space(1))) int*)info, (int)0x80000000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                return;
+            }
+        }
+    }
+}
+
+template <typename T>
+struct ChainArgs {
+    T* A;           // the W x W block (row-major), factored in place
+    int64_t ld;
+    int nb;         // W / 64
+    T* linv;        // nb x (64 x 64): inverses of the diagonal tiles
+    T* invdiag;     // W reciprocals of the diagonal of L
+    T* LW;          // explicit inverse (W x W, leading dimension wld; strict upper part zeroed) or nullptr: factor only
+    int64_t wld;
+    int* info;
+    int64_t pivot_base;
+    unsigned* sync;
+};
+
+template <typename T>
+__device__ __forceinline__ void product64(typename Mfma<T>::Acc (&acc)[2][2], const T* a, const T* b) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) mma16_nt<T>(acc[mi][ni], a + (wm * 32 + mi * 16) * LD, LD, b + (wn * 32 + ni * 16) * LD, LD, 64, lane);
+}
+// accumulators -> LDS tile; TRANSPOSE: buf[col][row]; v = sgn * acc (+ add[row][col] when ADD, read from global in the accumulator layout)
+template <typename T, bool TRANSPOSE>
+__device__ __forceinline__ void acc_to_lds(T* buf, const typename Mfma<T>::Acc (&acc)[2][2], T sgn) {
+    using MF = Mfma<T>;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * 32 + mi * 16 + MF::row_of(lane, r), col = wn * 32 + ni * 16 + MF::col_of(lane, r);
+                const T v = sgn * acc_get<T>(acc[mi][ni], r);
+                if constexpr (TRANSPOSE)
+                    buf[col * LD + row] = v;
+                else
+                    buf[row * LD + col] = v;
+            }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void chain_block_kernel(ChainArgs<T> a) {
+    using MF = Mfma<T>;
+    using Acc = typename MF::Acc;
+    constexpr int WPT = Tile<T>::WPT;
+    if (*a.info != 0) return;
+    __builtin_amdgcn_s_setprio(3);  // beside the trailing update's waves (see diag64_kernel)
+    __shared__ T pool[PANEL_POOL];
+    __shared__ ChainShared sh;
+    T* const buf1 = pool;            // diag64_body's S
+    T* const buf2 = pool + 64 * LD;  // diag64_body's XT
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int nb = a.nb;
+    const bool inv = a.LW != nullptr;
+    const int per_step = inv ? nb : 0;  // tasks per step with the inverse: nb - c of L and c of X
+    const int ntasks = inv ? nb * nb : nb * (nb + 1) / 2;
+    unsigned* const FL = a.sync + CH_HDR;
+    unsigned* const FX = FL + nb * nb;
+    unsigned* const CL = FX + nb * nb;
+    unsigned* const CX = CL + nb;
+    if (tid == 0) {
+        sh.wmL = 0;
+        sh.wmX = 1;  // row 0 of X has no off-diagonal tile
+        sh.abort = 0;
+    }
+    __syncthreads();
+
+    for (;;) {
+        // ---- next task + refresh of the completed-column / completed-row marks (one round trip, wave 0) ----
+        if (wv == 0) {
+            int t = 0;
+            if (lane == 0) t = (int)__hip_atomic_fetch_add((gu32*)(a.sync + CH_TASK), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int wl = sh.wmL, wx = sh.wmX;
+            // lanes 0..31 look at L columns wl .. wl+31, lanes 32..63 at X rows wx .. wx+31
+            const bool isx = lane >= 32;
+            const int idx = (isx ? wx : wl) + (lane & 31);
+            bool done = false;
+            if (idx < nb) done = ld_flag((isx ? CX : CL) + idx) >= (unsigned)(isx ? idx : nb - idx);
+            const unsigned long long m = __ballot(done);
+            const unsigned lo = (unsigned)(m & 0xffffffffull), hi = (unsigned)(m >> 32);
+            const int nl = __builtin_ctz(~lo | 0u) ;  // leading run of completed columns (32 when all)
+            const int nx = __builtin_ctz(~hi | 0u);
+            const unsigned ab = ld_flag(a.sync + CH_ABORT);
+            if (lane == 0) {
+                sh.task = t;
+                sh.wmL = wl + (lo == 0xffffffffu ? 32 : nl);
+                sh.wmX = wx + (hi == 0xffffffffu ? 32 : nx);
+                sh.abort = (int)ab;
+            }
+        }
+        __syncthreads();
+        const int t = sh.task;
+        const int wmL = sh.wmL < nb ? sh.wmL : nb, wmX = sh.wmX < nb ? sh.wmX : nb;
+        const bool aborted = sh.abort != 0;
+        __syncthreads();  // (sh is rewritten at the top of the next iteration)
+        if (t >= ntasks) break;
+        // ---- decode: step c, then L(i, c) for i = c .. nb-1, then X(c, j) for j = 0 .. c-1 ----
+        int c, q;
+        if (inv) {
+            c = t / per_step;
+            q = t - c * per_step;
+        } else {
+            c = 0;
+            q = t;
+            while (q >= nb - c) {
+                q -= nb - c;
+                ++c;
+            }
+        }
+        const bool is_x = q >= nb - c;
+        const int i = is_x ? c : c + q;          // output tile row
+        const int j = is_x ? q - (nb - c) : c;   // output tile column
+        unsigned* const my_flag = (is_x ? FX : FL) + i * nb + j;
+        unsigned* const my_count = is_x ? CX + i : CL + j;
+        if (aborted) {  // a pivot failed / a wait timed out: publish so that nobody waits, compute nothing
+            publish(my_flag, my_count);
+            continue;
+        }
+
+        Acc acc[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc_zero<T>(acc[mi][ni]);
+
+        if (!is_x) {
+            // =============================== L(i, c) ===============================
+            const bool diag = i == c;
+            // the original entries of the tile, in the accumulator layout (plain loads: written before this launch)
+            T orig[2][2][4];
+            {
+                const T* At = a.A + (int64_t)(i * 64) * a.ld + c * 64;
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = wm * 32 + mi * 16 + MF::row_of(lane, r), col = wn * 32 + ni * 16 + MF::col_of(lane, r);
+                            orig[mi][ni][r] = At[(int64_t)row * a.ld + col];
+                        }
+            }
+            if (inv && !diag) tile_zero<T>(a.LW + (int64_t)(c * 64) * a.wld + i * 64, a.wld);  // the mirrored (strictly upper) tile of LW
+            // ---- acc = sum_{k < c} L_ik L_ck'  (one operand when i == c), next slab in flight while this one is multiplied ----
+            unsigned long long ra[WPT], rb[WPT];
+            auto fetch = [&](int k) {
+                if (k >= wmL) {
+                    wait_flag(FL + i * nb + k, a.sync, a.info);
+                    if (!diag) wait_flag(FL + c * nb + k, a.sync, a.info);
+                }
+                tile_fetch<T, true>(ra, a.A + (int64_t)(i * 64) * a.ld + k * 64, a.ld);
+                if (!diag) tile_fetch<T, true>(rb, a.A + (int64_t)(c * 64) * a.ld + k * 64, a.ld);
+            };
+            if (c > 0) fetch(0);
+            for (int k = 0; k < c; ++k) {
+                tile_publish<T, false>(buf1, ra);
+                if (!diag) tile_publish<T, false>(buf2, rb);
+                __syncthreads();
+                if (k + 1 < c) fetch(k + 1);
+                product64<T>(acc, buf1, diag ? buf1 : buf2);
+                __syncthreads();
+            }
+            // ---- T = A_ic - acc ----
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = wm * 32 + mi * 16 + MF::row_of(lane, r), col = wn * 32 + ni * 16 + MF::col_of(lane, r);
+                        buf1[row * LD + col] = orig[mi][ni][r] - acc_get<T>(acc[mi][ni], r);
+                    }
+            if (diag) {
+                __syncthreads();
+                int fail = 0;
+                if (wv == 0) fail = diag64_body<T, true>(nullptr, 0, nullptr, a.invdiag + c * 64, a.info, a.pivot_base + (int64_t)c * 64, pool);
+                if (wv == 0 && lane == 0 && fail) st_flag(a.sync + CH_ABORT, 1u);
+                __syncthreads();
+                // (on failure the stores below write garbage that nobody uses: *info is set, every later kernel returns at once)
+                T* Lcc = a.A + (int64_t)(c * 64) * a.ld + c * 64;
+                tile_store<T, false, false>(Lcc, a.ld, buf1);                                   // L_cc, strict upper part zero
+                tile_store<T, true, true>(a.linv + (int64_t)c * 64 * 64, 64, buf2);             // Linv_c = XT'
+                if (inv) tile_store<T, false, true>(a.LW + (int64_t)(c * 64) * a.wld + c * 64, a.wld, buf2);   // X_cc
+                publish(my_flag, my_count);
+            } else {
+                // ---- L_ic = T Linv_c' ----
+                wait_flag(FL + c * nb + c, a.sync, a.info);
+                tile_fetch<T, true>(ra, a.linv + (int64_t)c * 64 * 64, 64);
+                tile_publish<T, false>(buf2, ra);
+                __syncthreads();
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) acc_zero<T>(acc[mi][ni]);
+                product64<T>(acc, buf1, buf2);
+                __syncthreads();
+                acc_to_lds<T, false>(buf1, acc, T(1));
+                __syncthreads();
+                tile_store<T, true, false>(a.A + (int64_t)(i * 64) * a.ld + c * 64, a.ld, buf1);
+                publish(my_flag, my_count);
+            }
+        } else {
+            // =============================== X(i, j), i > j ===============================
+            // acc = sum_{k = j}^{i-1} L_ik X_kj :  A operand L_ik (rows m, k contiguous), B operand [n][k] = X_kj[k][n] (transposed on its way into LDS)
+            unsigned long long ra[WPT], rb[WPT];
+            auto fetch = [&](int k) {
+                if (k >= wmL) wait_flag(FL + i * nb + k, a.sync, a.info);
+                tile_fetch<T, true>(ra, a.A + (int64_t)(i * 64) * a.ld + k * 64, a.ld);
+                if (k == j) {  // X_jj = Linv_j
+                    if (j >= wmL) wait_flag(FL + j * nb + j, a.sync, a.info);
+                    tile_fetch<T, true>(rb, a.linv + (int64_t)j * 64 * 64, 64);
+                } else {
+                    if (k >= wmX) wait_flag(FX + k * nb + j, a.sync, a.info);
+                    tile_fetch<T, true>(rb, a.LW + (int64_t)(k * 64) * a.wld + j * 64, a.wld);
+                }
+            };
+            fetch(j);
+            for (int k = j; k < i; ++k) {
+                tile_publish<T, false>(buf1, ra);
+                tile_publish<T, true>(buf2, rb);
+                __syncthreads();
+                if (k + 1 < i) fetch(k + 1);
+                product64<T>(acc, buf1, buf2);
+                __syncthreads();
+            }
+            // X_ij = -Linv_i W :  A operand Linv_i (rows m, k contiguous), B operand [n][k] = W[k][n]
+            acc_to_lds<T, true>(buf2, acc, T(-1));
+            wait_flag(FL + i * nb + i, a.sync, a.info);
+            tile_fetch<T, true>(ra, a.linv + (int64_t)i * 64 * 64, 64);
+            tile_publish<T, false>(buf1, ra);
+            __syncthreads();
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc_zero<T>(acc[mi][ni]);
+            product64<T>(acc, buf1, buf2);
+            __syncthreads();
+            acc_to_lds<T, false>(buf1, acc, T(1));
+            __syncthreads();
+            tile_store<T, true, false>(a.LW + (int64_t)(i * 64) * a.wld + j * 64, a.wld, buf1);
+            publish(my_flag, my_count);
+        }
+    }
+}
+
+}  // namespace
+
+// bytes of the synchronisation area for blocks of up to nb_max tiles per side
+int64_t chain_sync_bytes(int nb_max) { return (int64_t)(CH_HDR + 2 * nb_max * nb_max + 2 * nb_max) * 4; }
+
+template <typename T>
+bool launch_chain_block(gpmi_ctx* ctx, T* A, int64_t ld, int64_t w, T* linv, T* invdiag, T* LW, int64_t wld, int* info, int64_t pivot_base) {
+    if (!ctx->chain_kernel || ctx->refine_solves || w % 64 != 0 || w <= 0 || w > (int64_t)ctx->chain_nb_max * 64 || !ctx->chain_sync) return false;
+    const int nb = (int)(w / 64);
+    unsigned* sync = (unsigned*)ctx->chain_sync;
+    (void)hipMemsetAsync(sync, 0, (size_t)chain_sync_bytes(nb), ctx->stream);
+    ChainArgs<T> a{A, ld, nb, linv, invdiag, LW, wld, info, pivot_base, sync};
+    // workgroups: what fits beside the trailing update (chol.h beside_update: the reserved compute units / free slots), otherwise enough
+    // for the tasks of one step (nb) with one workgroup per compute unit
+    int64_t g = ctx->beside_update ? side_slots(ctx) : std::max<int64_t>(8, std::min<int64_t>(2 * nb, ctx->chain_wgs_max));
+    if (ctx->chain_wgs > 0) g = ctx->chain_wgs;
+    if (g < 1) g = 1;
+    const double flops = (LW ? 2.0 : 1.0) * (double)w * (double)w * (double)w / 3.0;
+    ProfScope ps(ctx, GPMI_PROF_PANEL, flops, 0.0, false, /*chain_kernel=*/false);
+    hipLaunchKernelGGL(chain_block_kernel<T>, dim3((unsigned)g), dim3(256), 0, ctx->stream, a);
+    return true;
+}
+template bool launch_chain_block<double>(gpmi_ctx*, double*, int64_t, int64_t, double*, double*, double*, int64_t, int*, int64_t);
+template bool launch_chain_block<float>(gpmi_ctx*, float*, int64_t, int64_t, float*, float*, float*, int64_t, int*, int64_t);
+
+}  // namespace gpmi
