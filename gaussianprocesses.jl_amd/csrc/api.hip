@@ -359,6 +359,10 @@ static int fit_t(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int
     GPMI_HIP(c, hipMemcpyAsync(&h_info, c->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     GPMI_HIP(c, hipStreamSynchronize(c->stream));
     GPMI_HIP(c, hipGetLastError());
+    if (h_info < 0) {  // chain.hip: a dependency wait ran into its bound (a workgroup of the chain launch never came up)
+        c->err = "chain kernel: a dependency wait timed out (GPMI_CHAIN=0 selects the multi-launch chain)";
+        return GPMI_EDEVICE;
+    }
     if (info_out) *info_out = h_info;
     if (h_info != 0) {
         c->err = "matrix is not positive definite; Cholesky factorization failed";
@@ -620,6 +624,7 @@ static int super_factor_t(gpmi_ctx* c, T* blk, int64_t ld, int64_t w, T* linv, T
     // factor_diag_block / build_super_inverse address the block as (k, k) of a matrix and the inverses by global index:
     // shift the bases so that k = pivot_base lands on the caller's buffers (nothing outside them is dereferenced)
     const int64_t k = pivot_base;
+    if (launch_chain_block<T>(c, blk, ld, w, linv, invdiag, lw, w, c->d_info, pivot_base)) return GPMI_OK;  // one persistent launch (chain.hip)
     T* Av = blk - (k * ld + k);
     T* linv_v = linv - (k / IB) * IB * IB;
     T* invd_v = invdiag - k;
@@ -710,7 +715,8 @@ static int create_one_context(int dev_code, gpmi_ctx** out) {
         hipMalloc(&c->d_queue, (64 + 4 * 1024) * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(c->d_queue, 0, (64 + 4 * 1024) * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&c->d_queue_side, 64 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(c->d_queue_side, 0, 64 * sizeof(unsigned long long)) != hipSuccess) {
+        hipMemset(c->d_queue_side, 0, 64 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc(&c->chain_sync, (size_t)chain_sync_bytes(c->chain_nb_max)) != hipSuccess) {
         c->stream = c->own_stream;
         gpmi_ctx_destroy(c);
         return GPMI_EDEVICE;
@@ -758,6 +764,10 @@ static int create_one_context(int dev_code, gpmi_ctx** out) {
         sscanf(e, "%lld,%lld,%lld", &a, &b, &d);
         c->super_min[0] = a; c->super_min[1] = b; c->super_min[2] = d;
     }
+    //   (round 5) GPMI_CHAIN=0  the multi-launch diagonal-block chain instead of the persistent chain kernel (chain.hip);
+    //             GPMI_CHAIN_WGS=g  workgroups of every chain launch (test hook: 1 = a serial walk of the task list)
+    if (const char* e = getenv("GPMI_CHAIN")) c->chain_kernel = atoi(e) != 0;
+    if (const char* e = getenv("GPMI_CHAIN_WGS")) c->chain_wgs = std::max(0, atoi(e));
     if (const char* e = getenv("GPMI_UPDATE256")) c->update256 = atoi(e) != 0;
     if (const char* e = getenv("GPMI_UPDATE256_MIN")) c->update256_min_tiles = std::max<long long>(1, atoll(e));
     if (const char* e = getenv("GPMI_UPDATE256_ATOMIC")) c->update256_atomic = atoi(e) != 0;
@@ -807,6 +817,7 @@ void gpmi_ctx_destroy(gpmi_ctx* c) {
     if (c->h_scal) hipHostFree(c->h_scal);
     if (c->d_queue) hipFree(c->d_queue);
     if (c->d_queue_side) hipFree(c->d_queue_side);
+    if (c->chain_sync) hipFree(c->chain_sync);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }

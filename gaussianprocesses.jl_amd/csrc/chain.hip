@@ -68,16 +68,29 @@ __device__ __forceinline__ unsigned long long pack<float>(const float* e) {
     return (unsigned long long)__float_as_uint(e[0]) | ((unsigned long long)__float_as_uint(e[1]) << 32);
 }
 
-// global (row-major, leading dimension ld elements) -> registers, coalesced; COHERENT: the tile was (or may have been) written by
-// another workgroup of this launch
+// Addressing of a 64 x 64 global tile (row-major, leading dimension ld elements) by a 256-thread workgroup, 8-byte words: thread t's word
+// q is word (t + 256 q) of the tile = row (t / WR) + q (256 / WR), column word t % WR.  The tile's base pointer is WAVE-UNIFORM (it comes
+// from the task index, which the task loop passes through readfirstlane), so base + q * row-step stays in scalar registers and each
+// thread keeps ONE 32-bit byte offset for all its words (global_load ... v_off, s[base:base+1]): the 16 + 16 loads of a slab would
+// otherwise hold 64 vector registers of addresses.
+template <typename T>
+struct TileAddr {
+    unsigned voff;      // byte offset of this thread's word 0
+    int64_t qstep;      // bytes between consecutive words of a thread (uniform)
+    __device__ __forceinline__ TileAddr(int64_t ld) {
+        constexpr int WR = Tile<T>::WR;
+        const int t = (int)threadIdx.x;
+        voff = (unsigned)(((int64_t)(t / WR) * ld) * (int64_t)sizeof(T) + (int64_t)(t % WR) * 8);
+        qstep = (int64_t)(256 / WR) * ld * (int64_t)sizeof(T);
+    }
+};
+
+// global -> registers, coalesced; COHERENT: the tile was (or may have been) written by another workgroup of this launch
 template <typename T, bool COHERENT>
-__device__ __forceinline__ void tile_fetch(unsigned long long (&r)[Tile<T>::WPT], const T* g, int64_t ld) {
-    constexpr int WR = Tile<T>::WR;
+__device__ __forceinline__ void tile_fetch(unsigned long long (&r)[Tile<T>::WPT], const T* g, const TileAddr<T>& ad) {
 #pragma unroll
     for (int q = 0; q < Tile<T>::WPT; ++q) {
-        const int e = (int)threadIdx.x + 256 * q;
-        const int row = e / WR, cw = e % WR;
-        const T* p = g + (int64_t)row * ld + cw * Tile<T>::EPW;
+        const char* p = reinterpret_cast<const char*>(g) + (int64_t)q * ad.qstep + ad.voff;
         if constexpr (COHERENT)
             r[q] = ld_sc1(p);
         else
@@ -104,9 +117,9 @@ __device__ __forceinline__ void tile_publish(T* buf, const unsigned long long (&
     }
 }
 // LDS tile -> global, coalesced; COHERENT: write-through stores (sc1) for tiles other workgroups of this launch will read.
-// TRANSPOSE: global[row][col] = buf[col][row].  scale multiplies every element (1 or -1).
+// TRANSPOSE: global[row][col] = buf[col][row].
 template <typename T, bool COHERENT, bool TRANSPOSE>
-__device__ __forceinline__ void tile_store(T* g, int64_t ld, const T* buf) {
+__device__ __forceinline__ void tile_store(T* g, const TileAddr<T>& ad, const T* buf) {
     constexpr int WR = Tile<T>::WR, EPW = Tile<T>::EPW;
 #pragma unroll
     for (int q = 0; q < Tile<T>::WPT; ++q) {
@@ -115,7 +128,7 @@ __device__ __forceinline__ void tile_store(T* g, int64_t ld, const T* buf) {
         T v[EPW];
 #pragma unroll
         for (int t = 0; t < EPW; ++t) v[t] = TRANSPOSE ? buf[(col + t) * LD + row] : buf[row * LD + col + t];
-        T* p = g + (int64_t)row * ld + col;
+        char* p = reinterpret_cast<char*>(g) + (int64_t)q * ad.qstep + ad.voff;
         if constexpr (COHERENT)
             st_sc1(p, pack<T>(v));
         else
@@ -123,13 +136,9 @@ __device__ __forceinline__ void tile_store(T* g, int64_t ld, const T* buf) {
     }
 }
 template <typename T>
-__device__ __forceinline__ void tile_zero(T* g, int64_t ld) {
-    constexpr int WR = Tile<T>::WR;
+__device__ __forceinline__ void tile_zero(T* g, const TileAddr<T>& ad) {
 #pragma unroll
-    for (int q = 0; q < Tile<T>::WPT; ++q) {
-        const int e = (int)threadIdx.x + 256 * q;
-        *reinterpret_cast<unsigned long long*>(g + (int64_t)(e / WR) * ld + (e % WR) * Tile<T>::EPW) = 0ull;
-    }
+    for (int q = 0; q < Tile<T>::WPT; ++q) *reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(g) + (int64_t)q * ad.qstep + ad.voff) = 0ull;
 }
 
 // publish: every storing wave has drained its write-through stores; then ONE lane raises the flag and counts the tile
@@ -166,6 +175,14 @@ __device__ __forceinline__ void wait_flag(const unsigned* flag, unsigned* sync, 
             }
         }
     }
+}
+
+// two flags at once: both loads are in flight together (one round trip when both are already set)
+__device__ __forceinline__ void wait_flags2(const unsigned* fa, const unsigned* fb, unsigned* sync, int* info) {
+    const unsigned a = ld_flag(fa), b = ld_flag(fb);
+    if (a != 0u && b != 0u) return;
+    if (a == 0u) wait_flag(fa, sync, info);
+    if (b == 0u) wait_flag(fb, sync, info);
 }
 
 template <typename T>
@@ -212,14 +229,23 @@ __device__ __forceinline__ void acc_to_lds(T* buf, const typename Mfma<T>::Acc (
             }
 }
 
+// The workgroup's LDS pool at file scope, so that the one-wavefront potf2 can be a function of its OWN (not inlined: inside the task loop
+// its 64 row registers on top of the loop's live values spill ~500 VGPRs; as a call only the handful of values live across it are saved)
+// and still address LDS as LDS.
+__shared__ double g_pool[PANEL_POOL];
+
+template <typename T>
+__device__ __attribute__((noinline)) int potf2_in_lds(T* invdiag, int* info, long long pivot_base) {
+    return diag64_body<T, true>(nullptr, 0, nullptr, invdiag, info, (int64_t)pivot_base, reinterpret_cast<T*>(g_pool));
+}
+
 template <typename T>
 __global__ __launch_bounds__(256, 2) void chain_block_kernel(ChainArgs<T> a) {
     using MF = Mfma<T>;
     using Acc = typename MF::Acc;
     constexpr int WPT = Tile<T>::WPT;
-    if (*a.info != 0) return;
     __builtin_amdgcn_s_setprio(3);  // beside the trailing update's waves (see diag64_kernel)
-    __shared__ T pool[PANEL_POOL];
+    T* const pool = reinterpret_cast<T*>(g_pool);
     __shared__ ChainShared sh;
     T* const buf1 = pool;            // diag64_body's S
     T* const buf2 = pool + 64 * LD;  // diag64_body's XT
@@ -237,7 +263,11 @@ __global__ __launch_bounds__(256, 2) void chain_block_kernel(ChainArgs<T> a) {
         sh.wmL = 0;
         sh.wmX = 1;  // row 0 of X has no off-diagonal tile
         sh.abort = 0;
+        sh.task = *a.info;  // an earlier factorisation step failed: nothing to do.  Read ONCE per workgroup: another workgroup of this very
+                            // launch may set *info while this one starts, and the waves of a workgroup must not disagree
     }
+    __syncthreads();
+    if (sh.task != 0) return;
     __syncthreads();
 
     for (;;) {
@@ -253,20 +283,23 @@ __global__ __launch_bounds__(256, 2) void chain_block_kernel(ChainArgs<T> a) {
             if (idx < nb) done = ld_flag((isx ? CX : CL) + idx) >= (unsigned)(isx ? idx : nb - idx);
             const unsigned long long m = __ballot(done);
             const unsigned lo = (unsigned)(m & 0xffffffffull), hi = (unsigned)(m >> 32);
-            const int nl = __builtin_ctz(~lo | 0u) ;  // leading run of completed columns (32 when all)
-            const int nx = __builtin_ctz(~hi | 0u);
+            const int nl = lo == 0xffffffffu ? 32 : __builtin_ctz(~lo);  // leading run of completed columns
+            const int nx = hi == 0xffffffffu ? 32 : __builtin_ctz(~hi);
             const unsigned ab = ld_flag(a.sync + CH_ABORT);
             if (lane == 0) {
                 sh.task = t;
-                sh.wmL = wl + (lo == 0xffffffffu ? 32 : nl);
-                sh.wmX = wx + (hi == 0xffffffffu ? 32 : nx);
+                sh.wmL = wl + nl;
+                sh.wmX = wx + nx;
                 sh.abort = (int)ab;
             }
         }
         __syncthreads();
-        const int t = sh.task;
-        const int wmL = sh.wmL < nb ? sh.wmL : nb, wmX = sh.wmX < nb ? sh.wmX : nb;
-        const bool aborted = sh.abort != 0;
+        // (readfirstlane: the values are the same in every lane, and now the compiler knows — everything derived from the task index,
+        //  the tile base pointers above all, lives in scalar registers)
+        const int t = __builtin_amdgcn_readfirstlane(sh.task);
+        const int wmL_raw = __builtin_amdgcn_readfirstlane(sh.wmL), wmX_raw = __builtin_amdgcn_readfirstlane(sh.wmX);
+        const int wmL = wmL_raw < nb ? wmL_raw : nb, wmX = wmX_raw < nb ? wmX_raw : nb;
+        const bool aborted = __builtin_amdgcn_readfirstlane(sh.abort) != 0;
         __syncthreads();  // (sh is rewritten at the top of the next iteration)
         if (t >= ntasks) break;
         // ---- decode: step c, then L(i, c) for i = c .. nb-1, then X(c, j) for j = 0 .. c-1 ----
@@ -293,16 +326,13 @@ __global__ __launch_bounds__(256, 2) void chain_block_kernel(ChainArgs<T> a) {
         }
 
         Acc acc[2][2];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc_zero<T>(acc[mi][ni]);
+        const TileAddr<T> adA(a.ld), adW(a.wld), adI(64);
 
         if (!is_x) {
             // =============================== L(i, c) ===============================
             const bool diag = i == c;
-            // the original entries of the tile, in the accumulator layout (plain loads: written before this launch)
-            T orig[2][2][4];
+            // the accumulators start at MINUS the original entries of the tile (plain loads: written before this launch), so that after the
+            // K loop they hold  sum_k L_ik L_ck' - A_ic = -T  and no second copy of the tile occupies registers meanwhile
             {
                 const T* At = a.A + (int64_t)(i * 64) * a.ld + c * 64;
 #pragma unroll
@@ -312,55 +342,52 @@ __global__ __launch_bounds__(256, 2) void chain_block_kernel(ChainArgs<T> a) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int row = wm * 32 + mi * 16 + MF::row_of(lane, r), col = wn * 32 + ni * 16 + MF::col_of(lane, r);
-                            orig[mi][ni][r] = At[(int64_t)row * a.ld + col];
+                            acc[mi][ni].v[r] = -At[(int64_t)row * a.ld + col];
                         }
             }
-            if (inv && !diag) tile_zero<T>(a.LW + (int64_t)(c * 64) * a.wld + i * 64, a.wld);  // the mirrored (strictly upper) tile of LW
-            // ---- acc = sum_{k < c} L_ik L_ck'  (one operand when i == c), next slab in flight while this one is multiplied ----
+            if (inv && !diag) tile_zero<T>(a.LW + (int64_t)(c * 64) * a.wld + i * 64, adW);  // the mirrored (strictly upper) tile of LW
+            // ---- acc += sum_{k < c} L_ik L_ck'  (one operand when i == c), next slab in flight while this one is multiplied ----
             unsigned long long ra[WPT], rb[WPT];
             auto fetch = [&](int k) {
                 if (k >= wmL) {
-                    wait_flag(FL + i * nb + k, a.sync, a.info);
-                    if (!diag) wait_flag(FL + c * nb + k, a.sync, a.info);
+                    if (diag)
+                        wait_flag(FL + i * nb + k, a.sync, a.info);
+                    else
+                        wait_flags2(FL + i * nb + k, FL + c * nb + k, a.sync, a.info);
                 }
-                tile_fetch<T, true>(ra, a.A + (int64_t)(i * 64) * a.ld + k * 64, a.ld);
-                if (!diag) tile_fetch<T, true>(rb, a.A + (int64_t)(c * 64) * a.ld + k * 64, a.ld);
+                tile_fetch<T, true>(ra, a.A + (int64_t)(i * 64) * a.ld + k * 64, adA);
+                if (!diag) tile_fetch<T, true>(rb, a.A + (int64_t)(c * 64) * a.ld + k * 64, adA);
             };
             if (c > 0) fetch(0);
             for (int k = 0; k < c; ++k) {
                 tile_publish<T, false>(buf1, ra);
                 if (!diag) tile_publish<T, false>(buf2, rb);
                 __syncthreads();
-                if (k + 1 < c) fetch(k + 1);
+                // the next slab's loads fly under this slab's product when no wait stands before them (old, complete columns); at the front
+                // the product goes first — it needs nothing that is still being computed — and the wait after it
+                const bool early = k + 1 < c && k + 1 < wmL;
+                if (early) fetch(k + 1);
                 product64<T>(acc, buf1, diag ? buf1 : buf2);
+                if (!early && k + 1 < c) fetch(k + 1);
                 __syncthreads();
             }
-            // ---- T = A_ic - acc ----
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = wm * 32 + mi * 16 + MF::row_of(lane, r), col = wn * 32 + ni * 16 + MF::col_of(lane, r);
-                        buf1[row * LD + col] = orig[mi][ni][r] - acc_get<T>(acc[mi][ni], r);
-                    }
+            acc_to_lds<T, false>(buf1, acc, T(-1));  // T = A_ic - sum
             if (diag) {
                 __syncthreads();
                 int fail = 0;
-                if (wv == 0) fail = diag64_body<T, true>(nullptr, 0, nullptr, a.invdiag + c * 64, a.info, a.pivot_base + (int64_t)c * 64, pool);
+                if (wv == 0) fail = potf2_in_lds<T>(a.invdiag + c * 64, a.info, (long long)(a.pivot_base + (int64_t)c * 64));
                 if (wv == 0 && lane == 0 && fail) st_flag(a.sync + CH_ABORT, 1u);
                 __syncthreads();
                 // (on failure the stores below write garbage that nobody uses: *info is set, every later kernel returns at once)
                 T* Lcc = a.A + (int64_t)(c * 64) * a.ld + c * 64;
-                tile_store<T, false, false>(Lcc, a.ld, buf1);                                   // L_cc, strict upper part zero
-                tile_store<T, true, true>(a.linv + (int64_t)c * 64 * 64, 64, buf2);             // Linv_c = XT'
-                if (inv) tile_store<T, false, true>(a.LW + (int64_t)(c * 64) * a.wld + c * 64, a.wld, buf2);   // X_cc
+                tile_store<T, false, false>(Lcc, adA, buf1);                                   // L_cc, strict upper part zero
+                tile_store<T, true, true>(a.linv + (int64_t)c * 64 * 64, adI, buf2);           // Linv_c = XT'
+                if (inv) tile_store<T, false, true>(a.LW + (int64_t)(c * 64) * a.wld + c * 64, adW, buf2);   // X_cc
                 publish(my_flag, my_count);
             } else {
                 // ---- L_ic = T Linv_c' ----
                 wait_flag(FL + c * nb + c, a.sync, a.info);
-                tile_fetch<T, true>(ra, a.linv + (int64_t)c * 64 * 64, 64);
+                tile_fetch<T, true>(ra, a.linv + (int64_t)c * 64 * 64, adI);
                 tile_publish<T, false>(buf2, ra);
                 __syncthreads();
 #pragma unroll
@@ -371,37 +398,45 @@ __global__ __launch_bounds__(256, 2) void chain_block_kernel(ChainArgs<T> a) {
                 __syncthreads();
                 acc_to_lds<T, false>(buf1, acc, T(1));
                 __syncthreads();
-                tile_store<T, true, false>(a.A + (int64_t)(i * 64) * a.ld + c * 64, a.ld, buf1);
+                tile_store<T, true, false>(a.A + (int64_t)(i * 64) * a.ld + c * 64, adA, buf1);
                 publish(my_flag, my_count);
             }
         } else {
             // =============================== X(i, j), i > j ===============================
             // acc = sum_{k = j}^{i-1} L_ik X_kj :  A operand L_ik (rows m, k contiguous), B operand [n][k] = X_kj[k][n] (transposed on its way into LDS)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc_zero<T>(acc[mi][ni]);
             unsigned long long ra[WPT], rb[WPT];
             auto fetch = [&](int k) {
-                if (k >= wmL) wait_flag(FL + i * nb + k, a.sync, a.info);
-                tile_fetch<T, true>(ra, a.A + (int64_t)(i * 64) * a.ld + k * 64, a.ld);
-                if (k == j) {  // X_jj = Linv_j
-                    if (j >= wmL) wait_flag(FL + j * nb + j, a.sync, a.info);
-                    tile_fetch<T, true>(rb, a.linv + (int64_t)j * 64 * 64, 64);
-                } else {
-                    if (k >= wmX) wait_flag(FX + k * nb + j, a.sync, a.info);
-                    tile_fetch<T, true>(rb, a.LW + (int64_t)(k * 64) * a.wld + j * 64, a.wld);
-                }
+                // the two operands' flags in one round trip (an operand known complete polls the task's own, always-set... no: its own flag
+                // is not set yet — a complete operand simply repeats the other's flag)
+                const unsigned* fa = FL + i * nb + k;                                   // L_ik
+                const unsigned* fb = k == j ? FL + j * nb + j : FX + k * nb + j;        // X_jj = Linv_j, or X_kj
+                const bool need_a = k >= wmL, need_b = k == j ? j >= wmL : k >= wmX;
+                if (need_a || need_b) wait_flags2(need_a ? fa : fb, need_b ? fb : fa, a.sync, a.info);
+                tile_fetch<T, true>(ra, a.A + (int64_t)(i * 64) * a.ld + k * 64, adA);
+                if (k == j)
+                    tile_fetch<T, true>(rb, a.linv + (int64_t)j * 64 * 64, adI);
+                else
+                    tile_fetch<T, true>(rb, a.LW + (int64_t)(k * 64) * a.wld + j * 64, adW);
             };
             fetch(j);
             for (int k = j; k < i; ++k) {
                 tile_publish<T, false>(buf1, ra);
                 tile_publish<T, true>(buf2, rb);
                 __syncthreads();
-                if (k + 1 < i) fetch(k + 1);
+                const bool early = k + 1 < i && k + 1 < wmL && k + 1 < wmX;
+                if (early) fetch(k + 1);
                 product64<T>(acc, buf1, buf2);
+                if (!early && k + 1 < i) fetch(k + 1);
                 __syncthreads();
             }
             // X_ij = -Linv_i W :  A operand Linv_i (rows m, k contiguous), B operand [n][k] = W[k][n]
             acc_to_lds<T, true>(buf2, acc, T(-1));
             wait_flag(FL + i * nb + i, a.sync, a.info);
-            tile_fetch<T, true>(ra, a.linv + (int64_t)i * 64 * 64, 64);
+            tile_fetch<T, true>(ra, a.linv + (int64_t)i * 64 * 64, adI);
             tile_publish<T, false>(buf1, ra);
             __syncthreads();
 #pragma unroll
@@ -412,7 +447,7 @@ __global__ __launch_bounds__(256, 2) void chain_block_kernel(ChainArgs<T> a) {
             __syncthreads();
             acc_to_lds<T, false>(buf1, acc, T(1));
             __syncthreads();
-            tile_store<T, true, false>(a.LW + (int64_t)(i * 64) * a.wld + j * 64, a.wld, buf1);
+            tile_store<T, true, false>(a.LW + (int64_t)(i * 64) * a.wld + j * 64, adW, buf1);
             publish(my_flag, my_count);
         }
     }

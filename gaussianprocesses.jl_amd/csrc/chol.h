@@ -278,6 +278,15 @@ inline void rows_below_super(gpmi_ctx* c, T* A, int64_t ld, const T* linv, int64
     }
 }
 
+// steps 1 + (ii): the w x w diagonal block at (k, k) factored, and — LW != nullptr — its explicit inverse built: ONE persistent launch
+// (chain.hip) when it applies, the multi-launch chain of rounds 1-4 otherwise (refinement wanted, GPMI_CHAIN=0)
+template <typename T>
+inline void factor_and_invert_block(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, int64_t k, int64_t w, T* LW, int64_t wld, int* d_info) {
+    if (launch_chain_block<T>(c, A + k * ld + k, ld, w, linv + (k / IB) * IB * IB, invdiag + k, LW, wld, d_info, k)) return;
+    factor_diag_block<T>(c, A, ld, linv, invdiag, k, w, d_info);
+    if (LW) build_super_inverse<T>(c, A, ld, linv, k, w, LW, wld, d_info);
+}
+
 // scratch of the inverse path for super-panels up to wmax columns and mrows rows below; GPMI_OK / GPMI_EDEVICE
 template <typename T>
 inline int super_scratch(gpmi_ctx* c, int64_t wmax, int64_t mrows) {
@@ -340,12 +349,8 @@ inline int cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, in
     int64_t ks = 0, ke = std::min<int64_t>(w0, npad);
     const T* LW = nullptr;  // inverse of the diagonal block of the current super-panel [ks, ke), or null
     int64_t wld = 0;
-    factor_diag_block<T>(c, A, ld, linv, invdiag, 0, ke, d_info);
-    if (by_inverse(ke) && Mtot > ke) {
-        T* p = place(0, ke, &wld);
-        build_super_inverse<T>(c, A, ld, linv, 0, ke, p, wld, d_info);
-        LW = p;
-    }
+    if (by_inverse(ke) && Mtot > ke) LW = place(0, ke, &wld);
+    factor_and_invert_block<T>(c, A, ld, linv, invdiag, 0, ke, const_cast<T*>(LW), wld, d_info);
     for (;;) {
         rows_below_super<T>(c, A, ld, linv, ks, ke, Mtot, d_info, LW, wld);
         if (ke >= npad) break;
@@ -359,8 +364,7 @@ inline int cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, in
         const double ntile = 0.5 * (double)(npad - ke2) * (double)(npad - ke2) / (GEMM_BM * GEMM_BN) * (double)K / NB;
         if (!can_look || ntile < (double)(masked ? c->lookahead_min_tiles_masked : c->lookahead_min_tiles) * (double)((w2 + NB - 1) / NB)) {
             launch_gemm_nt<T>(c, A + ke * ld + ke, ld, A + ke * ld + ks, ld, A + ke * ld + ks, ld, Mtot - ke, npad - ke, K, 1, d_info);
-            factor_diag_block<T>(c, A, ld, linv, invdiag, ke, w2, d_info);
-            if (inv2) build_super_inverse<T>(c, A, ld, linv, ke, w2, LW2, wld2, d_info);
+            factor_and_invert_block<T>(c, A, ld, linv, invdiag, ke, w2, LW2, wld2, d_info);
         } else {
             // The next diagonal block's own tiles go FIRST.  A 256-wide block (6 workgroups of 128 x 64 tiles) fits the
             // reserved slots and rides on the side stream, as in round 1.  Wider blocks go on the main stream at full speed
@@ -383,8 +387,7 @@ inline int cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, in
                 if (tiles_on_side)
                     launch_gemm_shape<T>(c, A + ke * ld + ke, ld, A + ke * ld + ks, ld, A + ke * ld + ks, ld, w2, w2, K,
                                          TileShape{0, 0, 1, 0, 1, 0}, d_info, GEMM_AUX);
-                factor_diag_block<T>(c, A, ld, linv, invdiag, ke, w2, d_info);
-                if (inv2) build_super_inverse<T>(c, A, ld, linv, ke, w2, LW2, wld2, d_info);
+                factor_and_invert_block<T>(c, A, ld, linv, invdiag, ke, w2, LW2, wld2, d_info);
                 c->beside_update = false;
             }
             c->side_one_per_xcd = false;

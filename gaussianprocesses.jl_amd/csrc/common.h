@@ -154,6 +154,12 @@ struct gpmi_ctx {
     int update256_atomic = 0;            // the C tile of a subtracting launch goes out as no-return atomic adds instead of load / add / store (GPMI_UPDATE256_ATOMIC)
     int64_t update256_rect_min_m = 8192; // rectangular / batched products go to the 256 x 128 kernel from this many rows on (GPMI_UPDATE256_RECT: test hook)
     int64_t update256_min_tiles = 1024;  // ... from this many 256 x 128 tiles on (GPMI_UPDATE256_MIN: test hook)
+    // the persistent chain kernel (chain.hip): one launch per diagonal super-block instead of ~15 dependent launches per 256 columns
+    int chain_kernel = 1;                // GPMI_CHAIN=0: the multi-launch chain of rounds 1-4 (factor_diag_block + build_super_inverse)
+    void* chain_sync = nullptr;          // its task counter, tile flags and column / row counters (zeroed before every launch)
+    int chain_nb_max = 32;               // blocks of up to 32 x 64 = 2048 columns
+    int chain_wgs_max = 64;              // workgroups of a chain launch that has the device to itself (the first block, serial tails)
+    int chain_wgs = 0;                   // > 0: the number of workgroups of EVERY chain launch (GPMI_CHAIN_WGS: test hook)
     hipStream_t own_stream = nullptr;    // the stream created with the context
     bool beside_update = false;          // launches made now run in the reserved slots beside the persistent update: no whole-CU kernels
     std::vector<hipEvent_t> la_events;
@@ -349,6 +355,12 @@ void launch_linv256(gpmi_ctx* ctx, const T* A, int64_t ld, const T* linv64, T* o
 // level 0 of the super-panel inverse: packed NB x NB inverses onto the diagonal of LW and (transposed) LWT
 template <typename T>
 void launch_place_inv_blocks(gpmi_ctx* ctx, const T* l256, T* LW, T* LWT, int64_t wld, int nblk);
+// chain.hip: the w x w diagonal block at A (leading dimension ld) factored in place, its 64 x 64 diagonal inverses (linv, w / 64 tiles),
+// 1 / L_ii (invdiag) and — LW != nullptr — its explicit inverse (leading dimension wld, strict upper part zero), all in ONE launch on
+// ctx->stream.  false: the launch does not apply (switched off, refinement wanted, w not a multiple of 64 or too wide): nothing was enqueued.
+template <typename T>
+bool launch_chain_block(gpmi_ctx* ctx, T* A, int64_t ld, int64_t w, T* linv, T* invdiag, T* LW, int64_t wld, int* info, int64_t pivot_base);
+int64_t chain_sync_bytes(int nb_max);
 template <typename T>
 void launch_bsolve256(gpmi_ctx* ctx, const T* Arow, int64_t ld, int64_t k0, int nbk, const T* linv256, T* z, T* alpha,
                       int64_t ldinv = NB);  // ldinv: row stride of the NB x NB inverse (a diagonal block of a wider explicit inverse)

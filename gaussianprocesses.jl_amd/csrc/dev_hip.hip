@@ -277,6 +277,10 @@ struct HipDev : Dev {
         int h = 0;
         note(hipMemcpyAsync(&h, c->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream), "hipMemcpyAsync");
         note(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+        if (h < 0) {  // chain.hip: a dependency wait ran into its bound — a device error, not a pivot
+            if (err.empty()) err = "chain kernel: a dependency wait timed out (GPMI_CHAIN=0 selects the multi-launch chain)";
+            return 0;
+        }
         return h;
     }
     void row_gemv(const void* R, int64_t ldr, int64_t P, int64_t n, const void* v, const void* add, void* out) override {

@@ -417,6 +417,10 @@ int fitc_fit_t(gpmi_fitc* f, const gpmi_kernel* k, double log_noise, const void*
     GPMI_HIP(c, hipMemcpyAsync(&h_info, c->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     GPMI_HIP(c, hipStreamSynchronize(c->stream));
     GPMI_HIP(c, hipGetLastError());
+    if (h_info < 0) {  // chain.hip: a dependency wait ran into its bound
+        c->err = "chain kernel: a dependency wait timed out (GPMI_CHAIN=0 selects the multi-launch chain)";
+        return GPMI_EDEVICE;
+    }
     if (info_out) *info_out = h_info;
     if (h_info != 0) {
         c->err = "matrix is not positive definite; Cholesky factorization failed";

