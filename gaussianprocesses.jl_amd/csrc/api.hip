@@ -333,7 +333,7 @@ static int fit_t(gpmi_gp* gp, const gpmi_kernel* k, const double* log_noise, int
     SuperStore<T> store;
     gp->sup_parts.clear();
     {
-        const int64_t w0 = super_width(c, npad);
+        const int64_t w0 = super_width_max(c, npad);
         if (w0 > NB && !refine && c->super_inverse) {
             const int rc_s = grow(c, &gp->supinv, &gp->supinv_cap, npad * (w0 + IB) * (int64_t)sizeof(T));
             if (rc_s) return rc_s;
@@ -768,6 +768,10 @@ static int create_one_context(int dev_code, gpmi_ctx** out) {
     //             GPMI_CHAIN_WGS=g  workgroups of every chain launch (test hook: 1 = a serial walk of the task list)
     if (const char* e = getenv("GPMI_CHAIN")) c->chain_kernel = atoi(e) != 0;
     if (const char* e = getenv("GPMI_CHAIN_WGS")) c->chain_wgs = std::max(0, atoi(e));
+    //             GPMI_TAIL_FUSE=rows  the last `rows` rows (<= 2048) of a factorisation as ONE diagonal block (0 = off)
+    //             GPMI_CUMASK_BELOW=rows  factorisations of fewer rows reserve whole compute units for the chain (default 32768)
+    if (const char* e = getenv("GPMI_TAIL_FUSE")) c->tail_fuse = std::min<long long>(std::max<long long>(0, atoll(e)) / IB * IB, (long long)c->chain_nb_max * IB);
+    if (const char* e = getenv("GPMI_CUMASK_BELOW")) c->whole_cus_below = atoll(e);
     if (const char* e = getenv("GPMI_UPDATE256")) c->update256 = atoi(e) != 0;
     if (const char* e = getenv("GPMI_UPDATE256_MIN")) c->update256_min_tiles = std::max<long long>(1, atoll(e));
     if (const char* e = getenv("GPMI_UPDATE256_ATOMIC")) c->update256_atomic = atoi(e) != 0;
@@ -778,7 +782,6 @@ static int create_one_context(int dev_code, gpmi_ctx** out) {
     if (const char* e = getenv("GPMI_WHITEN_SUPER")) c->whiten_super = std::max<long long>(NB, atoll(e) / NB * NB);
 #ifdef GPMI_TOOLS
     if (const char* e = getenv("GPMI_UPDATE256_RECT")) c->update256_rect_min_m = std::max<long long>(1, atoll(e));  // rows from which tall products take the 256 x 128 kernel
-    if (const char* e = getenv("GPMI_CUMASK_BELOW")) c->whole_cus_below = atoll(e);
     if (const char* e = getenv("GPMI_PHASE_LOCK")) c->phase_lock_min_k = atoll(e);
     if (const char* e = getenv("GPMI_REFINE")) c->refine_default = atoi(e) != 0;
     if (const char* e = getenv("GPMI_GEMM_NI")) c->gemm_ni = atoi(e) == 2 ? 2 : atoi(e) == 4 ? 4 : 0;

@@ -203,11 +203,24 @@ inline void main_update_beside_chain(gpmi_ctx* c, hipEvent_t after, F launch, bo
     c->gemm_reserve = 0;
 }
 
+// whether a w-wide diagonal block can go through the persistent chain kernel (chain.hip): then ANY multiple of 64 up to its limit is a valid
+// width with an explicit inverse (the multi-launch build_super_inverse merges halves: powers of two times NB only)
+inline bool chain_takes(const gpmi_ctx* c, int64_t w) {
+    return c->chain_kernel && c->chain_sync && !c->refine_solves && w > 0 && w % IB == 0 && w <= (int64_t)c->chain_nb_max * IB;
+}
 inline int64_t super_width(const gpmi_ctx* c, int64_t trailing) {
+    // the tail: everything that is left is ONE diagonal block (one chain launch, nothing below it but the carried rows)
+    if (c->tail_fuse > 0 && trailing <= c->tail_fuse && chain_takes(c, trailing)) return trailing;
     // widest first; widths are multiples of NB.  Below super_min[0] the factorisation is the plain NB = 256 one.
     for (int i = 2; i >= 0; --i)
         if (c->super_min[i] > 0 && trailing >= c->super_min[i]) return (int64_t)NB << (i + 1);
     return NB;
+}
+// the widest block a factorisation of npad rows will use (scratch / store sizing)
+inline int64_t super_width_max(const gpmi_ctx* c, int64_t npad) {
+    int64_t w = super_width(c, npad);
+    if (c->tail_fuse > 0 && chain_takes(c, std::min<int64_t>(npad, c->tail_fuse))) w = std::max<int64_t>(w, std::min<int64_t>(npad, c->tail_fuse));
+    return w;
 }
 
 // step 1: Cholesky of the w x w block at (k, k), in place, right-looking in NB panels (no rows below, nothing carried)
@@ -324,13 +337,14 @@ inline int cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, in
 
     // the inverse path serves super-panels of NB * 2^s > NB columns; factorisations that carry the refinement step
     // (nugget-regularised matrices) keep the substitution through the 64 x 64 inverses
-    const int64_t w0 = super_width(c, npad);
-    const bool inv_ok = c->super_inverse && !c->refine_solves && w0 > NB;
+    const int64_t w0 = super_width(c, npad), wmax = super_width_max(c, npad);
+    const bool inv_ok = c->super_inverse && !c->refine_solves && wmax > NB;
     if (inv_ok) {
-        const int rc = super_scratch<T>(c, w0, Mtot);
+        const int rc = super_scratch<T>(c, wmax, Mtot);
         if (rc) return rc;
     }
-    auto by_inverse = [&](int64_t w) { return inv_ok && w > NB && (w & (w - 1)) == 0; };  // NB * 2^s only
+    // NB * 2^s (the multi-launch inverse merges halves) or whatever the chain kernel takes
+    auto by_inverse = [&](int64_t w) { return inv_ok && w > NB && ((w & (w - 1)) == 0 || chain_takes(c, w)); };
     // the inverse of the super-panel at k: in the store when there is room (recorded), else in the scratch
     int64_t used = 0;
     auto place = [&](int64_t k, int64_t w, int64_t* wld) -> T* {
