@@ -123,15 +123,20 @@ struct gpmi_ctx {
     int reserved_cus = 0;
     int la_mode = -1;                // -1 none yet, 0 free slots (side_stream), 1 whole CUs (side_masked + upd_stream)
     bool mask_ok = false;            // CU-masked streams are available (256 CUs, GPMI_CUMASK != 0, creation has not failed)
-    int64_t whole_cus_below = 32768; // factorisations of fewer rows reserve whole CUs for the chain (the blocked path decides per
-                                     // step: its fixed-width blocks leave a long chain-bound tail, blocked.cpp)
+    int64_t whole_cus_below = 18432; // factorisations of fewer rows reserve whole CUs for the chain (the blocked path decides per
+                                     // step: its fixed-width blocks leave a long chain-bound tail, blocked.cpp).  32768 while the chain was a
+                                     // string of launches; with the persistent chain kernel free slots win from ~20 000 rows on
+                                     // (N = 28 000: 140.2 against 144.0 ms; N = 12 288: 21.6 against 21.1; profiles/r05_d_knob_sweeps_fine.log)
     int64_t lookahead_min_tiles_masked = 288;  // = a 3072-row trailing matrix at K = 256: the fast chain hides under shorter updates
     int lookahead_slots = 0;
     int64_t lookahead_min_tiles = 650;   // update length (in 128 x 128 x 256 tile products) below which the serial order is
                                          // faster (update < chain); 650 = the lower tiles of a 4608-row trailing matrix
     // two-level factorisation (chol.h): a super-panel of 512 / 1024 / 2048 columns is used while the remaining matrix has
     // at least super_min[0 / 1 / 2] rows (0 = never)
-    int64_t super_min[3] = {8192, 12288, 24576};  // swept on N = 50 000 and N = 20 000 (profiles/r02_super_sweep.log)
+    // {8192, 12288, 24576} in rounds 2-4 (profiles/r02_super_sweep.log); re-swept with the persistent chain kernel, whose blocks cost a
+    // third of the multi-launch chain's: wider panels now pay at much smaller trailing sizes (N = 20 000: 66.0 -> 61.3 ms per fit + predict,
+    // N = 50 000: 689.0 -> 683.9; profiles/r05_c_knob_sweeps_with_the_chain_kernel.log, r05_d_knob_sweeps_fine.log)
+    int64_t super_min[3] = {2048, 6144, 13312};
     // scratch of the two-level factorisation (grown on demand, chol.h): the explicit inverse of the current W x W diagonal
     // super-block (sup_lw, leading dimension sup_wld) and its transpose, the packed 256-inverses it is built from, an
     // (W/2)^2 product buffer, and the out-of-place image of the solved rows below (rows x W)

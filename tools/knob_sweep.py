@@ -46,6 +46,10 @@ if __name__ == "__main__":
                 {"GPMI_LOOKAHEAD_MIN": 2048}, {"GPMI_LOOKAHEAD_MIN": 1536, "GPMI_SUPER": "2048,6144,24576"},
                 {"GPMI_TAIL_FUSE": 1024}, {"GPMI_TAIL_FUSE": 1536}, {"GPMI_UPDATE256_MIN": 512}, {"GPMI_UPDATE256_MIN": 256, "GPMI_CUMASK_BELOW": 0}]
         for e in cfgs: run(n, e)
+    elif mode == "fine":
+        for sup in ("2048,6144,16384", "2048,6144,12288", "2048,4096,12288", "1024,4096,12288", "2048,5120,10240", "1536,4096,8192"):
+            for below in (32768, 0):
+                run(n, {"GPMI_SUPER": sup, "GPMI_CUMASK_BELOW": below})
     else:
         for blk in (0, 1024, 2048):
             for e in ({}, {"GPMI_CHAIN": 0}):
