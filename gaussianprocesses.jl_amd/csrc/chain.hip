@@ -375,7 +375,9 @@ __global__ __launch_bounds__(256, 2) void chain_block_kernel(ChainArgs<T> a) {
             if (diag) {
                 __syncthreads();
                 int fail = 0;
-                if (wv == 0) fail = potf2_in_lds<T>(a.invdiag + c * 64, a.info, (long long)(a.pivot_base + (int64_t)c * 64));
+                // (a pivot that failed in an earlier diagonal tile while this task was already under way: what is in S is garbage — no potf2)
+                if (wv == 0 && ld_flag(a.sync + CH_ABORT) == 0u)
+                    fail = potf2_in_lds<T>(a.invdiag + c * 64, a.info, (long long)(a.pivot_base + (int64_t)c * 64));
                 if (wv == 0 && lane == 0 && fail) st_flag(a.sync + CH_ABORT, 1u);
                 __syncthreads();
                 // (on failure the stores below write garbage that nobody uses: *info is set, every later kernel returns at once)

@@ -145,7 +145,15 @@ __device__ __forceinline__ int diag64_body(T* __restrict__ A, int64_t ld, T* __r
         }
     }
     if (fail) {
-        if (i == 0) *info = (int)(pivot_base + fail);
+        if (i == 0) {
+            if constexpr (FROM_LDS) {
+                // chain.hip: tasks already in flight when a pivot fails run on with garbage, and a LATER diagonal tile may fail on it: the
+                // first failure (diagonal tiles finish in order: the smallest pivot) must stay — dpotrf's info
+                atomicCAS(info, 0, (int)(pivot_base + fail));
+            } else {
+                *info = (int)(pivot_base + fail);
+            }
+        }
         return fail;
     }
     invdiag[i] = myinv;
