@@ -526,29 +526,10 @@ static int predict_t(gpmi_gp* gp, const gpmi_kernel* k, int64_t P, const void* x
         launch_row_gemv<T>(c, R, ld, P, n, (const T*)gp->alpha, d_mean, d_mu);  // mu = mx + Kfx' alpha, GP.jl:26
         // Lck = whiten!(Kff, Kfx), GP.jl:27
         const auto segs = whiten_segments<T>(gp);
-        // The test points are independent rows: two halves on two streams.  Every update of a half ends with a partial round of tiles (at
-        // N = 50 000 the 6 rounds of a 2048-wide segment's update are 5.86 rounds of work; 3.1 becomes 4 half-way through) during which most of
-        // the chip idles: 5.9 of 43 ms at N = 50 000, 2.1 of 8 ms at N = 20 000 by the round-count model; the other half's launches fill it.
-        // (each half reads the factor's panels itself: 2 x N^2 / 2 elements from L2 / HBM instead of one — the products stay MFMA-bound)
-        const int64_t P1 = (c->predict_split && c->side_stream && P >= 256) ? ((P / 2 + GEMM_BM - 1) / GEMM_BM) * GEMM_BM : P;
-        if (P1 < P) {
-            const int64_t P2 = P - P1;
-            hipStream_t main_s = c->stream;
-            hipEvent_t e0 = la_event(c), e1 = la_event(c);
-            GPMI_HIP(c, hipEventRecord(e0, main_s));
-            GPMI_HIP(c, hipStreamWaitEvent(c->side_stream, e0, 0));
-            {
-                StreamScope sc(c, c->side_stream, c->num_cus);
-                c->use_side_queue = true;
-                whiten_rows_inv<T>(c, A, ld, (const T*)gp->linv256, npad, R + P1 * ld, ld, V + P1 * ld, ld, [P2](int64_t) { return P2; }, &segs);
-                c->use_side_queue = false;
-                GPMI_HIP(c, hipEventRecord(e1, c->stream));
-            }
-            whiten_rows_inv<T>(c, A, ld, (const T*)gp->linv256, npad, R, ld, V, ld, [P1](int64_t) { return P1; }, &segs);
-            GPMI_HIP(c, hipStreamWaitEvent(main_s, e1, 0));
-        } else {
-            whiten_rows_inv<T>(c, A, ld, (const T*)gp->linv256, npad, R, ld, V, ld, [P](int64_t) { return P; }, &segs);
-        }
+        // (Measured and not kept, round 5 call F: the two halves of the test points whitened on two streams so that one half's launches fill the
+        //  partial last round of the other's updates — 44.6 against 44.2 ms at N = 50 000, 8.9 against 8.7 at N = 20 000: no gain, each half
+        //  re-reads the factor's panels.  profiles/r05_f_predict_split.log)
+        whiten_rows_inv<T>(c, A, ld, (const T*)gp->linv256, npad, R, ld, V, ld, [P](int64_t) { return P; }, &segs);
         if (!full_cov) launch_row_var<T>(c, V, ld, P, npad, kdiag, d_var);
     }
     GPMI_HIP(c, hipMemcpyAsync(mu_out, d_mu, (size_t)P * sizeof(T), hipMemcpyDeviceToHost, c->stream));
@@ -792,8 +773,7 @@ static int create_one_context(int dev_code, gpmi_ctx** out) {
     if (const char* e = getenv("GPMI_CHAIN_WGS")) c->chain_wgs = std::max(0, atoi(e));
     //             GPMI_TAIL_FUSE=rows  the last `rows` rows (<= 2048) of a factorisation as ONE diagonal block (0 = off)
     //             GPMI_CUMASK_BELOW=rows  factorisations of fewer rows reserve whole compute units for the chain (default 32768)
-    //             GPMI_PREDICT_SPLIT=0  predict_f whitens all test points in one stream of launches (rounds 1-4)
-    if (const char* e = getenv("GPMI_PREDICT_SPLIT")) c->predict_split = atoi(e) != 0;
+    if (const char* e = getenv("GPMI_FIRST")) c->first_width = std::max<long long>(0, atoll(e)) / NB * NB;
     if (const char* e = getenv("GPMI_TAIL_FUSE")) c->tail_fuse = std::min<long long>(std::max<long long>(0, atoll(e)) / IB * IB, (long long)c->chain_nb_max * IB);
     if (const char* e = getenv("GPMI_CUMASK_BELOW")) c->whole_cus_below = atoll(e);
     if (const char* e = getenv("GPMI_UPDATE256")) c->update256 = atoi(e) != 0;

@@ -360,7 +360,9 @@ inline int cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, in
         return (T*)c->sup_lw;
     };
 
-    int64_t ks = 0, ke = std::min<int64_t>(w0, npad);
+    // the first diagonal block is the one chain with nothing to hide behind: optionally a narrower first panel gets the pipeline going sooner
+    const int64_t w_first = (c->first_width >= NB && c->first_width < w0 && npad >= 4 * w0) ? c->first_width : w0;
+    int64_t ks = 0, ke = std::min<int64_t>(w_first, npad);
     const T* LW = nullptr;  // inverse of the diagonal block of the current super-panel [ks, ke), or null
     int64_t wld = 0;
     if (by_inverse(ke) && Mtot > ke) LW = place(0, ke, &wld);

@@ -165,10 +165,7 @@ struct gpmi_ctx {
     int chain_nb_max = 32;               // blocks of up to 32 x 64 = 2048 columns
     int chain_wgs_max = 64;              // workgroups of a chain launch that has the device to itself (the first block, serial tails)
     int chain_wgs = 0;                   // > 0: the number of workgroups of EVERY chain launch (GPMI_CHAIN_WGS: test hook)
-    int predict_split = 1;               // predict_f whitens the two halves of the test points on two streams (GPMI_PREDICT_SPLIT=0: one): the partial
-                                         // last round of one half's update is filled by the other half's launches (api.hip predict_t)
-    bool use_side_queue = false;         // full-width persistent launches made now pull from the SECOND set of tile-queue words (two streams' launches
-                                         // run concurrently and must not share them); unlike beside_update the grid is not capped
+    int64_t first_width = 0;             // > 0: the FIRST super-panel is only this wide (its chain has nothing to hide behind; GPMI_FIRST: experiment)
     int64_t tail_fuse = 2048;            // the LAST rows of a factorisation (at most this many) are ONE diagonal block: one chain launch instead of a
                                          // dozen 256-wide panels with their updates (GPMI_TAIL_FUSE; 0 = off; needs the chain kernel)
     hipStream_t own_stream = nullptr;    // the stream created with the context

@@ -467,9 +467,8 @@ static void launch_persistent_ni(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, i
     if (ntiles <= 0) return;
     const int per_cu = NI == 2 ? (ctx->gemm_wgs_per_cu == 1 ? 1 : 3) : ctx->gemm_wgs_per_cu;
     // beside the persistent update (side stream): no more workgroups than the slots it leaves free, and a queue of its own
-    const bool capped = ctx->beside_update;
-    const bool side = capped || ctx->use_side_queue;  // the second set of queue words: a launch that runs CONCURRENTLY with one on another stream
-    const int slots = capped ? side_slots(ctx) : per_cu * ctx->num_cus - ctx->gemm_reserve;  // multiples of 8
+    const bool side = ctx->beside_update;
+    const int slots = side ? side_slots(ctx) : per_cu * ctx->num_cus - ctx->gemm_reserve;  // multiples of 8
     // small launches: one workgroup per tile (rounded up to a multiple of 8 so XCD chunks stay contiguous)
     const int grid = (int)std::min<int64_t>(slots, (ntiles + 7) / 8 * 8);
     unsigned long long* const qbase = side ? ctx->queue_base_side : ctx->queue_base;

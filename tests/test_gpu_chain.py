@@ -123,22 +123,3 @@ def test_chain_kernel_on_a_blocked_handle(monkeypatch):
         np.testing.assert_allclose(s2, s2_o, rtol=1e-5, atol=1e-9)
         del gp
 
-
-def test_predict_on_two_streams_gives_the_same_bits(monkeypatch):
-    """predict_f whitens the two halves of the test points on two streams (api.hip predict_t: the partial last round of one half's update is
-    filled by the other half's launches).  The halves split at a multiple of the 128-row tile, so every tile does the same arithmetic in the
-    same order as in the single-stream form (GPMI_PREDICT_SPLIT=0): identical bits, and both match the oracle."""
-    res = {}
-    for split in (1, 0):
-        ctx = _ctx(monkeypatch, GPMI_PREDICT_SPLIT=split, GPMI_SUPER="512,1024,2048", GPMI_LOOKAHEAD_MIN=256)
-        gp, x, y, xs = _fit(ctx, 4100, p=1000)
-        res[split] = gp.predict_f(xs) + (gp.predict_f(xs[:, :300], full_cov=True)[1],)
-        if split:
-            ref = G.update_mll(SPEC, x, y, LN)
-            mu_o, s2_o = G.predict_f(SPEC, x, ref, xs)
-            np.testing.assert_allclose(res[1][0], mu_o, rtol=1e-6, atol=1e-8)
-            np.testing.assert_allclose(res[1][1], s2_o, rtol=1e-5, atol=1e-9)
-        del gp
-        ctx.close()
-    for a, b in zip(res[1], res[0]):
-        assert np.array_equal(a, b)

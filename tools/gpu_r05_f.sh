@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 5, call F: predict_f on two streams A/B, then the whole GPU suite as the driver runs it
+# round 5, call F: predict_f on two streams A/B (the GPMI_PREDICT_SPLIT experiment: no gain, removed again afterwards together with the
+# "predict" mode of tools/knob_sweep.py — profiles/r05_f_predict_split.log), then the whole GPU suite as the driver runs it
 mkdir -p gpurun_out; O=gpurun_out
 export TMPDIR=/tmp
 {
