@@ -773,7 +773,6 @@ static int create_one_context(int dev_code, gpmi_ctx** out) {
     if (const char* e = getenv("GPMI_CHAIN_WGS")) c->chain_wgs = std::max(0, atoi(e));
     //             GPMI_TAIL_FUSE=rows  the last `rows` rows (<= 2048) of a factorisation as ONE diagonal block (0 = off)
     //             GPMI_CUMASK_BELOW=rows  factorisations of fewer rows reserve whole compute units for the chain (default 32768)
-    if (const char* e = getenv("GPMI_FIRST")) c->first_width = std::max<long long>(0, atoll(e)) / NB * NB;
     if (const char* e = getenv("GPMI_TAIL_FUSE")) c->tail_fuse = std::min<long long>(std::max<long long>(0, atoll(e)) / IB * IB, (long long)c->chain_nb_max * IB);
     if (const char* e = getenv("GPMI_CUMASK_BELOW")) c->whole_cus_below = atoll(e);
     if (const char* e = getenv("GPMI_UPDATE256")) c->update256 = atoi(e) != 0;

@@ -47,6 +47,8 @@ BlockedGP::BlockedGP(Dev* dev, Comm* comm, int d, int64_t n, BlockedOpts o)
     nown_ = (int)own_.size();
     maxown_ = (int)((nblk_ + G_ - 1) / G_);
     per_ = (o.stripe_blocks <= 0 || o.stripe_blocks >= nown_) ? std::max(nown_, 1) : o.stripe_blocks;
+    u2a_cover_s_ = 1.1e-3 * ((double)WD_ / 1024.0) * ((double)WD_ / 1024.0) + 0.4e-3;  // chain kernel + inverse broadcast + margin
+    if (const char* e = getenv("GPMI_BLOCKED_U2A_US")) u2a_cover_s_ = 1e-6 * atof(e);     // tuning / test hook
 #ifdef GPMI_TOOLS  // tuning knob of the bring-up build (make TOOLS=1): U2a = 1 / u2a_div_ of the remaining block columns
     if (const char* e = getenv("GPMI_BLOCKED_U2A")) u2a_div_ = std::max(1, atoi(e));
 #endif
@@ -395,7 +397,21 @@ int BlockedGP::fit(const gpmi_kernel* kern, const double* log_noise, int64_t n_n
         // U2a: enough block columns to cover the chain and the broadcast, then the next panel, then the rest under the exchange
         // (one rank: nothing to exchange — the whole update hides the chain, the next panel is solved after it, as chol.h does)
         const int64_t rest = nblk_ - (k + 2);
-        const int64_t m = G_ == 1 ? nblk_ : std::min<int64_t>(nblk_, k + 2 + std::max<int64_t>(rest > 0 ? 1 : 0, (rest + u2a_div_ - 1) / u2a_div_));
+        int64_t m = nblk_;
+        if (G_ > 1 && u2a_div_ > 0) {
+            m = std::min<int64_t>(nblk_, k + 2 + std::max<int64_t>(rest > 0 ? 1 : 0, (rest + u2a_div_ - 1) / u2a_div_));
+        } else if (G_ > 1) {
+            // block columns k+2 .. m-1: enough flops (every rank's share of column c: (nblk - c) / G blocks of rows x WD x WD x 2) to keep the
+            // update kernel busy for u2a_cover_s_ at ~55 (fp64) / ~110 (fp32) TFLOP/s; the same m on every rank
+            const double need = u2a_cover_s_ * (es_ == 8 ? 55e12 : 110e12);
+            double got = 0.0;
+            m = k + 2;
+            while (m < nblk_) {
+                got += 2.0 * ((double)(nblk_ - m) * (double)WD_ / (double)G_) * (double)WD_ * (double)WD_;
+                ++m;
+                if (got >= need) break;
+            }
+        }
         dev_->use(DS_UPD);
         dev_->phase(GPMI_PROF_STEP_U2A, true);
         if (G_ == 1)

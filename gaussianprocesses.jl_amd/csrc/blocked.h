@@ -111,9 +111,13 @@ class BlockedGP {
     double* dfull_ = nullptr;
     int64_t dfull_cap_ = 0;
     int comm_rc_ = 0;
-    int u2a_div_ = 2;  // U2a (the part of a step's update that hides the chain and the inverse broadcast) = 1 / u2a_div_ of the remaining block
-                       // columns; the panel exchange hides under the rest.  Two CU partitions, N = 32 768: 367 / 362 / 344 ms for 4 / 3 / 2
-                       // (profiles/r04_i_partitions.log)
+    // U2a = the part of a step's update that hides the chain and the inverse broadcast; the panel exchange hides under the rest (U2b), so U2a
+    // should be just long enough.  Rounds 3-4: a fixed half of the remaining block columns (u2a_div_ = 2: 367 / 362 / 344 ms for 4 / 3 / 2 on
+    // two CU partitions at N = 32 768 with the 3.5 ms multi-launch chain, profiles/r04_i_partitions.log) — but half of the COLUMNS of a lower
+    // staircase is three quarters of its area, which left the exchange a quarter of the update to hide under.  Round 5: as many block columns
+    // as cover the chain kernel's ~1.1 ms (x (WD / 1024)^2) plus the broadcast at the update kernel's rate, counted in flops.
+    int u2a_div_ = 0;            // > 0: the fixed fraction again (GPMI_BLOCKED_U2A, tools builds)
+    double u2a_cover_s_ = 0.0;   // seconds of update that U2a must hold (set in the constructor from WD)
 };
 
 }  // namespace gpmi

@@ -360,9 +360,9 @@ inline int cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, in
         return (T*)c->sup_lw;
     };
 
-    // the first diagonal block is the one chain with nothing to hide behind: optionally a narrower first panel gets the pipeline going sooner
-    const int64_t w_first = (c->first_width >= NB && c->first_width < w0 && npad >= 4 * w0) ? c->first_width : w0;
-    int64_t ks = 0, ke = std::min<int64_t>(w_first, npad);
+    // (a narrower FIRST super-panel — its chain is the one with nothing to hide behind — measured neutral: 1024 first 61.7 against 61.9 – 62.1 ms
+    //  at N = 20 000, 678.5 against 678.4 – 680.2 at N = 50 000; 512 / 256 first lose 2 – 3 ms.  profiles/r05_g_*)
+    int64_t ks = 0, ke = std::min<int64_t>(w0, npad);
     const T* LW = nullptr;  // inverse of the diagonal block of the current super-panel [ks, ke), or null
     int64_t wld = 0;
     if (by_inverse(ke) && Mtot > ke) LW = place(0, ke, &wld);

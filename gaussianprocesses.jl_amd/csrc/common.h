@@ -165,7 +165,6 @@ struct gpmi_ctx {
     int chain_nb_max = 32;               // blocks of up to 32 x 64 = 2048 columns
     int chain_wgs_max = 64;              // workgroups of a chain launch that has the device to itself (the first block, serial tails)
     int chain_wgs = 0;                   // > 0: the number of workgroups of EVERY chain launch (GPMI_CHAIN_WGS: test hook)
-    int64_t first_width = 0;             // > 0: the FIRST super-panel is only this wide (its chain has nothing to hide behind; GPMI_FIRST: experiment)
     int64_t tail_fuse = 2048;            // the LAST rows of a factorisation (at most this many) are ONE diagonal block: one chain launch instead of a
                                          // dozen 256-wide panels with their updates (GPMI_TAIL_FUSE; 0 = off; needs the chain kernel)
     hipStream_t own_stream = nullptr;    // the stream created with the context

@@ -156,10 +156,15 @@ def _run_threads(world, body):
 
 @pytest.mark.parametrize("world,n,block,stripes", [(2, 700, 0, 0), (3, 1300, 0, 0), (2, 2100, 256, 2), (4, 2600, 256, 0), (3, 2500, 512, 0),
                                                    (5, 900, 0, 0)])
-def test_virtual_ranks(world, n, block, stripes):
+def test_virtual_ranks(world, n, block, stripes, monkeypatch):
     """(5, 900): more ranks than blocks — a rank that owns nothing still takes part in every collective."""
     x, y, xs = _problem(n)
     H.build()
+    # U2a (the part of a step's update that hides the chain) is sized in flops (blocked.cpp): at these sizes it would always be the whole
+    # update and U2b — the part that hides the panel exchange — empty.  Every other case asks for the minimum (one block column) instead,
+    # so that both shapes of the split are exercised.
+    if (n // 100) % 2 == 1:
+        monkeypatch.setenv("GPMI_BLOCKED_U2A_US", "0")
 
     def body(comm):
         gp = H.HostBlockedGP(SPEC, x, y, LN, mean_const=0.2, comm=comm, block=block, stripe_blocks=stripes)

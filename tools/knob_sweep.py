@@ -7,7 +7,7 @@ import numpy as np
 import gpmi355x as g
 from gpmi355x import dist as gd
 
-KNOBS = ("GPMI_SUPER", "GPMI_CUMASK_BELOW", "GPMI_LOOKAHEAD_MIN", "GPMI_TAIL_FUSE", "GPMI_CHAIN", "GPMI_CHAIN_WGS", "GPMI_UPDATE256_MIN", "GPMI_FIRST")
+KNOBS = ("GPMI_SUPER", "GPMI_CUMASK_BELOW", "GPMI_LOOKAHEAD_MIN", "GPMI_TAIL_FUSE", "GPMI_CHAIN", "GPMI_CHAIN_WGS", "GPMI_UPDATE256_MIN")
 
 def synth(n, d, p, seed=20240501):
     rng = np.random.default_rng(seed)
@@ -46,9 +46,6 @@ if __name__ == "__main__":
                 {"GPMI_LOOKAHEAD_MIN": 2048}, {"GPMI_LOOKAHEAD_MIN": 1536, "GPMI_SUPER": "2048,6144,24576"},
                 {"GPMI_TAIL_FUSE": 1024}, {"GPMI_TAIL_FUSE": 1536}, {"GPMI_UPDATE256_MIN": 512}, {"GPMI_UPDATE256_MIN": 256, "GPMI_CUMASK_BELOW": 0}]
         for e in cfgs: run(n, e)
-    elif mode == "first":
-        for e in ({}, {"GPMI_FIRST": 512}, {"GPMI_FIRST": 1024}, {"GPMI_FIRST": 256}, {}):
-            run(n, e, reps=4)
     elif mode == "fine":
         for sup in ("2048,6144,16384", "2048,6144,12288", "2048,4096,12288", "1024,4096,12288", "2048,5120,10240", "1536,4096,8192"):
             for below in (32768, 0):
