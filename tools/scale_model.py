@@ -5,7 +5,7 @@ rounds: everything below is a PREDICTION from single-device measurements, valida
 blocked handle on one rank, and a model sharded over the two CU partitions of one device).
 
 The pipeline of one block step k on every rank (blocked.cpp), W = rows per block, G ranks, R = rows below block k:
-    UPD stream :  U1 (next diagonal block, block column k+1)  ->  U2a  ->  solve of panel k+1 (needs LW_{k+1})  ->  U2b
+    UPD stream :  U1 (next diagonal block, block column k+1)  ->  U2a (sized to cover chain + broadcast)  ->  solve of panel k+1 (needs LW_{k+1})  ->  U2b (the rest)
     SIDE stream:  chain(k+1) = factor + explicit inverse of the next diagonal block, after U1's diagonal part (its owner only)
     COMM stream:  broadcast LW_{k+1} after the chain;  all-gather of panel k+1 after the solve (next step's U1 waits for it)
     step  ~=  max(U1 + U2a,  U1diag + chain + bcast)  +  solve  +  max(U2b, gather)
@@ -35,7 +35,7 @@ def update_time(rows, cols_lo, cols_hi, K, es, p, lower=True):
     return rounds * t_tile + p["launch_s"]
 
 
-def step_model(N, W, G, es, p, u2a_div=2):
+def step_model(N, W, G, es, p):
     nblk = math.ceil(N / W)
     tot = 0.0
     parts = {"update": 0.0, "chain_exposed": 0.0, "solve": 0.0, "gather_exposed": 0.0, "head": 0.0}
@@ -53,9 +53,10 @@ def step_model(N, W, G, es, p, u2a_div=2):
         # U1: next diagonal block (its owner) + block column k+1 of the own rows
         t_u1diag = 2.0 * W * W * W / 2 / (p["R_small"][es] * 1e12) + p["launch_s"]
         t_u1 = t_u1diag + (update_time(own, 0, W, W, es, p, lower=False) if G > 1 else 0.0)
-        c_a = W + (cols - W) / u2a_div if G > 1 else cols
-        t_u2a = update_time(own, W, c_a, W, es, p)
-        t_u2b = update_time(own, c_a, cols, W, es, p) if G > 1 else 0.0
+        # U2a: just enough of the update to cover the chain kernel + the broadcast (blocked.cpp u2a_cover_s_), U2b: the rest
+        t_upd = update_time(own, W, cols, W, es, p)
+        t_u2a = t_upd if G == 1 else min(t_upd, p["u2a_cover_s"](W))
+        t_u2b = 0.0 if G == 1 else max(0.0, t_upd - t_u2a)
         own_next = max(0.0, (R - W) / G)
         t_solve = (own_next * W * W) / (p["R_solve"][es] * 1e12) + p["launch_s"]
         t_b = p["bcast_s"](W, es, G) if G > 1 else 0.0
@@ -99,6 +100,7 @@ def params(chain_ms, partitions=False):
         "link_Bps": link,
         "hbm_Bps": 4.0e12,
         "allreduce_small_s": 30e-6,
+        "u2a_cover_s": lambda W: 1.1e-3 * (W / 1024.0) ** 2 + 0.4e-3,
         # RCCL ring all-gather: (G - 1) hops of one block over one link; broadcast of W x W: a ring / tree pipelined over ~2 link times
         "gather_s": lambda rows, W, es, G: lat + (G - 1) * rows * W * es / link,
         "bcast_s": lambda W, es, G: lat + 2.0 * W * W * es / link,
