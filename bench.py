@@ -266,10 +266,14 @@ def run_workload(g, ctx, n, d, p, dtype, steps, warmup, barrier, comm=None, shar
     # events (attached to the dispatch: hipExtLaunchKernelGGL start / stop events).  Marker events around EVERY other profiled launch —
     # thousands per fit for the chain kernels — cost 4 ms of a 69 ms step at N = 20 000, so the stage times are taken over the warm-up
     # steps and the timed steps bracket the roofline kernel only.  One measured exception: in the free-slot look-ahead mode (factorisations
-    # of >= 32 768 rows) events on the update alone cost MORE than events everywhere (N = 50 000 fit: none 652, everywhere 657, update
+    # of >= 18 432 rows since round 5; N = 20 000 bracketed on the update alone: 81.6 ms per step against 61 – 62 un-instrumented) events on
+    # the update alone cost MORE than events everywhere (N = 50 000 fit: none 652, everywhere 657, update
     # only 665 ms — the markers on the side stream's chain kernels evidently help the chain along once the update's dispatch carries a
     # completion signal), so those workloads keep every class bracketed, as in rounds 1 and 2.
-    syrk_only = (not sharded) and n < 32768
+    syrk_only = (not sharded) and n < 18432
+    how = os.environ.get("GPMI_BENCH_PROFILE", "")   # measurement study: "none" = no event in the timed region (no roofline then), "all", "syrk"
+    if how in ("all", "syrk"):
+        syrk_only = how == "syrk"
     stage = None
     if warmup > 0:
         ctx.profile_enable(True)
@@ -277,7 +281,9 @@ def run_workload(g, ctx, n, d, p, dtype, steps, warmup, barrier, comm=None, shar
         step(i)
     if warmup > 0:
         stage = {name: ctx.profile_get(getattr(g._lib, "PROF_" + name)) for name in ("SYRK", "COV", "PANEL", "SOLVE", "PREDICT")}
-    if syrk_only:
+    if how == "none":
+        ctx.profile_enable(False)
+    elif syrk_only:
         ctx.profile_enable(True, only=g._lib.PROF_SYRK)
     else:
         ctx.profile_enable(True)
@@ -332,16 +338,15 @@ def roofline_object(args, res, n, d, p, dtype, steps, ctx=None):
             samples.extend(ctx.mfma_peak(bits) for _ in range(3))
             best = max(samples)
             extra = {"peak_measured": best, "frac_of_measured": achieved / best, "peak_measured_samples": [round(v, 2) for v in samples],
-                     "peak_measured_note": "gpmi_mfma_peak of this run (back-to-back v_mfma_*_16x16x4 on every SIMD, 16 waves per CU), sampled before "
-                                           "the first fit and after the timed steps; the best sample.  A bare MFMA loop is power-limited differently "
-                                           "from the update kernel: samples below `achieved` mean the chip clocked the micro-benchmark down, not that "
-                                           "the kernel beat the hardware"}
+                     "peak_measured_note": "gpmi_mfma_peak of this run (back-to-back v_mfma_*_16x16x4 on every SIMD: 8 waves per CU, 16 independent "
+                                           "accumulator tiles per wave — the update kernels' own register shape), sampled before the first fit and "
+                                           "after the timed steps; the best sample"}
         except Exception:  # noqa: BLE001
             extra = {}
     return {
         **extra,
-        "kernel": "Cholesky trailing update, K = super-panel width, v_mfma_f64_16x16x4: update256_kernel<T> (256x128 tiles, the big launches of "
-                  "factorisations of >= 32768 rows) + gemm_nt_kernel<T, 0, 4> (128x128 tiles, the others); all launches of the class are averaged",
+        "kernel": "Cholesky trailing update, K = super-panel width, v_mfma_f64_16x16x4: update256_kernel<T> (256x128 tiles: launches of >= 1024 tiles "
+                  "in factorisations of >= 18432 rows) + gemm_nt_kernel<T, 0, 4> (128x128 tiles, the others); all launches of the class are averaged",
         "bound": "mfma",
         "achieved": achieved,
         "peak": peak,
