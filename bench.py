@@ -338,9 +338,12 @@ def roofline_object(args, res, n, d, p, dtype, steps, ctx=None):
             samples.extend(ctx.mfma_peak(bits) for _ in range(3))
             best = max(samples)
             extra = {"peak_measured": best, "frac_of_measured": achieved / best, "peak_measured_samples": [round(v, 2) for v in samples],
-                     "peak_measured_note": "gpmi_mfma_peak of this run (back-to-back v_mfma_*_16x16x4 on every SIMD: 8 waves per CU, 16 independent "
-                                           "accumulator tiles per wave — the update kernels' own register shape), sampled before the first fit and "
-                                           "after the timed steps; the best sample"}
+                     "peak_measured_note": "gpmi_mfma_peak of this run: a bare loop of v_mfma_*_16x16x4 on every SIMD, sampled before the first fit "
+                                           "and after the timed steps; the best sample.  For fp64 it is NOT a ceiling: the bare loop (same operand "
+                                           "registers in every product) issues one instruction per 140 - 200 cycles and reaches ~48 TFLOP/s for any number "
+                                           "of accumulators, while the update kernel sustains more with the PMC showing 64 busy cycles per instruction "
+                                           "(profiles/r01_mfma_bench_instruction_ceilings.log, r05_bench_pmc_hbm.json): `frac` (against the 78.6 TFLOP/s "
+                                           "of 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz) is the roofline fraction"}
         except Exception:  # noqa: BLE001
             extra = {}
     return {

@@ -39,6 +39,7 @@ __device__ __forceinline__ void st_flag(unsigned* p, unsigned v) { __hip_atomic_
 constexpr int CH_TASK = 0;    // next task index
 constexpr int CH_ABORT = 1;   // 1: a pivot failed (tasks after it publish without computing), 2: a wait timed out
 constexpr int CH_HDR = 4;
+// (the word BEHIND the zeroed area — chain_started_word() — counts the workgroups of ALL chain launches that have come up: never reset)
 // then: FL[nb * nb] (L tile final), FX[nb * nb] (X tile final), CL[nb] (finished tiles of L column k), CX[nb] (finished tiles of X row r)
 
 constexpr int LD = 65;  // leading dimension of the 64 x 64 LDS tiles (as the panel kernels)
@@ -197,6 +198,7 @@ struct ChainArgs {
     int* info;
     int64_t pivot_base;
     unsigned* sync;
+    unsigned* started;  // monotonic count of chain workgroups that have started (chain_wait_kernel)
 };
 
 template <typename T>
@@ -260,6 +262,7 @@ __global__ __launch_bounds__(256, 2) void chain_block_kernel(ChainArgs<T> a) {
     unsigned* const CL = FX + nb * nb;
     unsigned* const CX = CL + nb;
     if (tid == 0) {
+        __hip_atomic_fetch_add((gu32*)a.started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // "this workgroup holds a compute unit now"
         sh.wmL = 0;
         sh.wmX = 1;  // row 0 of X has no off-diagonal tile
         sh.abort = 0;
@@ -455,18 +458,43 @@ __global__ __launch_bounds__(256, 2) void chain_block_kernel(ChainArgs<T> a) {
     }
 }
 
+// One wavefront on the UPDATE's stream, in front of a trailing update that a chain launch on another (unmasked) stream is meant to run
+// beside: returns when all `expect` chain workgroups launched so far have come up (or after ~100 us).  Without it the two launches
+// race for compute units, and the dispatcher queues a chain workgroup on a shader engine whose compute units the update has just taken —
+// where it stays until the update ends, although another engine of the same XCD has the free one: measured 2 of 8 chain workgroups resident
+// on average (14 ms per 2048 block instead of 4; hidden at N = 50 000, exposed at N = 20 000 — and WHICH workgroups lose the lottery moved
+// with the instrumentation of the run: 61 ms per step un-instrumented, 82 with events on the update).  With the chain placed first on the
+// idle chip it is the update whose last workgroups may wait for the chain's few milliseconds: a persistent kernel with a tile queue does
+// not care.
+__global__ void chain_wait_kernel(const unsigned* started, unsigned expect) {
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();  // 100 MHz
+    while ((int)(ld_flag(started) - expect) < 0) {
+        if (wall_clock64() - t0 > 10000) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
 }  // namespace
 
-// bytes of the synchronisation area for blocks of up to nb_max tiles per side
-int64_t chain_sync_bytes(int nb_max) { return (int64_t)(CH_HDR + 2 * nb_max * nb_max + 2 * nb_max) * 4; }
+// bytes of the synchronisation area for blocks of up to nb_max tiles per side (+ the never-reset `started` word behind the zeroed part)
+static int64_t chain_zeroed_words(int nb) { return (int64_t)CH_HDR + 2 * (int64_t)nb * nb + 2 * nb; }
+int64_t chain_sync_bytes(int nb_max) { return (chain_zeroed_words(nb_max) + 16) * 4; }
+
+void launch_chain_wait(gpmi_ctx* ctx) {
+    if (!ctx->chain_sync || !ctx->chain_wait_pending) return;
+    ctx->chain_wait_pending = false;
+    const unsigned* started = (const unsigned*)ctx->chain_sync + chain_zeroed_words(ctx->chain_nb_max);
+    hipLaunchKernelGGL(chain_wait_kernel, dim3(1), dim3(64), 0, ctx->stream, started, ctx->chain_started_expect);
+}
 
 template <typename T>
 bool launch_chain_block(gpmi_ctx* ctx, T* A, int64_t ld, int64_t w, T* linv, T* invdiag, T* LW, int64_t wld, int* info, int64_t pivot_base) {
     if (!ctx->chain_kernel || ctx->refine_solves || w % 64 != 0 || w <= 0 || w > (int64_t)ctx->chain_nb_max * 64 || !ctx->chain_sync) return false;
     const int nb = (int)(w / 64);
     unsigned* sync = (unsigned*)ctx->chain_sync;
-    (void)hipMemsetAsync(sync, 0, (size_t)chain_sync_bytes(nb), ctx->stream);
-    ChainArgs<T> a{A, ld, nb, linv, invdiag, LW, wld, info, pivot_base, sync};
+    (void)hipMemsetAsync(sync, 0, (size_t)chain_zeroed_words(nb) * 4, ctx->stream);
+    ChainArgs<T> a{A, ld, nb, linv, invdiag, LW, wld, info, pivot_base, sync, sync + chain_zeroed_words(ctx->chain_nb_max)};
     // workgroups: what fits beside the trailing update (chol.h beside_update: the reserved compute units / free slots), otherwise enough
     // for the tasks of one step (nb) with one workgroup per compute unit
     int64_t g = ctx->beside_update ? side_slots(ctx) : std::max<int64_t>(8, std::min<int64_t>(2 * nb, ctx->chain_wgs_max));
@@ -475,6 +503,9 @@ bool launch_chain_block(gpmi_ctx* ctx, T* A, int64_t ld, int64_t w, T* linv, T* 
     const double flops = (LW ? 2.0 : 1.0) * (double)w * (double)w * (double)w / 3.0;
     ProfScope ps(ctx, GPMI_PROF_PANEL, flops, 0.0, false, /*chain_kernel=*/false);
     hipLaunchKernelGGL(chain_block_kernel<T>, dim3((unsigned)g), dim3(256), 0, ctx->stream, a);
+    ctx->chain_started_expect += (unsigned)g;
+    // beside an update on an UNMASKED stream the update's launch first waits for these workgroups to be placed (chain_wait_kernel)
+    ctx->chain_wait_pending = ctx->beside_update && ctx->la_mode != 1;
     return true;
 }
 template bool launch_chain_block<double>(gpmi_ctx*, double*, int64_t, int64_t, double*, double*, double*, int64_t, int*, int64_t);

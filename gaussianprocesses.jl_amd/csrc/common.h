@@ -165,6 +165,8 @@ struct gpmi_ctx {
     int chain_nb_max = 32;               // blocks of up to 32 x 64 = 2048 columns
     int chain_wgs_max = 64;              // workgroups of a chain launch that has the device to itself (the first block, serial tails)
     int chain_wgs = 0;                   // > 0: the number of workgroups of EVERY chain launch (GPMI_CHAIN_WGS: test hook)
+    unsigned chain_started_expect = 0;   // workgroups of all chain launches so far (what the never-reset `started` word counts up to)
+    bool chain_wait_pending = false;     // the next trailing update on an unmasked stream first waits for the last chain launch's workgroups to be placed
     int64_t tail_fuse = 2048;            // the LAST rows of a factorisation (at most this many) are ONE diagonal block: one chain launch instead of a
                                          // dozen 256-wide panels with their updates (GPMI_TAIL_FUSE; 0 = off; needs the chain kernel)
     hipStream_t own_stream = nullptr;    // the stream created with the context
@@ -368,6 +370,7 @@ void launch_place_inv_blocks(gpmi_ctx* ctx, const T* l256, T* LW, T* LWT, int64_
 template <typename T>
 bool launch_chain_block(gpmi_ctx* ctx, T* A, int64_t ld, int64_t w, T* linv, T* invdiag, T* LW, int64_t wld, int* info, int64_t pivot_base);
 int64_t chain_sync_bytes(int nb_max);
+void launch_chain_wait(gpmi_ctx* ctx);  // on ctx->stream, when a chain launch is pending beside it (no-op otherwise)
 template <typename T>
 void launch_bsolve256(gpmi_ctx* ctx, const T* Arow, int64_t ld, int64_t k0, int nbk, const T* linv256, T* z, T* alpha,
                       int64_t ldinv = NB);  // ldinv: row stride of the NB x NB inverse (a diagonal block of a wider explicit inverse)

@@ -253,6 +253,8 @@ struct HipDev : Dev {
     void gemm(void* C, int64_t ldc, const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, DevShape s,
               int flags) override {
         if (M <= 0 || N <= 0 || K <= 0) return;
+        // free-slot mode: the update that a chain launch is to run beside waits until the chain's workgroups are placed (chain.hip)
+        if (c->chain_wait_pending && c->stream == main_s && !c->beside_update) launch_chain_wait(c);
         TileShape sh{0, 0, s.mode, s.g0, s.G, s.nstair, s.tpb > 0 ? s.tpb : 2};
         launch_gemm_shape<T>(c, (T*)C, ldc, (const T*)A, lda, (const T*)B, ldb, M, N, K, sh, c->d_info, flags);
     }
