@@ -210,7 +210,7 @@ __device__ __forceinline__ void product64(typename Mfma<T>::Acc (&acc)[2][2], co
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) mma16_nt<T>(acc[mi][ni], a + (wm * 32 + mi * 16) * LD, LD, b + (wn * 32 + ni * 16) * LD, LD, 64, lane);
 }
-// accumulators -> LDS tile; TRANSPOSE: buf[col][row]; v = sgn * acc (+ add[row][col] when ADD, read from global in the accumulator layout)
+// accumulators -> LDS tile (leading dimension LD); TRANSPOSE: buf[col][row]; every element multiplied by sgn (1 or -1)
 template <typename T, bool TRANSPOSE>
 __device__ __forceinline__ void acc_to_lds(T* buf, const typename Mfma<T>::Acc (&acc)[2][2], T sgn) {
     using MF = Mfma<T>;
