@@ -16,6 +16,7 @@
 // (s_waitcnt vmcnt(0)), __syncthreads(), then one lane stores the flag (sc1); readers poll the flag relaxed and read the tile with sc1 loads
 // (L1 bypassed) — no fences, no L2 write-back / invalidate that would disturb the trailing update running beside the chain.
 #include "common.h"
+#include "chain_order.h"
 #include "mfma.h"
 #include "potf2.h"
 
@@ -255,8 +256,7 @@ __global__ __launch_bounds__(256, 2) void chain_block_kernel(ChainArgs<T> a) {
     const int wm = wv >> 1, wn = wv & 1;
     const int nb = a.nb;
     const bool inv = a.LW != nullptr;
-    const int per_step = inv ? nb : 0;  // tasks per step with the inverse: nb - c of L and c of X
-    const int ntasks = inv ? nb * nb : nb * (nb + 1) / 2;
+    const int ntasks = chain_ntasks(nb, inv);
     unsigned* const FL = a.sync + CH_HDR;
     unsigned* const FX = FL + nb * nb;
     unsigned* const CL = FX + nb * nb;
@@ -305,22 +305,11 @@ __global__ __launch_bounds__(256, 2) void chain_block_kernel(ChainArgs<T> a) {
         const bool aborted = __builtin_amdgcn_readfirstlane(sh.abort) != 0;
         __syncthreads();  // (sh is rewritten at the top of the next iteration)
         if (t >= ntasks) break;
-        // ---- decode: step c, then L(i, c) for i = c .. nb-1, then X(c, j) for j = 0 .. c-1 ----
-        int c, q;
-        if (inv) {
-            c = t / per_step;
-            q = t - c * per_step;
-        } else {
-            c = 0;
-            q = t;
-            while (q >= nb - c) {
-                q -= nb - c;
-                ++c;
-            }
-        }
-        const bool is_x = q >= nb - c;
-        const int i = is_x ? c : c + q;          // output tile row
-        const int j = is_x ? q - (nb - c) : c;   // output tile column
+        // ---- decode (chain_order.h: step c lists L(c .. nb-1, c), then X(c, 0 .. c-1); the order is topological — tests/test_chain_order.py) ----
+        const ChainTask task = chain_decode(t, nb, inv);
+        const bool is_x = task.is_x != 0;
+        const int i = task.i, j = task.j;  // output tile row / column
+        const int c = is_x ? i : j;        // the step
         unsigned* const my_flag = (is_x ? FX : FL) + i * nb + j;
         unsigned* const my_count = is_x ? CX + i : CL + j;
         if (aborted) {  // a pivot failed / a wait timed out: publish so that nobody waits, compute nothing
