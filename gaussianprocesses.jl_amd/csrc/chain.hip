@@ -17,6 +17,10 @@
 // (L1 bypassed) — no fences, no L2 write-back / invalidate that would disturb the trailing update running beside the chain.
 #include "common.h"
 #include "chain_order.h"
+#ifdef GPMI_CHAIN_TRACE
+#include <string>
+#include <vector>
+#endif
 #include "mfma.h"
 #include "potf2.h"
 
@@ -161,30 +165,32 @@ struct ChainShared {
 
 // Wait (every wave for itself: wave-uniform, no barrier) until *flag is set.  Bounded: after ~4 s of polling the launch is declared dead
 // (CH_ABORT = 2, *info = INT_MIN: gpmi_fit returns GPMI_EDEVICE) and every wait returns at once.
-__device__ __forceinline__ void wait_flag(const unsigned* flag, unsigned* sync, int* info) {
+__device__ __forceinline__ void wait_flag(const unsigned* flag, unsigned* sync, int* info, unsigned long long* waited = nullptr) {
     if (ld_flag(flag) != 0u) return;
+    const unsigned long long t0 = waited ? wall_clock64() : 0ull;  // (trace builds only: nullptr is a compile-time constant in the product)
     for (unsigned spins = 0;; ++spins) {
         __builtin_amdgcn_s_sleep(4);
-        if (ld_flag(flag) != 0u) return;
+        if (ld_flag(flag) != 0u) break;
         if ((spins & 63u) == 63u) {
-            if (ld_flag(sync + CH_ABORT) != 0u) return;
+            if (ld_flag(sync + CH_ABORT) != 0u) break;
             if (spins > (1u << 22)) {
                 if ((threadIdx.x & 63) == 0) {
                     st_flag(sync + CH_ABORT, 2u);
                     __hip_atomic_store((__attribute__((address_space(1))) int*)info, (int)0x80000000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                return;
+                break;
             }
         }
     }
+    if (waited) *waited += wall_clock64() - t0;
 }
 
 // two flags at once: both loads are in flight together (one round trip when both are already set)
-__device__ __forceinline__ void wait_flags2(const unsigned* fa, const unsigned* fb, unsigned* sync, int* info) {
+__device__ __forceinline__ void wait_flags2(const unsigned* fa, const unsigned* fb, unsigned* sync, int* info, unsigned long long* waited = nullptr) {
     const unsigned a = ld_flag(fa), b = ld_flag(fb);
     if (a != 0u && b != 0u) return;
-    if (a == 0u) wait_flag(fa, sync, info);
-    if (b == 0u) wait_flag(fb, sync, info);
+    if (a == 0u) wait_flag(fa, sync, info, waited);
+    if (b == 0u) wait_flag(fb, sync, info, waited);
 }
 
 template <typename T>
@@ -200,16 +206,54 @@ struct ChainArgs {
     int64_t pivot_base;
     unsigned* sync;
     unsigned* started;  // monotonic count of chain workgroups that have started (chain_wait_kernel)
+#ifdef GPMI_CHAIN_TRACE
+    unsigned long long* trace;  // tools/chain_trace.py: 8 words per task (100 MHz clock marks), or nullptr
+#endif
 };
 
+// Task timeline of tools/chain_trace.py — compiled in only with -DGPMI_CHAIN_TRACE (tools/build_chain_trace.sh; never in libgpmi.so):
+// CH_TR(slot) stores the 100 MHz clock (s_memrealtime: ~1 us each — only at task phase boundaries and in the slow path of a wait).
+#ifdef GPMI_CHAIN_TRACE
+#define CH_TR(slot)                                                                      \
+    do {                                                                                 \
+        if (a.trace && threadIdx.x == 0) a.trace[(int64_t)t * 8 + (slot)] = wall_clock64(); \
+    } while (0)
+#define CH_TW , &tr_wait  // the flag waits add the time of their SLOW path (flag not yet set) to the task's wait total
+#define CH_TR_END()                                                                                   \
+    do {                                                                                              \
+        if (a.trace && threadIdx.x == 0) {                                                            \
+            a.trace[(int64_t)t * 8 + 5] = tr_wait;                                                    \
+            a.trace[(int64_t)t * 8 + 6] = ((unsigned long long)blockIdx.x << 8) | (unsigned long long)(__smid() & 0xff); \
+            a.trace[(int64_t)t * 8 + 7] = ((unsigned long long)is_x << 16) | ((unsigned long long)i << 8) | (unsigned long long)j; \
+        }                                                                                             \
+    } while (0)
+#else
+#define CH_TR(slot) ((void)0)
+#define CH_TW
+#define CH_TR_END() ((void)0)
+#endif
+
+// acc[mi][ni] += a[rows mi] b[rows ni]' over one 64-deep slab: each wave's 32 x 32 quadrant as 2 x 2 MFMA tiles.  Per k-step the two A
+// and the two B fragments are read ONCE and feed four MFMAs (mma16_nt per tile would read each fragment twice), and the 16 steps are
+// unrolled so that the LDS reads run ahead of the MFMAs: one wave per SIMD has nothing else to hide their latency behind.  Every tile
+// still accumulates k = 0, 4, 8, ... in order: the same bits as four mma16_nt calls.
 template <typename T>
 __device__ __forceinline__ void product64(typename Mfma<T>::Acc (&acc)[2][2], const T* a, const T* b) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wm = wv >> 1, wn = wv & 1;
+    const T* ap = a + (wm * 32 + (lane & 15)) * LD + (lane >> 4);  // fragment element of tile mi = 0; mi = 1: 16 rows further down
+    const T* bp = b + (wn * 32 + (lane & 15)) * LD + (lane >> 4);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) mma16_nt<T>(acc[mi][ni], a + (wm * 32 + mi * 16) * LD, LD, b + (wn * 32 + ni * 16) * LD, LD, 64, lane);
+    for (int kk = 0; kk < 64; kk += 4) {
+        const T a0 = ap[kk], a1 = ap[16 * LD + kk];
+        T b0[4], b1[4];
+        Mfma<T>::rotations(bp[kk], b0);
+        Mfma<T>::rotations(bp[16 * LD + kk], b1);
+        Mfma<T>::mma(a0, b0, acc[0][0]);
+        Mfma<T>::mma(a0, b1, acc[0][1]);
+        Mfma<T>::mma(a1, b0, acc[1][0]);
+        Mfma<T>::mma(a1, b1, acc[1][1]);
+    }
 }
 // accumulators -> LDS tile (leading dimension LD); TRANSPOSE: buf[col][row]; every element multiplied by sgn (1 or -1)
 template <typename T, bool TRANSPOSE>
@@ -312,6 +356,10 @@ __global__ __launch_bounds__(256, 2) void chain_block_kernel(ChainArgs<T> a) {
         const int c = is_x ? i : j;        // the step
         unsigned* const my_flag = (is_x ? FX : FL) + i * nb + j;
         unsigned* const my_count = is_x ? CX + i : CL + j;
+#ifdef GPMI_CHAIN_TRACE
+        unsigned long long tr_wait = 0;
+#endif
+        CH_TR(0);
         if (aborted) {  // a pivot failed / a wait timed out: publish so that nobody waits, compute nothing
             publish(my_flag, my_count);
             continue;
@@ -343,9 +391,9 @@ __global__ __launch_bounds__(256, 2) void chain_block_kernel(ChainArgs<T> a) {
             auto fetch = [&](int k) {
                 if (k >= wmL) {
                     if (diag)
-                        wait_flag(FL + i * nb + k, a.sync, a.info);
+                        wait_flag(FL + i * nb + k, a.sync, a.info CH_TW);
                     else
-                        wait_flags2(FL + i * nb + k, FL + c * nb + k, a.sync, a.info);
+                        wait_flags2(FL + i * nb + k, FL + c * nb + k, a.sync, a.info CH_TW);
                 }
                 tile_fetch<T, true>(ra, a.A + (int64_t)(i * 64) * a.ld + k * 64, adA);
                 if (!diag) tile_fetch<T, true>(rb, a.A + (int64_t)(c * 64) * a.ld + k * 64, adA);
@@ -355,6 +403,7 @@ __global__ __launch_bounds__(256, 2) void chain_block_kernel(ChainArgs<T> a) {
                 tile_publish<T, false>(buf1, ra);
                 if (!diag) tile_publish<T, false>(buf2, rb);
                 __syncthreads();
+                if (k == 0) CH_TR(1);
                 // the next slab's loads fly under this slab's product when no wait stands before them (old, complete columns); at the front
                 // the product goes first — it needs nothing that is still being computed — and the wait after it
                 const bool early = k + 1 < c && k + 1 < wmL;
@@ -364,6 +413,7 @@ __global__ __launch_bounds__(256, 2) void chain_block_kernel(ChainArgs<T> a) {
                 __syncthreads();
             }
             acc_to_lds<T, false>(buf1, acc, T(-1));  // T = A_ic - sum
+            CH_TR(2);
             if (diag) {
                 __syncthreads();
                 int fail = 0;
@@ -372,18 +422,22 @@ __global__ __launch_bounds__(256, 2) void chain_block_kernel(ChainArgs<T> a) {
                     fail = potf2_in_lds<T>(a.invdiag + c * 64, a.info, (long long)(a.pivot_base + (int64_t)c * 64));
                 if (wv == 0 && lane == 0 && fail) st_flag(a.sync + CH_ABORT, 1u);
                 __syncthreads();
+                CH_TR(3);
                 // (on failure the stores below write garbage that nobody uses: *info is set, every later kernel returns at once)
                 T* Lcc = a.A + (int64_t)(c * 64) * a.ld + c * 64;
                 tile_store<T, false, false>(Lcc, adA, buf1);                                   // L_cc, strict upper part zero
                 tile_store<T, true, true>(a.linv + (int64_t)c * 64 * 64, adI, buf2);           // Linv_c = XT'
                 if (inv) tile_store<T, false, true>(a.LW + (int64_t)(c * 64) * a.wld + c * 64, adW, buf2);   // X_cc
                 publish(my_flag, my_count);
+                CH_TR(4);
+                CH_TR_END();
             } else {
                 // ---- L_ic = T Linv_c' ----
-                wait_flag(FL + c * nb + c, a.sync, a.info);
+                wait_flag(FL + c * nb + c, a.sync, a.info CH_TW);
                 tile_fetch<T, true>(ra, a.linv + (int64_t)c * 64 * 64, adI);
                 tile_publish<T, false>(buf2, ra);
                 __syncthreads();
+                CH_TR(3);
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -394,6 +448,8 @@ __global__ __launch_bounds__(256, 2) void chain_block_kernel(ChainArgs<T> a) {
                 __syncthreads();
                 tile_store<T, true, false>(a.A + (int64_t)(i * 64) * a.ld + c * 64, adA, buf1);
                 publish(my_flag, my_count);
+                CH_TR(4);
+                CH_TR_END();
             }
         } else {
             // =============================== X(i, j), i > j ===============================
@@ -409,7 +465,7 @@ __global__ __launch_bounds__(256, 2) void chain_block_kernel(ChainArgs<T> a) {
                 const unsigned* fa = FL + i * nb + k;                                   // L_ik
                 const unsigned* fb = k == j ? FL + j * nb + j : FX + k * nb + j;        // X_jj = Linv_j, or X_kj
                 const bool need_a = k >= wmL, need_b = k == j ? j >= wmL : k >= wmX;
-                if (need_a || need_b) wait_flags2(need_a ? fa : fb, need_b ? fb : fa, a.sync, a.info);
+                if (need_a || need_b) wait_flags2(need_a ? fa : fb, need_b ? fb : fa, a.sync, a.info CH_TW);
                 tile_fetch<T, true>(ra, a.A + (int64_t)(i * 64) * a.ld + k * 64, adA);
                 if (k == j)
                     tile_fetch<T, true>(rb, a.linv + (int64_t)j * 64 * 64, adI);
@@ -421,6 +477,7 @@ __global__ __launch_bounds__(256, 2) void chain_block_kernel(ChainArgs<T> a) {
                 tile_publish<T, false>(buf1, ra);
                 tile_publish<T, true>(buf2, rb);
                 __syncthreads();
+                if (k == j) CH_TR(1);
                 const bool early = k + 1 < i && k + 1 < wmL && k + 1 < wmX;
                 if (early) fetch(k + 1);
                 product64<T>(acc, buf1, buf2);
@@ -429,10 +486,12 @@ __global__ __launch_bounds__(256, 2) void chain_block_kernel(ChainArgs<T> a) {
             }
             // X_ij = -Linv_i W :  A operand Linv_i (rows m, k contiguous), B operand [n][k] = W[k][n]
             acc_to_lds<T, true>(buf2, acc, T(-1));
-            wait_flag(FL + i * nb + i, a.sync, a.info);
+            CH_TR(2);
+            wait_flag(FL + i * nb + i, a.sync, a.info CH_TW);
             tile_fetch<T, true>(ra, a.linv + (int64_t)i * 64 * 64, adI);
             tile_publish<T, false>(buf1, ra);
             __syncthreads();
+            CH_TR(3);
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -443,6 +502,8 @@ __global__ __launch_bounds__(256, 2) void chain_block_kernel(ChainArgs<T> a) {
             __syncthreads();
             tile_store<T, true, false>(a.LW + (int64_t)(i * 64) * a.wld + j * 64, adW, buf1);
             publish(my_flag, my_count);
+            CH_TR(4);
+            CH_TR_END();
         }
     }
 }
@@ -484,6 +545,22 @@ bool launch_chain_block(gpmi_ctx* ctx, T* A, int64_t ld, int64_t w, T* linv, T* 
     unsigned* sync = (unsigned*)ctx->chain_sync;
     (void)hipMemsetAsync(sync, 0, (size_t)chain_zeroed_words(nb) * 4, ctx->stream);
     ChainArgs<T> a{A, ld, nb, linv, invdiag, LW, wld, info, pivot_base, sync, sync + chain_zeroed_words(ctx->chain_nb_max)};
+#ifdef GPMI_CHAIN_TRACE
+    static unsigned long long* tr_dev = nullptr;
+    static long long tr_left = 0, tr_skip = 0;  // (re)read whenever the file variable changes (the tool sets it after each warm-up fit)
+    static std::string tr_name;
+    const char* tr_file = getenv("GPMI_CHAIN_TRACE_FILE");
+    if (tr_file && tr_name != tr_file) {
+        tr_name = tr_file;
+        tr_left = getenv("GPMI_CHAIN_TRACE_LAUNCHES") ? atoll(getenv("GPMI_CHAIN_TRACE_LAUNCHES")) : 1;
+        tr_skip = getenv("GPMI_CHAIN_TRACE_SKIP") ? atoll(getenv("GPMI_CHAIN_TRACE_SKIP")) : 0;
+    }
+    const int64_t tr_words = (int64_t)chain_ntasks(nb, LW != nullptr) * 8;
+    if (!tr_dev) (void)hipMalloc(&tr_dev, (size_t)chain_ntasks(32, true) * 8 * sizeof(unsigned long long));
+    const bool tr_on = tr_file && tr_dev && tr_left > 0 && (tr_skip-- <= 0);
+    a.trace = tr_on ? tr_dev : nullptr;
+    if (tr_on) (void)hipMemsetAsync(tr_dev, 0, (size_t)tr_words * 8, ctx->stream);
+#endif
     // workgroups: what fits beside the trailing update (chol.h beside_update: the reserved compute units / free slots), otherwise enough
     // for the tasks of one step (nb) with one workgroup per compute unit
     int64_t g = ctx->beside_update ? side_slots(ctx) : std::max<int64_t>(8, std::min<int64_t>(2 * nb, ctx->chain_wgs_max));
@@ -492,6 +569,26 @@ bool launch_chain_block(gpmi_ctx* ctx, T* A, int64_t ld, int64_t w, T* linv, T* 
     const double flops = (LW ? 2.0 : 1.0) * (double)w * (double)w * (double)w / 3.0;
     ProfScope ps(ctx, GPMI_PROF_PANEL, flops, 0.0, false, /*chain_kernel=*/false);
     hipLaunchKernelGGL(chain_block_kernel<T>, dim3((unsigned)g), dim3(256), 0, ctx->stream, a);
+#ifdef GPMI_CHAIN_TRACE
+    if (tr_on) {
+        --tr_left;
+        std::vector<unsigned long long> h((size_t)tr_words);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipMemcpy(h.data(), tr_dev, (size_t)tr_words * 8, hipMemcpyDeviceToHost);
+        if (FILE* f = fopen(tr_file, "a")) {
+            unsigned long long pm[8] = {0};
+            (void)hipMemcpyFromSymbol(pm, HIP_SYMBOL(g_potf2_marks), sizeof(pm));
+            fprintf(f, "launch nb %d wgs %lld ld %lld inverse %d beside %d elem %d potf2 %llu %llu %llu %llu\n", nb, (long long)g, (long long)ld, LW ? 1 : 0,
+                    ctx->beside_update ? 1 : 0, (int)sizeof(T), pm[1] - pm[0], pm[2] - pm[1], pm[3] - pm[2], pm[4] - pm[3]);
+            for (int64_t q = 0; q < tr_words / 8; ++q) {
+                fprintf(f, "%lld", (long long)q);
+                for (int m = 0; m < 8; ++m) fprintf(f, " %llu", h[(size_t)(q * 8 + m)]);
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
+    }
+#endif
     ctx->chain_started_expect += (unsigned)g;
     // beside an update on an UNMASKED stream the update's launch first waits for these workgroups to be placed (chain_wait_kernel)
     ctx->chain_wait_pending = ctx->beside_update && ctx->la_mode != 1;

@@ -66,6 +66,17 @@ __device__ __forceinline__ void store16(const typename Mfma<T>::Acc& acc, T* C, 
 // LDS pool of the panel kernels, in elements: diag64 needs S + XT + DI + WT + sinv, rows64 two 64 x 65 buffers (a subset)
 constexpr int PANEL_POOL = 2 * 64 * 65 + 64 * 16 + 16 * 17 + 64;
 
+// phase clock of the trace build (tools/chain_trace.py; never in libgpmi.so): the 100 MHz clock at six points of the LAST potf2 that ran
+#ifdef GPMI_CHAIN_TRACE
+__device__ unsigned long long g_potf2_marks[8];
+#define POTF2_MARK(slot)                                                         \
+    do {                                                                         \
+        if ((threadIdx.x & 63) == 0) g_potf2_marks[slot] = wall_clock64();       \
+    } while (0)
+#else
+#define POTF2_MARK(slot) ((void)0)
+#endif
+
 // barrier of a phase that ONE wavefront executes (diag64): LDS operations of a wave complete in issue order, so a fence that
 // keeps the compiler from moving them (and waits for them) is all a single wave needs — and, unlike __syncthreads(), it does
 // not involve the workgroup's other waves
@@ -91,6 +102,7 @@ __device__ __forceinline__ int diag64_body(T* __restrict__ A, int64_t ld, T* __r
         for (int r = 0; r < 64; ++r) S[r * SLD + i] = A[(int64_t)r * ld + i];  // coalesced rows
         wave_sync();
     }
+    POTF2_MARK(0);
     T a[64];
 #pragma unroll
     for (int c = 0; c < 64; ++c) a[c] = S[i * SLD + c];
@@ -98,7 +110,6 @@ __device__ __forceinline__ int diag64_body(T* __restrict__ A, int64_t ld, T* __r
     // Blocked by 16 columns: inside a block the rank-1 updates stay in registers (<= 15 per step); the rank-16
     // update of everything to the right goes through the matrix cores (panel -> LDS -> P P' tiles -> LDS -> rows).
     int fail = 0;
-    T myinv = T(0);
     using AccP = typename Mfma<T>::Acc;
     T* PL = XT;  // [64][17] panel image (XT is not needed before the inverse phase)
 #pragma unroll
@@ -118,7 +129,9 @@ __device__ __forceinline__ int diag64_body(T* __restrict__ A, int64_t ld, T* __r
             const T inv = r + r * (T(1) - sq * r);        // 1 / sqrt(d)
             const T lij = (i == j) ? sq : a[j] * inv;
             a[j] = lij;
-            if (i == j) myinv = inv;
+            // 1 / L_jj is the same in every lane: lane 0 parks it in LDS.  (Kept per lane as `if (i == j) myinv = inv`, the compiler held all
+            // 64 reciprocals live to the end of the loop and selected there — spills, and a chain of scratch reloads worth ~3 us of the 22.)
+            if (i == 0) sinv[j] = inv;
 #pragma unroll
             for (int c = j + 1; c < 16 * b + 16; ++c) a[c] -= lij * bcast_lane<T>(lij, c);
         }
@@ -144,6 +157,7 @@ __device__ __forceinline__ int diag64_body(T* __restrict__ A, int64_t ld, T* __r
             }
         }
     }
+    POTF2_MARK(1);  // the 64 columns done
     if (fail) {
         if (i == 0) {
             if constexpr (FROM_LDS) {
@@ -156,9 +170,8 @@ __device__ __forceinline__ int diag64_body(T* __restrict__ A, int64_t ld, T* __r
         }
         return fail;
     }
-    invdiag[i] = myinv;
-    sinv[i] = myinv;
     wave_sync();
+    invdiag[i] = sinv[i];
 #pragma unroll
     for (int c = 0; c < 64; ++c) {
         S[i * SLD + c] = (c <= i) ? a[c] : T(0);
@@ -168,6 +181,7 @@ __device__ __forceinline__ int diag64_body(T* __restrict__ A, int64_t ld, T* __r
     if constexpr (!FROM_LDS)
         for (int r = 0; r < 64; ++r) A[(int64_t)r * ld + i] = S[r * SLD + i];  // lower triangle = L, strict upper = 0
 
+    POTF2_MARK(2);  // L (and the zeroed XT) in LDS
     // ---- 16 x 16 diagonal inverses: lane (b, c) computes column c of (L_bb)^-1 ----------------------------
     {
         const int b = i >> 4, c = i & 15;
@@ -186,6 +200,7 @@ __device__ __forceinline__ int diag64_body(T* __restrict__ A, int64_t ld, T* __r
         }
     }
     wave_sync();
+    POTF2_MARK(3);  // the four 16 x 16 inverses
     // ---- off-diagonal blocks, by distance from the diagonal ---------------------------------------------
     using Acc = typename Mfma<T>::Acc;
     for (int dist = 1; dist < 4; ++dist) {
@@ -204,6 +219,7 @@ __device__ __forceinline__ int diag64_body(T* __restrict__ A, int64_t ld, T* __r
             wave_sync();
         }
     }
+    POTF2_MARK(4);  // the six off-diagonal blocks
     if constexpr (!FROM_LDS)
         for (int k = 0; k < 64; ++k) Linv[k * 64 + i] = XT[i * SLD + k];  // Linv[k][n] = XT[n][k]
     return 0;
