@@ -65,3 +65,76 @@ def test_chain_task_order_is_topological_and_complete():
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "gaussianprocesses.jl_amd", "csrc"), src, "-o", exe])
         out = subprocess.check_output([exe]).decode()
     assert out.strip() == "OK 64", out
+
+
+DUMP = r"""
+#include <cstdio>
+#include "chain_order.h"
+int main() {
+    const int sizes[4] = {1, 2, 5, 16};
+    for (int nb : sizes) {
+        const int n = gpmi::chain_ntasks(nb, true);
+        for (int t = 0; t < n; ++t) {
+            const gpmi::ChainTask k = gpmi::chain_decode(t, nb, true);
+            std::printf("%d %c %d %d\n", nb, k.is_x ? 'X' : 'L', k.i, k.j);
+        }
+    }
+    return 0;
+}
+"""
+
+
+def test_queue_model_and_trace_parser_follow_the_kernels_order():
+    """tools/chain_sim.py (the queue model the LABBOOK's order comparison rests on) must model the order the kernel really uses, and
+    tools/chain_trace.py must parse what the trace build writes (a synthetic file in that format)."""
+    import importlib.util
+    import sys
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        argv, sys.argv = sys.argv, [name]
+        try:
+            spec.loader.exec_module(mod)
+        finally:
+            sys.argv = argv
+        return mod
+
+    sim = load("chain_sim")
+    with tempfile.TemporaryDirectory() as td:
+        src, exe = os.path.join(td, "d.cpp"), os.path.join(td, "d")
+        with open(src, "w") as fh:
+            fh.write(DUMP)
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "gaussianprocesses.jl_amd", "csrc"), src, "-o", exe])
+        lines = subprocess.check_output([exe]).decode().split("\n")
+    got = {}
+    for ln in lines:
+        if ln:
+            nb, kind, i, j = ln.split()
+            got.setdefault(int(nb), []).append((kind, int(i), int(j)))
+    for nb, order in got.items():
+        assert order == sim.order_diag_ahead(nb), nb
+        assert sim.check_topological(order, nb)
+        assert not sim.check_topological(order[::-1], nb) or nb == 1
+    # the model itself: more workgroups never make a block slower, the diagonal-ahead list beats the column-by-column one
+    spans = [sim.simulate(sim.order_diag_ahead(16), 16, w) for w in (1, 2, 4, 8, 16, 32)]
+    assert all(a >= b - 1e-9 for a, b in zip(spans, spans[1:])), spans
+    assert sim.simulate(sim.order_diag_ahead(16), 16, 8) < sim.simulate(sim.order_round5_first(16), 16, 8)
+
+    tr = load("chain_trace")
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "t.txt")
+        with open(path, "w") as fh:
+            fh.write("launch nb 2 wgs 2 ld 128 inverse 1 beside 0 elem 8 potf2 900 300 140 350\n")
+            t = 1000
+            for q, (kind, i, j) in enumerate(sim.order_diag_ahead(2)):
+                x = 1 if kind == "X" else 0
+                fh.write(" ".join(map(str, [q, t, t + 100, t + 300, t + 500, t + 600, 50, ((q % 2) << 8) | 3, (x << 16) | (i << 8) | j])) + "\n")
+                t += 400
+        (L,) = tr.parse(path)
+        assert (L["nb"], L["wgs"], L["inverse"], len(L["tasks"])) == (2, 2, 1, 4) and L["potf2"] == [900, 300, 140, 350]
+        assert [(k["is_x"], k["i"], k["j"]) for k in L["tasks"]] == [(0, 0, 0), (0, 1, 0), (0, 1, 1), (1, 1, 0)]
+        import io
+        buf = io.StringIO()
+        tr.report(L, out=buf)
+        assert "span 18.0 us" in buf.getvalue() and "diagonal chain, 1 steps" in buf.getvalue(), buf.getvalue()
