@@ -5,7 +5,8 @@
 //   L(c, c)   potrf:  S = A_cc - sum_{k<c} L_ck L_ck' ;  L_cc = chol(S), Linv_c = L_cc^-1         (potf2.h, one wavefront)
 //   L(i, c)   i > c:  T = A_ic - sum_{k<c} L_ik L_ck' ;  L_ic = T Linv_c'                          (left-looking: dpotrf's TRSM as a product)
 //   X(i, j)   i > j:  X_ij = -Linv_i sum_{k=j}^{i-1} L_ik X_kj ,  X_jj = Linv_j                   (row i of L^-1 by forward substitution)
-// Tasks are handed out by ONE device-scope counter in a fixed topological order — step c: L(c, c), L(c+1 .. nb-1, c), then X(c, 0 .. c-1) —
+// Tasks are handed out by ONE device-scope counter in a fixed topological order (chain_order.h: L(0, 0), then step c lists L(c+1, c) and the
+// next diagonal tile L(c+1, c+1) ahead of L(c+2 .. nb-1, c) and X(c, 0 .. c-1) — the diagonal tiles are the block's critical path),
 // so a workgroup only ever waits for tasks with SMALLER indices, which are finished or held by a workgroup that is running: the launch
 // makes progress with any number of resident workgroups (late or never-scheduled ones simply take no tasks; no grid barrier, no co-residency
 // requirement), and every spin is bounded.  Dependencies are per-tile flags; whole finished columns of L / rows of X are tracked by
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void chain_block_kernel(ChainArgs<T> a) {
         const bool aborted = __builtin_amdgcn_readfirstlane(sh.abort) != 0;
         __syncthreads();  // (sh is rewritten at the top of the next iteration)
         if (t >= ntasks) break;
-        // ---- decode (chain_order.h: step c lists L(c .. nb-1, c), then X(c, 0 .. c-1); the order is topological — tests/test_chain_order.py) ----
+        // ---- decode (chain_order.h: the diagonal tile of the next step first, then the column, then the row of X; topological — tests/test_chain_order.py) ----
         const ChainTask task = chain_decode(t, nb, inv);
         const bool is_x = task.is_x != 0;
         const int i = task.i, j = task.j;  // output tile row / column
