@@ -51,9 +51,8 @@ for p in (ROOT, os.path.join(ROOT, "gaussianprocesses.jl_amd")):
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (v_mfma_f64_16x16x4_f64): 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: Peak FP32 (matrix)
-PMC_RECORD = os.path.join("profiles", "r05_bench_pmc_hbm.json")
-if not os.path.exists(os.path.join(ROOT, PMC_RECORD)):
-    PMC_RECORD = os.path.join("profiles", "r04_bench_pmc_hbm.json")
+PMC_RECORD = next((os.path.join("profiles", f"r{r:02d}_bench_pmc_hbm.json") for r in (6, 5, 4)
+                   if os.path.exists(os.path.join(ROOT, "profiles", f"r{r:02d}_bench_pmc_hbm.json"))), os.path.join("profiles", "r05_bench_pmc_hbm.json"))
 
 
 def _pmc_traffic(args, n, d, p):
@@ -68,7 +67,9 @@ def _pmc_traffic(args, n, d, p):
         return {"traffic": None}
     try:
         j = json.load(open(path))
-        return {"traffic": j["traffic_bytes_per_launch"], "traffic_unit": f"HBM bytes per launch (PMC, {PMC_RECORD})"}
+        return {"traffic": j["traffic_bytes_per_launch"], "traffic_unit": f"HBM bytes per launch (PMC, {PMC_RECORD})",
+                "traffic_source": f"committed profile {PMC_RECORD} (separate rocprofv3 --pmc passes over this command at the commit named in that file; "
+                                  "NOT a measurement of this run - PMC counters cannot be read from inside the timed process)"}
     except Exception:
         return {"traffic": None}
 
@@ -338,12 +339,11 @@ def roofline_object(args, res, n, d, p, dtype, steps, ctx=None):
             samples.extend(ctx.mfma_peak(bits) for _ in range(3))
             best = max(samples)
             extra = {"peak_measured": best, "frac_of_measured": achieved / best, "peak_measured_samples": [round(v, 2) for v in samples],
-                     "peak_measured_note": "gpmi_mfma_peak of this run: a bare loop of v_mfma_*_16x16x4 on every SIMD, sampled before the first fit "
-                                           "and after the timed steps; the best sample.  For fp64 it is NOT a ceiling: the bare loop (same operand "
-                                           "registers in every product) issues one instruction per 140 - 200 cycles and reaches ~48 TFLOP/s for any number "
-                                           "of accumulators, while the update kernel sustains more with the PMC showing 64 busy cycles per instruction "
-                                           "(profiles/r01_mfma_bench_instruction_ceilings.log, r05_bench_pmc_hbm.json): `frac` (against the 78.6 TFLOP/s "
-                                           "of 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz) is the roofline fraction"}
+                     "peak_measured_note": "gpmi_mfma_peak of this run, sampled before the first fit and after the timed steps (best sample): the update "
+                                           "kernel's OWN K loop with everything but its MFMAs compiled out (update256_kernel<T, ABL = 15>: no operand DMA, no "
+                                           "fragment reads, no slab barrier, no epilogue; 4096 tiles of 256 x 128 x 2048 through the same per-XCD queues, "
+                                           "random operands) - the rate the product kernel would reach if memory, LDS and barriers were free, at the clock "
+                                           "the chip sustains under that stream.  `frac` stays against the spec peak (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)"}
         except Exception:  # noqa: BLE001
             extra = {}
     return {
@@ -797,6 +797,7 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     sec[key] = {"error": repr(e)[:300]}
 
+    exit_code = 0
     if world == 1:
         if not args.no_secondary:
             sec = {}
@@ -819,21 +820,41 @@ def main():
         # oracle-rebuilt rows, rank 0, ~2 s), `per_step_ms` (already measured in the timed region) and `c4_sharded` — north_star's
         # N = 200 000 fp32 configuration on the same ranks, with its own parity.  A watchdog on EVERY rank prints the line with whatever is
         # there when the extras have not finished in time (all ranks leave together, so nobody waits in a collective for a rank that left).
+        import copy
         import threading
 
-        lock = threading.Lock()
+        lock = threading.Lock()  # guards `out` (the main thread adds to it, the watchdog prints it) and `printed`
         printed = [False]
         done = threading.Event()
+
+        def put(**kv):
+            with lock:
+                out.update(kv)
+
+        def persist(tag):
+            """the line as it stands, on disk: a secondary that takes the process down (a device fault, an OOM kill, torchrun tearing the
+            ranks down) must not take the primary measurement with it"""
+            if rank != 0:
+                return
+            try:
+                with lock:
+                    snap = copy.deepcopy(out)
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(ROOT, "gpurun_out", f"bench_gpus{world}{tag}.json"), "w") as fh:
+                    json.dump(snap, fh)
+            except OSError:
+                pass
 
         def emit(note=None):
             with lock:
                 if printed[0]:
                     return
-                printed[0] = True
                 if rank == 0:
+                    snap = copy.deepcopy(out)
                     if note:
-                        out["secondary_note"] = note
-                    print(json.dumps(out), flush=True)
+                        snap["secondary_note"] = note
+                    print(json.dumps(snap), flush=True)
+                printed[0] = True  # only after the line is out: a failed dump leaves the other thread free to try again
 
         budget_s = float(os.environ.get("GPMI_BENCH_SECONDARY_S", "420"))
 
@@ -843,12 +864,14 @@ def main():
                 os._exit(0)
 
         threading.Thread(target=watchdog, daemon=True).start()
+        persist("_primary")  # the timed region's result, before anything else runs
         if rank == 0:
-            out["per_step_ms"] = phases_object(res, args.steps)
+            put(per_step_ms=phases_object(res, args.steps))
             try:
-                out["parity"] = sparse_probe_parity(res, n, d, p, 1e-5 if args.dtype == "f64" else 1e-2)
+                put(parity=sparse_probe_parity(res, n, d, p, 1e-5 if args.dtype == "f64" else 1e-2))
             except Exception as e:  # noqa: BLE001
-                out["parity"] = {"checked": False, "error": repr(e)[:300]}
+                put(parity={"checked": False, "error": repr(e)[:300]})
+            persist("_primary")
         if not args.no_secondary:
             sec = {}
             try:
@@ -856,18 +879,15 @@ def main():
             except Exception as e:  # noqa: BLE001  (a collective that failed on this rank: say so, print what there is)
                 sec["secondary_error"] = repr(e)[:300]
             if rank == 0:
-                out.update(sec)
+                put(**sec)
         done.set()
         emit()
-        if rank == 0:
-            try:
-                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-                with open(os.path.join(ROOT, "gpurun_out", f"bench_gpus{world}.json"), "w") as fh:
-                    json.dump(out, fh)
-            except OSError:
-                pass
-            if isinstance(out.get("parity"), dict) and out["parity"].get("checked") and not out["parity"].get("ok"):
-                sys.stderr.write("bench.py: PARITY FAILED (sharded fit, solve residual on oracle-rebuilt rows): " + json.dumps(out["parity"]) + "\n")
+        persist("")
+        with lock:
+            par = out.get("parity")
+        if rank == 0 and isinstance(par, dict) and par.get("checked") and not par.get("ok"):
+            sys.stderr.write("bench.py: PARITY FAILED (sharded fit, solve residual on oracle-rebuilt rows): " + json.dumps(par) + "\n")
+            exit_code = 3
 
     if dist is not None:
         try:
@@ -877,7 +897,7 @@ def main():
             pass
     if world > 1:
         sys.stdout.flush()
-        os._exit(0)  # skip interpreter teardown of RCCL / HIP objects in multi-process runs
+        os._exit(exit_code)  # skip interpreter teardown of RCCL / HIP objects in multi-process runs
 
 
 if __name__ == "__main__":

@@ -719,7 +719,10 @@ static int create_one_context(int dev_code, gpmi_ctx** out) {
         hipMemset(c->d_queue, 0, (64 + 4 * 1024) * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&c->d_queue_side, 64 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(c->d_queue_side, 0, 64 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMalloc(&c->chain_sync, (size_t)chain_sync_bytes(c->chain_nb_max)) != hipSuccess) {
+        hipMalloc(&c->chain_sync, (size_t)chain_sync_bytes(c->chain_nb_max)) != hipSuccess ||
+        // the whole area, INCLUDING the never-reset `started` word behind the part every launch zeroes: it counts up from 0 together with
+        // chain_started_expect (a recycled allocation would hand chain_wait_kernel a stale count: no wait, or a full timeout, per update)
+        hipMemset(c->chain_sync, 0, (size_t)chain_sync_bytes(c->chain_nb_max)) != hipSuccess) {
         c->stream = c->own_stream;
         gpmi_ctx_destroy(c);
         return GPMI_EDEVICE;
@@ -776,6 +779,7 @@ static int create_one_context(int dev_code, gpmi_ctx** out) {
     if (const char* e = getenv("GPMI_TAIL_FUSE")) c->tail_fuse = std::min<long long>(std::max<long long>(0, atoll(e)) / IB * IB, (long long)c->chain_nb_max * IB);
     if (const char* e = getenv("GPMI_CUMASK_BELOW")) c->whole_cus_below = atoll(e);
     if (const char* e = getenv("GPMI_UPDATE256")) c->update256 = atoi(e) != 0;
+    if (const char* e = getenv("GPMI_UPDATE_FULL_GRID")) c->update_full_grid = atoi(e) != 0;
     if (const char* e = getenv("GPMI_UPDATE256_MIN")) c->update256_min_tiles = std::max<long long>(1, atoll(e));
     if (const char* e = getenv("GPMI_UPDATE256_ATOMIC")) c->update256_atomic = atoi(e) != 0;
 

@@ -166,8 +166,18 @@ struct ChainShared {
 
 // Wait (every wave for itself: wave-uniform, no barrier) until *flag is set.  Bounded: after ~4 s of polling the launch is declared dead
 // (CH_ABORT = 2, *info = INT_MIN: gpmi_fit returns GPMI_EDEVICE) and every wait returns at once.
+// ISA assumption (write side: publish(); read side: here): the producer's tile stores are `sc1` write-through stores that are acknowledged
+// (vmcnt) only once they are visible at the device-coherent level, and it raises the flag after s_waitcnt vmcnt(0) + a workgroup barrier; a
+// consumer wave's loads are issued and return in program order, and LLVM does not hoist a monotonic (relaxed atomic) or any other load
+// across `asm volatile("" ::: "memory")` — the compiler barrier below is what keeps the tile loads BEHIND the successful poll at the source
+// level; tests/test_gpu_chain.py::test_chain_stress_many_workgroup_counts is the canary for a toolchain that breaks either half.
+__device__ __forceinline__ void flag_seen() { asm volatile("" ::: "memory"); }
+
 __device__ __forceinline__ void wait_flag(const unsigned* flag, unsigned* sync, int* info, unsigned long long* waited = nullptr) {
-    if (ld_flag(flag) != 0u) return;
+    if (ld_flag(flag) != 0u) {
+        flag_seen();
+        return;
+    }
     const unsigned long long t0 = waited ? wall_clock64() : 0ull;  // (trace builds only: nullptr is a compile-time constant in the product)
     for (unsigned spins = 0;; ++spins) {
         __builtin_amdgcn_s_sleep(4);
@@ -175,21 +185,26 @@ __device__ __forceinline__ void wait_flag(const unsigned* flag, unsigned* sync, 
         if ((spins & 63u) == 63u) {
             if (ld_flag(sync + CH_ABORT) != 0u) break;
             if (spins > (1u << 22)) {
-                if ((threadIdx.x & 63) == 0) {
+                // (a pivot failure recorded meanwhile stays: dpotrf's info outranks the timeout)
+                if ((threadIdx.x & 63) == 0 && ld_flag(sync + CH_ABORT) == 0u) {
                     st_flag(sync + CH_ABORT, 2u);
-                    __hip_atomic_store((__attribute__((address_space(1))) int*)info, (int)0x80000000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    atomicCAS(info, 0, (int)0x80000000);
                 }
                 break;
             }
         }
     }
+    flag_seen();
     if (waited) *waited += wall_clock64() - t0;
 }
 
 // two flags at once: both loads are in flight together (one round trip when both are already set)
 __device__ __forceinline__ void wait_flags2(const unsigned* fa, const unsigned* fb, unsigned* sync, int* info, unsigned long long* waited = nullptr) {
     const unsigned a = ld_flag(fa), b = ld_flag(fb);
-    if (a != 0u && b != 0u) return;
+    if (a != 0u && b != 0u) {
+        flag_seen();
+        return;
+    }
     if (a == 0u) wait_flag(fa, sync, info, waited);
     if (b == 0u) wait_flag(fb, sync, info, waited);
 }
@@ -277,15 +292,10 @@ __device__ __forceinline__ void acc_to_lds(T* buf, const typename Mfma<T>::Acc (
             }
 }
 
-// The workgroup's LDS pool at file scope, so that the one-wavefront potf2 can be a function of its OWN (not inlined: inside the task loop
-// its 64 row registers on top of the loop's live values spill ~500 VGPRs; as a call only the handful of values live across it are saved)
-// and still address LDS as LDS.
-__shared__ double g_pool[PANEL_POOL];
-
-template <typename T>
-__device__ __attribute__((noinline)) int potf2_in_lds(T* invdiag, int* info, long long pivot_base) {
-    return diag64_body<T, true>(nullptr, 0, nullptr, invdiag, info, (int64_t)pivot_base, reinterpret_cast<T*>(g_pool));
-}
+// The workgroup's LDS pool: two 64 x 65 tile buffers (the K loops' operands; potf2_wg's S and XT) + potf2_wg's small blocks.  Two workgroups
+// of this size share a compute unit's 160 KiB (the half-CU slots of the masked chain stream).
+__shared__ double g_pool[POTF2_WG_POOL];
+static_assert(sizeof(double) * POTF2_WG_POOL + 64 <= 80 * 1024, "two chain workgroups per compute unit");
 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void chain_block_kernel(ChainArgs<T> a) {
@@ -416,12 +426,13 @@ __global__ __launch_bounds__(256, 2) void chain_block_kernel(ChainArgs<T> a) {
             acc_to_lds<T, false>(buf1, acc, T(-1));  // T = A_ic - sum
             CH_TR(2);
             if (diag) {
+                // (a pivot that failed in an earlier diagonal tile while this task was already under way: what is in S is garbage — no potf2.
+                //  Read by ONE thread: the flag may flip between two waves' loads, and the whole workgroup must take the same branch)
+                if (tid == 0) sh.abort = (int)ld_flag(a.sync + CH_ABORT);
                 __syncthreads();
                 int fail = 0;
-                // (a pivot that failed in an earlier diagonal tile while this task was already under way: what is in S is garbage — no potf2)
-                if (wv == 0 && ld_flag(a.sync + CH_ABORT) == 0u)
-                    fail = potf2_in_lds<T>(a.invdiag + c * 64, a.info, (long long)(a.pivot_base + (int64_t)c * 64));
-                if (wv == 0 && lane == 0 && fail) st_flag(a.sync + CH_ABORT, 1u);
+                if (sh.abort == 0) fail = potf2_wg<T>(a.invdiag + c * 64, a.info, a.pivot_base + (int64_t)c * 64, pool);  // the whole workgroup (potf2.h)
+                if (tid == 0 && fail) st_flag(a.sync + CH_ABORT, 1u);
                 __syncthreads();
                 CH_TR(3);
                 // (on failure the stores below write garbage that nobody uses: *info is set, every later kernel returns at once)

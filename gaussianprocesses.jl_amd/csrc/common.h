@@ -152,6 +152,9 @@ struct gpmi_ctx {
     int whiten_by_super_inverse = 1;     // predict / gradient whitening through the stored super-block inverses (GPMI_WHITEN_INV=0: NB blocks)
     int64_t whiten_super = 1024;         // super-block width of whiten_rows_inv (GPMI_WHITEN_SUPER; 256 = one level)
     int gemm_reserve = 0;
+    bool update_full_grid = true;   // dense look-ahead: the 256 x 128 update is launched with a workgroup for EVERY compute unit; the ones whose unit the chain
+                                     // holds start when the chain's workgroup there exits and pull what is left of their XCD's queue (GPMI_UPDATE_FULL_GRID=0: off)
+    bool update_late_wgs = false;    // set around that launch (chol.h main_update_beside_chain)
     int update256 = 1;                   // big trailing updates in 256 x 128 tiles, one 512-thread workgroup per CU (update256.hip;
                                          // GPMI_UPDATE256=0: round 2's 128 x 128 kernel everywhere)
     bool side_one_per_xcd = false;       // set around a look-ahead chain whose update will run as update256_kernel (chol.h, side_slots)

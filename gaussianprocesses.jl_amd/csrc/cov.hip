@@ -131,6 +131,11 @@ struct ScaleW {
 // distance loops difference the raw inputs (distance.jl:41-106: (x_k - y_k)^2 w_k), whose rounding error is relative to |x - y|; scaling
 // first would make it relative to |x| (inputs with a large common offset — years, timestamps — lose digits in r).  With both blocks
 // centred on a common data point the rounding of (x_k - c_k) is relative to the data's SPREAD, and (x_k - c_k) - (y_k - c_k) = x_k - y_k.
+// The centre is PER CALL (the first point of the call's column block xb).  Every assembly of K for a factorisation — gpmi_fit and the
+// blocked handle's assemble(), whatever the rank or stripe — passes the WHOLE training set as xb, so all of K shares one centre (the first
+// training point) and an entry has the same bits whichever call or rank generated it.  The cross-covariance blocks of predict (blocked:
+// one call per column block, centred on that block's first point) are independent of each other: entries of DIFFERENT calls agree only to
+// rounding, and nothing downstream assumes more.
 template <typename T, int DMAX>
 __global__ __launch_bounds__(256) void scale_inputs_kernel(const T* __restrict__ x, int64_t n, int d, ScaleW<DMAX> w, T* __restrict__ out,
                                                            unsigned long long* __restrict__ amax, const T* __restrict__ shift) {

@@ -433,29 +433,6 @@ __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __rest
     }
 }
 
-// ---- peak-rate micro-benchmark: back-to-back MFMAs of the instruction the GEMM uses -----------
-// NOT a ceiling for fp64: a bare loop of v_mfma_f64_16x16x4 on the same operand registers measures 140 - 200 cycles per instruction and
-// 48 TFLOP/s chip-wide whatever the number of accumulators (4: 47.7, 16: 36; profiles/r01_mfma_bench_instruction_ceilings.log,
-// r05_i_instrumentation.log) while the update kernel — distinct operands per product, 16 accumulator tiles — sustains 67.7 with the PMC
-// showing 64 busy cycles per instruction.  bench.py prints it as `peak_measured` with that caveat; the denominator of `frac` is the spec.
-template <typename T>
-__global__ __launch_bounds__(256) void mfma_peak_kernel(T* out, int iters) {
-    using MF = Mfma<T>;
-    typename MF::Acc a0, a1, a2, a3;
-    for (int r = 0; r < 4; ++r) a0.v[r] = a1.v[r] = a2.v[r] = a3.v[r] = T(0);
-    T x = T(threadIdx.x & 7) * T(0.125), y = T(1.0) + T(threadIdx.x & 3) * T(1e-3);
-    T bx[4] = {x, y, x, y}, by[4] = {y, x, y, x};
-    for (int i = 0; i < iters; ++i) {
-        MF::mma(x, by, a0);
-        MF::mma(y, bx, a1);
-        MF::mma(x, bx, a2);
-        MF::mma(y, by, a3);
-    }
-    T s = T(0);
-    for (int r = 0; r < 4; ++r) s += a0.v[r] + a1.v[r] + a2.v[r] + a3.v[r];
-    if (s == T(-1.2345)) out[0] = s;  // keep the chain live
-}
-
 }  // namespace
 
 template <typename T, int V, int NI>
@@ -710,30 +687,5 @@ int gemm_bench(gpmi_ctx* ctx, int64_t M, int64_t N, int64_t K, int lower, int va
 template int gemm_bench<double>(gpmi_ctx*, int64_t, int64_t, int64_t, int, int, int, double*);
 template int gemm_bench<float>(gpmi_ctx*, int64_t, int64_t, int64_t, int, int, int, double*);
 
-template <typename T>
-int mfma_peak(gpmi_ctx* ctx, double* tflops) {
-    T* d_out = nullptr;
-    GPMI_HIP(ctx, hipMalloc(&d_out, 64));
-    const int iters = 20000;
-    const int blocks = 256 * 4;  // 4 workgroups (16 waves) per CU
-    hipEvent_t e0, e1;
-    GPMI_HIP(ctx, hipEventCreate(&e0));
-    GPMI_HIP(ctx, hipEventCreate(&e1));
-    hipLaunchKernelGGL(mfma_peak_kernel<T>, dim3(blocks), dim3(256), 0, ctx->stream, d_out, 100);  // warm-up
-    GPMI_HIP(ctx, hipEventRecord(e0, ctx->stream));
-    hipLaunchKernelGGL(mfma_peak_kernel<T>, dim3(blocks), dim3(256), 0, ctx->stream, d_out, iters);
-    GPMI_HIP(ctx, hipEventRecord(e1, ctx->stream));
-    GPMI_HIP(ctx, hipEventSynchronize(e1));
-    float ms = 0.f;
-    GPMI_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
-    double flops = (double)blocks * 4.0 /*waves*/ * (double)iters * 4.0 /*16x16x4 products per iter*/ * 2.0 * 16 * 16 * 4;
-    *tflops = flops / ((double)ms * 1e-3) / 1e12;
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    hipFree(d_out);
-    return GPMI_OK;
-}
-template int mfma_peak<double>(gpmi_ctx*, double*);
-template int mfma_peak<float>(gpmi_ctx*, double*);
 
 }  // namespace gpmi

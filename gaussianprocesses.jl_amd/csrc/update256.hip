@@ -35,6 +35,7 @@
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include "common.h"
+#include <vector>
 #include "gemm_queue.h"
 #include "mfma.h"
 #include "tile_order.h"
@@ -476,7 +477,10 @@ static bool launch_update256_abl(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, i
     if (!prepare<T, ABL, OVW, ATOM>(ctx)) return false;
     const int64_t ntiles = tiles_per * (batch ? batch->count : 1);
     // one workgroup per CU; the look-ahead's free slots (two per CU in the 128 x 128 kernel's terms) become whole free CUs
-    const int cus = (ctx->num_cus - (ctx->gemm_reserve + 1) / 2) / 8 * 8;
+    // Beside a chain launch that is already resident (chol.h: chain_wait_kernel went first) the grid still covers EVERY compute unit: the
+    // workgroups that find theirs taken wait in the dispatcher until the chain's workgroup on that unit exits, then take tiles from their
+    // XCD's queue like everyone else — the chain is busy a sixth of a factorisation, and its eight units used to idle for the rest of it.
+    const int cus = ctx->update_late_wgs ? ctx->num_cus / 8 * 8 : (ctx->num_cus - (ctx->gemm_reserve + 1) / 2) / 8 * 8;
     const int grid = (int)std::min<int64_t>(cus, (ntiles + 7) / 8 * 8);
     if (grid <= 0) return false;
     QueueArgs qa;
@@ -521,6 +525,73 @@ bool launch_update256(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda,
 #endif
     return launch_update256_abl<T, 0>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info);
 }
+// The measured matrix-core ceiling (gpmi_mfma_peak, SURVEY 8(d) "builder must confirm with a micro-benchmark"): update256_kernel's OWN K loop
+// with everything but the MFMAs compiled out — ABL = 15: no operand DMA after the first two slabs, no fragment reads after the first, no slab
+// barrier, no epilogue — over 4096 rectangular 256 x 128 tiles with K = 2048 (16 tiles per compute unit through the same per-XCD queues).
+// What it times is the instruction stream the product kernel issues (16 accumulator tiles per wave, two waves per SIMD, the loop's scalar
+// bookkeeping) at the clock the chip sustains under it: the rate the real kernel would reach if memory, LDS and barriers cost nothing.
+// (A plain loop of v_mfma_f64_16x16x4 on four accumulators — rounds 1-5's gpmi_mfma_peak — measured 48 TFLOP/s, BELOW the product kernel:
+// not a ceiling of anything; profiles/r01_mfma_bench_instruction_ceilings.log.)
+template <typename T>
+int mfma_peak(gpmi_ctx* ctx, double* tflops) {
+    constexpr int64_t M = 16384, N = 8192, K = 2048;
+    T* A = nullptr;
+    GPMI_HIP(ctx, hipMalloc(&A, (size_t)(M * K) * sizeof(T)));
+    auto fail = [&](const char* what) {
+        (void)hipGetLastError();
+        hipFree(A);
+        ctx->err = std::string("gpmi_mfma_peak: ") + what;
+        return GPMI_EDEVICE;
+    };
+    {   // operands of the magnitude and variety of a factor panel (all-zero data would flatter the clock: MFMA power follows the toggling)
+        std::vector<T> h((size_t)(M * K));
+        unsigned long long st = 0x9E3779B97F4A7C15ull;
+        for (auto& v : h) {
+            st = st * 6364136223846793005ull + 1442695040888963407ull;
+            v = (T)((double)(long long)(st >> 11) * (1.0 / 9007199254740992.0) - 0.5) * T(0.03125);
+        }
+        if (hipMemcpyAsync(A, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+            return fail("operand upload");
+    }
+    if (!prepare<T, 15, false, false>(ctx)) return fail("LDS attribute");
+    TileShape s{(int)(M / U_BM), (int)(N / U_BN), 0, 0, 1, 0};
+    const int64_t ntiles = tile_count(s);
+    const int grid = ctx->num_cus / 8 * 8;
+    const unsigned lds = U_NBUF * (U_BM + U_BN) * 128;
+    auto go = [&]() {
+        QueueArgs qa;
+        qa.use_queue = ntiles > grid;
+        qa.tiles_per = ntiles;
+        qa.strideA = qa.strideB = qa.strideC = 0;
+        for (int x = 0; x <= 8; ++x) qa.start[x] = ntiles * x / 8;
+        for (int x = 0; x < 8; ++x) {
+            qa.base[x] = ctx->queue_base[x];
+            if (qa.use_queue) ctx->queue_base[x] += (unsigned long long)(qa.start[x + 1] - qa.start[x]);
+            qa.done_base[x] = 0;
+        }
+        // (C is never touched with ABL & 1; the operand panel stands in for the pointer)
+        hipLaunchKernelGGL((update256_kernel<T, 15, false, false>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, A, K, (const T*)A, K, (const T*)A, K, M, N, K,
+                           s, ctx->d_queue, qa, (const int*)nullptr);
+    };
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail("events");
+    go();  // warm-up: clocks, code object
+    const int iters = 3;
+    (void)hipEventRecord(e0, ctx->stream);
+    for (int i = 0; i < iters; ++i) go();
+    (void)hipEventRecord(e1, ctx->stream);
+    float ms = 0.f;
+    const bool ok = hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.f;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (!ok) return fail("timing");
+    hipFree(A);
+    *tflops = 2.0 * (double)M * (double)N * (double)K * iters / ((double)ms * 1e-3) / 1e12;
+    return GPMI_OK;
+}
+template int mfma_peak<double>(gpmi_ctx*, double*);
+template int mfma_peak<float>(gpmi_ctx*, double*);
+
 template <typename T>
 bool update256_applies(const gpmi_ctx* ctx, const T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
                        TileShape shape) {

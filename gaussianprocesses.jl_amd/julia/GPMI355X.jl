@@ -320,14 +320,27 @@ function hip_predict(cK::HIPPDMat, kernel::Kernel, meanf::Mean, x::AbstractMatri
     end
     check(context(), rc); μ, Σ
 end
-function predict_f(gp::GPE{X,Y,M,K,HIPCovariance}, x::AbstractMatrix; full_cov::Bool=false) where {X,Y,M,K}
+# Element types the device path takes (marshalled to Float64 at the C boundary).  ANY OTHER eltype — ForwardDiff.Dual test points pushed
+# through predict_y (test/kernels.jl:174-181), BigFloat, ... — keeps the reference's eltype-generic path (src/GP.jl:64-79 allocates
+# `Array{eltype(x)}`): no predict_f method is defined for it here, so dispatch lands on the reference's predict_f(::GPBase, ::AbstractMatrix),
+# which reaches predictMVN below one point at a time, and THAT method runs the reference's own host algebra (src/GP.jl:25-49) against a
+# host copy of the factor.  (Round 5's single method accepted every eltype and then threw in `Matrix{Float64}(x)`.)
+const DeviceReal = Union{AbstractFloat, Integer}
+device_eltype(x::AbstractMatrix) = eltype(x) <: DeviceReal && !(eltype(x) <: BigFloat)
+host_pdmat(a::HIPPDMat) = PDMat(Cholesky(UpperTriangular(cholfactors(a))))    # K = UᵀU: the reference's own PDMat (src/GP.jl:16-17), on the host
+function predict_f(gp::GPE{X,Y,M,K,HIPCovariance}, x::AbstractMatrix{<:DeviceReal}; full_cov::Bool=false) where {X,Y,M,K}
     size(x, 1) == gp.dim || throw(ArgumentError("Gaussian Process object and input observations do not have consistent dimensions"))
+    device_eltype(x) || return invoke(predict_f, Tuple{GPBase, AbstractMatrix}, gp, x; full_cov=full_cov)
     hip_predict(gp.cK, gp.kernel, gp.mean, x, full_cov)
 end
-# predictMVN (src/GP.jl:39-49; reached by predict_full, src/GPE.jl:399, for callers that bypass predict_f): the full
-# predictive covariance from the device.  `alpha` is the one the last gpmi_fit left in the handle (= gp.alpha).
-predictMVN(xpred::AbstractMatrix, xtrain::AbstractMatrix, ytrain::AbstractVector, kernel::Kernel, meanf::Mean,
-           alpha::AbstractVector, ::HIPCovariance, Ktrain::HIPPDMat) = hip_predict(Ktrain, kernel, meanf, xpred, true)
+# predictMVN (src/GP.jl:39-49; reached by predict_full, src/GPE.jl:399, for callers that bypass predict_f — and by the reference's
+# generic predict_f for the eltypes the device does not take): the full predictive covariance from the device, or the reference's generic
+# method on a host PDMat.  `alpha` is the one the last gpmi_fit left in the handle (= gp.alpha).
+function predictMVN(xpred::AbstractMatrix, xtrain::AbstractMatrix, ytrain::AbstractVector, kernel::Kernel, meanf::Mean,
+                    alpha::AbstractVector, ::HIPCovariance, Ktrain::HIPPDMat)
+    device_eltype(xpred) && return hip_predict(Ktrain, kernel, meanf, xpred, true)
+    predictMVN(xpred, xtrain, ytrain, kernel, meanf, alpha, GaussianProcesses.FullCovariance(), host_pdmat(Ktrain))
+end
 
 # convenience constructor, as SoR(...)/FITC(...) are (src/sparse/subsetofregressors.jl:324-327)
 GP_hip(x::AbstractMatrix, y::AbstractVector, m::Mean, k::Kernel, logNoise=-2.0; kw...) = GPE(x, y, m, k, logNoise, HIPCovariance(; kw...))

@@ -12,6 +12,7 @@
 # HIPCovariance against FullCovariance on the same data), test/optim.jl:20-37 (optimize!, fixed kernel), test/heteroscedastic.jl,
 # test/test_sparse.jl:156 (FITC's stored value), docs/src/Regression.md:60-63,83-89,118-124 (printed transcript).
 using Test, Random, LinearAlgebra, Statistics, PDMats
+import ForwardDiff
 using GaussianProcesses
 using GaussianProcesses: get_params, set_params!, update_target!, update_target_and_dtarget!, update_mll!, update_cK!, init_precompute,
     predict_LOO, fix, get_param_names
@@ -173,6 +174,21 @@ both(x, y, m, k, ln) = (GPE(x, y, deepcopy(m), deepcopy(k), ln), GPE(x, y, deepc
         @test whiten(hip.cK, B) ≈ whiten(cpu.cK, B) rtol = 1e-6
         @test UpperTriangular(GaussianProcesses.cholfactors(hip.cK)) ≈ UpperTriangular(GaussianProcesses.cholfactors(cpu.cK)) rtol = 1e-8
         @test Matrix(hip.cK) ≈ Matrix(cpu.cK) rtol = 1e-8
+    end
+
+    @testset "eltype-generic predict (src/GP.jl:70; test/kernels.jl:174-181: ForwardDiff through predict_y)" begin
+        # Dual-valued test points are not a device eltype: dispatch must fall to the reference's predict_f(::GPBase, ::AbstractMatrix) and from
+        # there to the shim's predictMVN, which runs the reference's host algebra on a host copy of the factor — same numbers, derivatives intact
+        cpu, hip = both(X, y, MeanConst(0.0), SEArd(zeros(d), 0.0), -3.0)
+        f_hip = z -> sum(predict_y(hip, reshape(z, :, 1)))[1]
+        f_cpu = z -> sum(predict_y(cpu, reshape(z, :, 1)))[1]
+        z = rand(d)
+        @test f_hip(z) ≈ f_cpu(z) rtol = RTOL                                       # Float64: the device path
+        @test ForwardDiff.gradient(f_hip, z) ≈ ForwardDiff.gradient(f_cpu, z) rtol = 1e-8   # (ForwardDiff: a dependency of GaussianProcesses itself, Project.toml:12)
+        μb, σb = predict_f(hip, big.(Xtest[:, 1:3]))                                 # BigFloat: also the generic path
+        μc, σc = predict_f(cpu, Xtest[:, 1:3])
+        @test Float64.(μb) ≈ μc rtol = 1e-8
+        @test Float64.(σb) ≈ σc rtol = 1e-6
     end
 
     @testset "packed storage on one device (gpmi_gp_create_blocked)" begin

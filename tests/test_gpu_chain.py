@@ -74,6 +74,37 @@ def test_any_number_of_workgroups_gives_the_same_bits_and_matches_the_multi_laun
     assert facs["default"][1] == pytest.approx(facs["old"][1], rel=1e-12)
 
 
+def test_chain_stress_many_workgroup_counts(monkeypatch):
+    """The canary for the inter-workgroup visibility protocol (chain.hip publish() / wait_flag: sc1 write-through stores, drain, flag; relaxed
+    poll, compiler barrier, sc1 loads — no fences): a toolchain or runtime that breaks it shows up as a factor whose bits depend on who
+    computed which tile.  Ten workgroup counts x repeated fits with refreshed parameters, every factor bit-identical to the one-workgroup
+    (purely sequential, nothing to synchronise) run of the same parameters."""
+    n, sup = 4100, "600,1500,3000"
+    x, y, _ = G.synthetic_inputs(n, 4, p=8)
+    lns = [LN + 0.01 * r for r in range(4)]
+
+    def run(wgs):
+        monkeypatch.delenv("GPMI_CHAIN_WGS", raising=False)
+        env = {} if wgs is None else {"GPMI_CHAIN_WGS": wgs}
+        ctx = _ctx(monkeypatch, GPMI_SUPER=sup, GPMI_LOOKAHEAD_MIN=256, **env)
+        gp = g.GP(x, y, g.MeanZero(), g.from_spec(SPEC), LN, ctx=ctx)
+        out = []
+        for ln in lns:
+            gp.set_params(np.concatenate([[ln], gp.get_params()[1:]]))
+            gp.update_mll()
+            out.append((gp.mll, np.triu(gp.cK.cholfactors())))
+        del gp
+        ctx.close()
+        return out
+
+    base = run(1)
+    for wgs in (None, 2, 5, 8, 13, 16, 24, 32, 48, 64):
+        got = run(wgs)
+        for (m0, f0), (m1, f1) in zip(base, got):
+            assert m0 == m1, wgs
+            assert np.array_equal(f0, f1), wgs
+
+
 def test_chain_kernel_fp32(monkeypatch):
     ctx = _ctx(monkeypatch, GPMI_SUPER="512,1024,2048", GPMI_LOOKAHEAD_MIN=256)
     gp, x, y, xs = _fit(ctx, 2900, dtype=np.float32)

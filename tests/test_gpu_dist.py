@@ -418,7 +418,16 @@ def test_cu_partitions_and_injected_collective_latency():
     in flops to cover just the ~1.1 ms chain kernel + a broadcast (u2a_cover_s_; a launcher that measures a slow broadcast widens it:
     GPMI_BLOCKED_U2A_US, used below for the broadcast case).  Both must come out well below 1.0 — and cannot reach 0 (the last steps
     are shorter than the delay).  Timing-sensitive, so it runs in a process of its own (a long-lived pytest
-    process that has created dozens of contexts shares hardware queues between their streams)."""
+    process that has created dozens of contexts shares hardware queues between their streams) and gets TWO attempts: the bounds are wall-clock
+    ratios, and one noisy box must not take the rest of a `pytest -x` run down with it (a regression of the pipeline fails both)."""
+    try:
+        _overlap_attempt()
+    except AssertionError as first:
+        print("overlap test: first attempt failed, retrying once:", str(first)[:2000])
+        _overlap_attempt()
+
+
+def _overlap_attempt():
     import json
 
     out = subprocess.run([sys.executable, "-c", _OVERLAP], cwd=ROOT, capture_output=True, text=True, timeout=1500)

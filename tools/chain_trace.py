@@ -45,7 +45,8 @@ def report(L, out=sys.stdout):
     if BRIEF: return
     if L.get("potf2"):
         q = [v * TICK_US for v in L["potf2"]]
-        print(f"  the last potf2 of the launch (each mark costs ~1 us): 64 columns {q[0]:.2f} us | L and zeros to LDS {q[1]:.2f} | four 16 x 16 inverses {q[2]:.2f} | six off-diagonal blocks {q[3]:.2f}", file=out)
+        print(f"  the last potf2 of the launch (potf2_wg, round 6: the marks cost ~1 us each): four panels and the inverse work under them {q[0]:.2f} us | last step "
+              f"(X_3b, pivot test) {q[3]:.2f}", file=out)
     wgs = sorted({k["wg"] for k in tasks})
     print(f"  workgroups that took tasks: {len(wgs)}; tasks per workgroup min/max {min(sum(1 for k in tasks if k['wg'] == w) for w in wgs)}/"
           f"{max(sum(1 for k in tasks if k['wg'] == w) for w in wgs)}", file=out)
