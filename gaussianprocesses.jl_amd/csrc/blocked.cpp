@@ -37,6 +37,7 @@ static int64_t default_block(int64_t n, int world) {
 
 BlockedGP::BlockedGP(Dev* dev, Comm* comm, int d, int64_t n, BlockedOpts o)
     : dev_(dev), comm_(comm), rank_(comm ? comm->rank : 0), G_(comm ? comm->world : 1), d_(d), n_(n) {
+    dev_->set_world(G_);
     es_ = dev->es;
     WD_ = o.block > 0 ? o.block : default_block(n, G_);
     nblk_ = (n + WD_ - 1) / WD_;

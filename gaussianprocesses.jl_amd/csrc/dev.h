@@ -51,6 +51,9 @@ struct Dev {
     // gives up ~4 % but the chain runs undisturbed and collectives find free CUs) or free workgroup slots beside a full-width
     // update (~1.5 %, the chain crawls: fine while the update is long).  The driver decides per step (blocked.cpp).
     virtual void whole_cus(bool on) = 0;
+    // how many ranks share the factorisation (1: nothing but the chain ever wants the compute units an update leaves free — the update
+    // may take them back as soon as the chain's workgroups exit; > 1: the collectives' kernels need them too)
+    virtual void set_world(int world) { (void)world; }
     virtual DevEvent record() = 0;   // on the current stream
     virtual void wait(DevEvent e) = 0;  // the current stream waits for e
     virtual void sync() = 0;         // host waits for every stream; returns after device errors are collected in err

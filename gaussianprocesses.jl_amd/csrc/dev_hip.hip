@@ -161,7 +161,9 @@ struct HipDev : Dev {
     }
     // ---- streams ----
     bool is_masked = false;
+    bool solo = false;
     void whole_cus(bool on) override { is_masked = set_lookahead_mode(c, on) == 1; }
+    void set_world(int world) override { solo = world == 1; }
     bool masked() const { return is_masked && c->upd_stream && c->side_masked; }
     void begin_call() override {
         (void)hipSetDevice(c->device);
@@ -170,6 +172,7 @@ struct HipDev : Dev {
         c->num_cus = full_cus();
         c->beside_update = false;
         c->gemm_reserve = 0;
+        c->update_late_wgs = false;
         la_reset(c);
     }
     int full_cus_ = 0;
@@ -181,6 +184,7 @@ struct HipDev : Dev {
         c->beside_update = false;
         c->side_one_per_xcd = false;
         c->gemm_reserve = 0;
+        c->update_late_wgs = false;
         c->num_cus = full_cus();
         switch (s) {
             case DS_MAIN: c->stream = main_s; break;
@@ -191,6 +195,9 @@ struct HipDev : Dev {
                 } else {
                     c->stream = main_s;
                     c->gemm_reserve = c->side_stream ? c->lookahead_slots : 0;
+                    // one rank: the 256 x 128 update's grid covers every compute unit (update256.hip: the workgroups whose unit the chain
+                    // holds start when the chain's exits; gemm() below puts chain_wait_kernel in front so that the chain is placed first)
+                    c->update_late_wgs = solo && c->update_full_grid && c->gemm_reserve > 0;
                 }
                 break;
             case DS_SIDE:
@@ -222,6 +229,7 @@ struct HipDev : Dev {
         c->num_cus = full_cus();
         c->beside_update = false;
         c->gemm_reserve = 0;
+        c->update_late_wgs = false;
     }
     void* native_stream() override { return (void*)c->stream; }
     // ---- ops ----

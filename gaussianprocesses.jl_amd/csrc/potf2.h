@@ -332,11 +332,11 @@ __device__ __forceinline__ void potf2_panel(T* __restrict__ S, T* __restrict__ X
             e = tfma<T>(-t, r, T(0.5));
             POTF2_SB(); items(5); POTF2_SB();
             r = tfma<T>(r, e, r);
-            T p = T(0);
-            if (jj < 15) p = a[jj] * sc[jj + 1];
             POTF2_SB(); items(6); POTF2_SB();
             const T rr = r * r;
             if (jj < 15) {
+                // (every item of the step has been issued by now — sc[jj + 1] may come with the last slice when the step has few items)
+                const T p = a[jj] * sc[jj + 1];
                 a[jj + 1] = tfma<T>(-p, rr, a[jj + 1]);  // the next pivot's column: two operations behind r
                 d = bcast_lane<T>(a[jj + 1], base + jj + 1);
             }

@@ -22,6 +22,51 @@ pytestmark = pytest.mark.gpu
 LL8 = [math.log(0.5) + 0.05 * k for k in range(8)]
 
 
+import time
+
+
+class _Laps:
+    """stage clock of the three long tests: printed, and appended to gpurun_out/test_laps.log when that directory exists (where the suite's minutes go)"""
+
+    def __init__(self, name):
+        self.name, self.t0, self.laps = name, time.perf_counter(), []
+
+    def __call__(self, what):
+        t = time.perf_counter()
+        self.laps.append((what, t - self.t0))
+        self.t0 = t
+
+    def done(self):
+        line = f"[laps] {self.name}: " + ", ".join(f"{w} {s:.1f}s" for w, s in self.laps)
+        print(line)
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        if os.path.isdir(d):
+            with open(os.path.join(d, "test_laps.log"), "a") as fh:
+                fh.write(line + "\n")
+
+
+def _assemble_upper_parallel(spec, x, log_noise):
+    """update_cK! of the oracle (oracle/cov_oracle.c: the reference-order scalar loops) for the UPPER triangle dpotrf('U') reads, column
+    blocks on the host's cores (ctypes releases the GIL): the single-threaded whole-matrix call was half a minute of this file at N = 50 000."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import c_oracle
+
+    n = x.shape[1]
+    K = np.empty((n, n), order="F")
+    w = 1000
+
+    def block(j0):
+        j1 = min(n, j0 + w)
+        K[:j1, j0:j1] = c_oracle.cov(spec, x[:, :j1], x[:, j0:j1])
+        K[j1:, j0:j1] = 0.0
+
+    with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
+        list(ex.map(block, range(0, n, w)))
+    K[np.diag_indices(n)] += math.exp(2.0 * log_noise)
+    return K
+
+
 def _Kv_chunked(spec, x, noise_var, V, chunk=2500):
     """(K + noise_var I) V with K rebuilt by the oracle, a block of rows at a time."""
     n = x.shape[1]
@@ -181,7 +226,9 @@ def test_f3_packed_n220000_fp64_on_one_device_block_diagonal():
     y = np.sin(6.0 * (x[0] % 100.0)) + x[1] + 0.1 * rng.standard_normal(n)
     spec = ("se_iso", math.log(0.3), 0.0)
     ln = math.log(0.1)
+    lap = _Laps(f"f3 packed N={n}")
     gp = g.GP(x, y, g.MeanZero(), g.from_spec(spec), ln, packed=True)
+    lap("device fit (packed)")
     assert gp.nobs == n and gp.cK.nstripes > 20
     print(f"[f3] N = {n}: packed factor {gp.cK.factor_bytes / 1e9:.1f} GB in {gp.cK.nstripes} stripes, mll {gp.mll:.6f}")
     packed_bytes = gp.cK.factor_bytes
@@ -196,6 +243,7 @@ def test_f3_packed_n220000_fp64_on_one_device_block_diagonal():
         alpha_ref[sl] = ref["alpha"]
         if c in (0, 57, nc - 1):
             refs[c] = ref
+    lap("oracle cluster fits")
     assert gp.mll == pytest.approx(mll_ref, rel=1e-9)
     np.testing.assert_allclose(gp.alpha, alpha_ref, rtol=1e-6, atol=1e-8 * np.abs(alpha_ref).max())
     # predictions next to three clusters (first stripe, a middle one, the last block)
@@ -206,6 +254,11 @@ def test_f3_packed_n220000_fp64_on_one_device_block_diagonal():
         mu_o, s2_o = G.predict_f(spec, x[:, sl], refs[c], xs[:, 16 * j:16 * (j + 1)])
         np.testing.assert_allclose(mu[16 * j:16 * (j + 1)], mu_o, rtol=1e-6, atol=1e-8)
         np.testing.assert_allclose(s2[16 * j:16 * (j + 1)], s2_o, rtol=1e-5, atol=1e-9)
+    lap("predict + checks")
+    del gp
+    _free_device_memory()
+    lap("free")
+    lap.done()
 
 
 # --------------------------------------------------------------------------------------------
@@ -229,6 +282,7 @@ def test_c3_n50000_composite_direct_vs_oracle():
     from oracle import c_oracle
 
     _free_device_memory()
+    lap = _Laps("c3 direct N=50000")
     n, p = 50000, 256
     x, y, xs = G.synthetic_inputs(n, 8, p=p)
     spec = ("sum", ("sum", ("se_ard", LL8, 0.0), ("mat52_iso", math.log(0.7), math.log(0.5))), ("noise", math.log(0.05)))
@@ -237,8 +291,11 @@ def test_c3_n50000_composite_direct_vs_oracle():
     mu, s2 = gp.predict_f(xs)
     mll_dev, alpha_dev = gp.mll, np.asarray(gp.alpha, dtype=np.float64)
     del gp
-    K = c_oracle.assemble(spec, x, log_noise)                               # update_cK!: cov! + exp(2 logNoise) on the diagonal
+    lap("device fit + predict")
+    K = _assemble_upper_parallel(spec, x, log_noise)                        # update_cK!: cov! + exp(2 logNoise) on the diagonal
+    lap("oracle cov!")
     U, info = sla.lapack.dpotrf(K, lower=0, clean=0, overwrite_a=1)         # make_posdef!
+    lap("host dpotrf")
     del K
     assert info == 0
     alpha = sla.cho_solve((U, False), y)
@@ -248,6 +305,8 @@ def test_c3_n50000_composite_direct_vs_oracle():
     Lck = sla.solve_triangular(U, Kc, trans="T", lower=False, overwrite_b=True)
     kdiag = 1.0 + 0.25 + 0.05 ** 2
     s2_o = np.maximum(kdiag - np.sum(Lck * Lck, axis=0), 0.0)
+    lap("host solves")
+    lap.done()
     print(f"[C3 direct] mll device {mll_dev:.6f} oracle {mll:.6f} (rel {abs(mll_dev / mll - 1):.2e}); "
           f"max|dmu| {np.abs(mu - mu_o).max():.2e}, max|ds2| {np.abs(s2 - s2_o).max():.2e}")
     assert mll_dev == pytest.approx(mll, rel=1e-9)
@@ -263,16 +322,20 @@ def test_c4_fp32_n200000_d16_properties_at_full_size():
     mu = K*' alpha — and (round 4) mll / alpha / mu / s2 DIRECTLY against the fp64 fit of the same model in packed storage
     (~180 GB), for the dense fp32 handle and for the blocked fp32 handle; bar 1e-2 (fp32)."""
     _free_device_memory()
+    lap = _Laps("c4 N=200000")
     n, d = 200000, 16
     x, y, xs = G.synthetic_inputs(n, d, p=256)
     spec = ("se_ard", LL16, 0.0)
     log_noise = math.log(0.1)
     nv = math.exp(2 * log_noise)
     gp = g.GP(x, y, g.MeanZero(), g.from_spec(spec), log_noise, dtype=np.float32)   # raises PosDefException if not PD
+    lap("fp32 dense fit")
     a = np.asarray(gp.alpha, dtype=np.float64)
     rng = np.random.default_rng(7)
     rows = np.sort(rng.choice(n, 512, replace=False))
-    r = G.cov(spec, x[:, rows], x) @ a + nv * a[rows] - y[rows]
+    Krows = G.cov(spec, x[:, rows], x)                 # (kept: the fp64 fit's residual below reads the same 512 rows)
+    r = Krows @ a + nv * a[rows] - y[rows]
+    lap("oracle rows + residual")
     print(f"[fp32 N=200000] mll {gp.mll:.3f}; residual max {np.abs(r).max():.3e} (|y| max {np.abs(y).max():.2f})")
     assert np.abs(r).max() <= 1e-2 * np.abs(y).max()
     S = np.sort(rng.choice(n, 64, replace=False))
@@ -297,23 +360,30 @@ def test_c4_fp32_n200000_d16_properties_at_full_size():
     mu_t, _ = gp.predict_f(x[:, :128])
     np.testing.assert_allclose(mu_t, y[:128], atol=0.5)
     mll32, mu32, s232 = gp.mll, np.array(mu), np.array(s2)
+    lap("probes, predicts")
     del gp
     _free_device_memory()
+    lap("free")
     # (round 4) the same model through the BLOCKED fp32 handle — the per-rank code of the 8-GPU run — on one rank
     from gpmi355x import dist as gd
 
     gb = gd.ShardedGPE(x, y, g.MeanZero(), g.from_spec(spec), log_noise, dtype=np.float32)
+    lap("fp32 blocked fit")
     mub, s2b = gb.predict_f(xs)
     mllb, ab = gb.mll, np.asarray(gb.alpha, dtype=np.float64)
     del gb
     _free_device_memory()
+    lap("predict, free")
     # ... and DIRECTLY against fp64 at this size: packed storage holds N = 200 000 fp64 in ~180 GB on the one device (the dense fp64
     # matrix would need 320 GB); the fp64 fit certifies itself by its solve residual on the oracle-rebuilt rows
     g64 = g.GP(x, y, g.MeanZero(), g.from_spec(spec), log_noise, packed=True, stripe_blocks=8)
+    lap("fp64 packed fit")
     a64 = np.asarray(g64.alpha, dtype=np.float64)
-    r64 = G.cov(spec, x[:, rows], x) @ a64 + nv * a64[rows] - y[rows]
+    r64 = Krows @ a64 + nv * a64[rows] - y[rows]
     assert np.abs(r64).max() <= 1e-8 * np.abs(y).max()
     mu64, s264 = g64.predict_f(xs)
+    lap("residual, predict")
+    lap.done()
     print(f"[C4 N=200000 d=16] mll fp32 dense {mll32:.3f} / fp32 blocked {mllb:.3f} / fp64 packed {g64.mll:.3f} "
           f"(rel {abs(mll32 / g64.mll - 1):.2e}, {abs(mllb / g64.mll - 1):.2e}); max|dmu| {np.abs(mu32 - mu64).max():.2e} / {np.abs(mub - mu64).max():.2e}, "
           f"max|ds2| {np.abs(s232 - s264).max():.2e} / {np.abs(s2b - s264).max():.2e}, fp64 residual {np.abs(r64).max():.1e}")
