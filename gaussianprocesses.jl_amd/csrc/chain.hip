@@ -528,11 +528,15 @@ __global__ __launch_bounds__(256, 2) void chain_block_kernel(ChainArgs<T> a) {
 // with the instrumentation of the run: 61 ms per step un-instrumented, 82 with events on the update).  With the chain placed first on the
 // idle chip it is the update whose last workgroups may wait for the chain's few milliseconds: a persistent kernel with a tile queue does
 // not care.
-__global__ void chain_wait_kernel(const unsigned* started, unsigned expect) {
+// `ticks`: how long to wait at most (100 MHz).  ~100 us when the update leaves the chain's compute units free anyway (a late chain then only
+// starts late); 5 ms when the update's grid covers EVERY unit (update256.hip update_late_wgs): a chain that lost the race would wait for
+// the whole update — measured on the blocked handle's one-rank path, where the chain's launch sits behind a cross-stream event and a
+// memset: 9.2 ms per step in the chain phase instead of 1.3 (profiles/r06_c_*).
+__global__ void chain_wait_kernel(const unsigned* started, unsigned expect, long long ticks) {
     if (threadIdx.x != 0) return;
     const long long t0 = wall_clock64();  // 100 MHz
     while ((int)(ld_flag(started) - expect) < 0) {
-        if (wall_clock64() - t0 > 10000) break;
+        if (wall_clock64() - t0 > ticks) break;
         __builtin_amdgcn_s_sleep(8);
     }
 }
@@ -547,7 +551,8 @@ void launch_chain_wait(gpmi_ctx* ctx) {
     if (!ctx->chain_sync || !ctx->chain_wait_pending) return;
     ctx->chain_wait_pending = false;
     const unsigned* started = (const unsigned*)ctx->chain_sync + chain_zeroed_words(ctx->chain_nb_max);
-    hipLaunchKernelGGL(chain_wait_kernel, dim3(1), dim3(64), 0, ctx->stream, started, ctx->chain_started_expect);
+    hipLaunchKernelGGL(chain_wait_kernel, dim3(1), dim3(64), 0, ctx->stream, started, ctx->chain_started_expect,
+                       (long long)(ctx->update_late_wgs ? 500000 : 10000));
 }
 
 template <typename T>

@@ -199,8 +199,8 @@ inline void main_update_beside_chain(gpmi_ctx* c, hipEvent_t after, F launch, bo
         return;
     }
     c->gemm_reserve = c->lookahead_slots;
-    launch_chain_wait(c);  // the chain's workgroups are placed before the update takes the compute units (chain.hip chain_wait_kernel)
     c->update_late_wgs = c->update_full_grid;
+    launch_chain_wait(c);  // the chain's workgroups are placed before the update takes the compute units (chain.hip chain_wait_kernel)
     launch();
     c->update_late_wgs = false;
     c->gemm_reserve = 0;
