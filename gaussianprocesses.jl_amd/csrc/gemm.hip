@@ -146,6 +146,10 @@ __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __rest
         int ti, tj;
         const int64_t bi = t / qa.tiles_per;  // 0 unless batched
         tile_decode(t - bi * qa.tiles_per, shape, &ti, &tj);
+        // GEMM_KEND_COL (rectangles only): a tile's K loop ends at its last column, so its cost grows with tj — up to K / 128 (K / 64) times
+        // the first column's.  Walking every strip from the RIGHT hands the long tiles out first and leaves the short ones for the end
+        // of each XCD's queue: the launch's tail is a 64 ... 128-deep tile instead of a K-deep one (0.33 ms at K = 2048 in 128 x 64 tiles).
+        if (flags & GEMM_KEND_COL) tj = shape.ntn - 1 - tj;
         T* __restrict__ const Ct = C + bi * qa.strideC;
         const int64_t m0 = (int64_t)ti * BM, n0 = (int64_t)tj * BN;
 
