@@ -154,6 +154,7 @@ struct gpmi_ctx {
     int gemm_reserve = 0;
     bool update_full_grid = true;   // dense look-ahead: the 256 x 128 update is launched with a workgroup for EVERY compute unit; the ones whose unit the chain
                                      // holds start when the chain's workgroup there exits and pull what is left of their XCD's queue (GPMI_UPDATE_FULL_GRID=0: off)
+    bool kend_heavy_first = true;    // GEMM_KEND_COL launches hand their long tiles out first (GPMI_KEND_HEAVY_FIRST=0: columns in ascending order, rounds 1-5)
     bool update_late_wgs = false;    // set around that launch (chol.h main_update_beside_chain)
     int update256 = 1;                   // big trailing updates in 256 x 128 tiles, one 512-thread workgroup per CU (update256.hip;
                                          // GPMI_UPDATE256=0: round 2's 128 x 128 kernel everywhere)
@@ -333,6 +334,7 @@ enum GemmFlags { GEMM_OVERWRITE = 1 /* C = A B' instead of C -= A B' */, GEMM_KS
                  GEMM_KEND_COL = 8 /* B[j][k] = 0 for k > j: end K at the tile's last column */,
                  GEMM_PHASE_LOCK = 64 /* tiles of an XCD start round by round (gemm.hip QueueArgs::done_base) */,
                  GEMM_NEGOUT = 256 /* with GEMM_OVERWRITE: C = -A B' */,
+                 GEMM_HEAVY_FIRST = 512 /* set by the launcher on GEMM_KEND_COL rectangles: every strip is walked from its last (longest-K) column */,
                  GEMM_AUX = 4 /* no effect on the kernel: account the launch to the panel class, not to the trailing update */,
                  GEMM_NO_PAIR16 = 32 /* tools: 8-byte instead of 16-byte C accesses in fp64 (A/B of the access width) */ };
 

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, NI == 4 ? 2 : 3) void gemm_nt_kernel(T* __rest
         // GEMM_KEND_COL (rectangles only): a tile's K loop ends at its last column, so its cost grows with tj — up to K / 128 (K / 64) times
         // the first column's.  Walking every strip from the RIGHT hands the long tiles out first and leaves the short ones for the end
         // of each XCD's queue: the launch's tail is a 64 ... 128-deep tile instead of a K-deep one (0.33 ms at K = 2048 in 128 x 64 tiles).
-        if (flags & GEMM_KEND_COL) tj = shape.ntn - 1 - tj;
+        if (flags & GEMM_HEAVY_FIRST) tj = shape.ntn - 1 - tj;
         T* __restrict__ const Ct = C + bi * qa.strideC;
         const int64_t m0 = (int64_t)ti * BM, n0 = (int64_t)tj * BN;
 
@@ -477,6 +477,9 @@ static void launch_persistent_ni(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, i
     static const bool no_pair16 = getenv("GPMI_GEMM_NO_PAIR16") != nullptr;  // tools: A/B of the C access width
     if (no_pair16) flags |= GEMM_NO_PAIR16;
 #endif
+    // (launches of few rounds only: there the last round's K-deep tiles are a visible tail — C2's panel solves 51.8 -> 51.3 ms per fit —, while
+    //  the 15-round solves of the first N = 50 000 panels measured 1 ms per fit SLOWER walked from the right: profiles/r06_e_*)
+    if ((flags & GEMM_KEND_COL) && shape.mode == 0 && ctx->kend_heavy_first && ntiles < 8 * (int64_t)slots) flags |= GEMM_HEAVY_FIRST;
     if (ctx->attach_a) {  // profiled launch: the dispatch carries its own start / stop events (ProfScope attach mode)
         hipEvent_t ea = ctx->attach_a, eb = ctx->attach_b;
         ctx->attach_a = ctx->attach_b = nullptr;

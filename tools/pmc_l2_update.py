@@ -3,7 +3,7 @@ read requests they receive, per launch.  Prints one JSON object."""
 import csv, glob, json, os, sys
 
 root = sys.argv[1]
-KERNELS = ("gemm_nt_kernel<double, 0, 4>", "update256_kernel<double")
+KERNELS = ("gemm_nt_kernel<double, 0, 4>", "update256_kernel<double, 0")
 out = {"kernel": " + ".join(KERNELS), "command": "python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary", "units": "per launch (summed over the 8 XCDs)"}
 for folder in ("tcc", "tcp"):
     per = {}

@@ -8,9 +8,10 @@ import os
 import sys
 
 root = sys.argv[1]
-KERNELS = ("gemm_nt_kernel<double, 0, 4>", "update256_kernel<double")  # the trailing update: 128 x 128 and 256 x 128 forms (one roofline class)
+KERNELS = ("gemm_nt_kernel<double, 0, 4>", "update256_kernel<double, 0")  # the trailing update: 128 x 128 and 256 x 128 forms (one roofline class;
+# "<double, 0": not the <double, 15, ...> launches of gpmi_mfma_peak, the bare MFMA stream bench.py samples before and after the timed steps)
 KERNEL = " + ".join(KERNELS)
-out = {"kernel": KERNEL, "command": "python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary", "units": "bytes per launch"}
+out = {"commit": os.environ.get("GPMI_COMMIT", "unknown"), "kernel": KERNEL, "command": "python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary", "units": "bytes per launch"}
 for counter, folder in (("FETCH_SIZE", "FETCH_SIZE"), ("WRITE_SIZE", "WRITE_SIZE"), ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES"),
                         ("SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES"), ("GRBM_GUI_ACTIVE", "GRBM_GUI_ACTIVE")):
     vals = {}
