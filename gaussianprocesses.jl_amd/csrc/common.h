@@ -154,6 +154,8 @@ struct gpmi_ctx {
     int gemm_reserve = 0;
     bool update_full_grid = true;   // dense look-ahead: the 256 x 128 update is launched with a workgroup for EVERY compute unit; the ones whose unit the chain
                                      // holds start when the chain's workgroup there exits and pull what is left of their XCD's queue (GPMI_UPDATE_FULL_GRID=0: off)
+    int update256_kend = 0;              // GPMI_UPDATE256_KEND=1: tall panel solves X LW' (GEMM_KEND_COL) in 256 x 128 tiles too (update256_kernel's KEND instantiation).
+                                         // Built, parity-green (tests/test_gpu_twolevel.py) and measured NEUTRAL: N = 50 000 667.3 / 667.3 ms, C2 59.3 / 59.5 (profiles/r06_g_*): off
     bool kend_heavy_first = true;    // GEMM_KEND_COL launches hand their long tiles out first (GPMI_KEND_HEAVY_FIRST=0: columns in ascending order, rounds 1-5)
     bool update_late_wgs = false;    // set around that launch (chol.h main_update_beside_chain)
     int update256 = 1;                   // big trailing updates in 256 x 128 tiles, one 512-thread workgroup per CU (update256.hip;

@@ -537,7 +537,8 @@ void launch_gemm_shape(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda
     const bool trailing = shape.mode && !flags && !narrow;
     // FITC's tall products (n x m matrices, n ~ 1e6) in 256 x 128 tiles as well: rectangular or overwriting or split-K batched
     // (update256.hip decides: plain or GEMM_OVERWRITE launches only, M >= update256_rect_min_m for rectangles)
-    const bool tall = !trailing && !narrow && !(flags & ~(GEMM_OVERWRITE | GEMM_AUX)) && (shape.mode == 0 || shape.mode == 1) &&
+    // ... and the tall panel solves X LW' (GEMM_OVERWRITE | GEMM_KEND_COL: the K loop of a column tile ends at its last column), round 6
+    const bool tall = !trailing && !narrow && !(flags & ~(GEMM_OVERWRITE | GEMM_AUX | GEMM_KEND_COL)) && (shape.mode == 0 || shape.mode == 1) &&
                       (batch || M >= ctx->update256_rect_min_m);
     // the trailing update with a long K: phase-lock the tiles of an XCD (operand panels of 128 x K exceed the 4 MB L2 16 at a time)
     if (trailing && K >= ctx->phase_lock_min_k && ctx->phase_lock_min_k > 0) flags |= GEMM_PHASE_LOCK;
@@ -551,7 +552,7 @@ void launch_gemm_shape(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda
         // the big updates of the dense path go in 256 x 128 tiles (update256.hip); everything else in 128 x 128 / 128 x 64
         if (!batch && !flags && launch_update256<T>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, 0, nullptr)) return;
         launch_persistent<T, 0>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags, batch, false);
-    } else if (tall && launch_update256<T>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags & GEMM_OVERWRITE, batch)) {
+    } else if (tall && launch_update256<T>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags & (GEMM_OVERWRITE | GEMM_KEND_COL), batch)) {
         return;
     } else
         launch_persistent<T, 64>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags, batch, narrow);

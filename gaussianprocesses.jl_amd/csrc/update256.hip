@@ -83,7 +83,10 @@ __device__ __forceinline__ void slab_wait(Vec (&a)[4], Vec (&b)[4]) {  // own DM
 // no-return global_atomic_add (the L2 does the read-modify-write; exactly one add per element, so the result is bit-identical and
 // deterministic): no load latency left in the epilogue (LABBOOK 3.2b: the epilogue was 2.4 % of the kernel at K = 2048, 5.5 % at
 // K = 1024 — four dependent load batches per tile, not bytes).
-template <typename T, int ABL, bool OVW, bool ATOM = false>
+// KEND (with OVW; rectangles): B is lower-triangular-by-rows (B[j][k] = 0 for k > j — an explicit triangular inverse: the panel solve
+// X LW' of chol.h rows_below_super), so a tile's K loop ends at its last column (gemm.hip GEMM_KEND_COL).  Its own instantiation: the
+// trailing update's code is not touched by it.
+template <typename T, int ABL, bool OVW, bool ATOM = false, bool KEND = false>
 __global__ __launch_bounds__(512, 2) void update256_kernel(T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int64_t lda,
                                                            const T* __restrict__ B, int64_t ldb, int64_t M, int64_t N, int64_t K,
                                                            TileShape shape, unsigned long long* __restrict__ queue, QueueArgs qa,
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(512, 2) void update256_kernel(T* __restrict__ C, in
     const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform
     const int wm = wvu >> 1, wn = wvu & 1;
     const int r16 = lane & 15, g = lane >> 4;
-    const int nk = (int)(K / BK);
+    const int nk_full = (int)(K / BK);
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
     // fragment rows: byte offset of (row r16, logical chunk g) of this wave's first A block; k-half 1 is chunk g + 4 = the
     // same address with bit 6 flipped (rows are 128 bytes); B rows lie a wave-uniform distance further on
@@ -209,6 +212,8 @@ __global__ __launch_bounds__(512, 2) void update256_kernel(T* __restrict__ C, in
         const char* const Ab = cur_t.Ab;
         const char* const Bb = cur_t.Bb;
         const int mrem = cur_t.mrem, nrem = cur_t.nrem;
+        // (KEND: at least U_BN / BK = 8 (fp64) / 4 (fp32) slabs — the two the prologue stages are always inside the loop)
+        const int nk = KEND ? (int)((cur_t.n0 + U_BN < K ? cur_t.n0 + U_BN : K) / BK) : nk_full;
         Acc acc[4][4];
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
@@ -407,13 +412,13 @@ __global__ __launch_bounds__(512, 2) void update256_kernel(T* __restrict__ C, in
     }
 }
 
-template <typename T, int ABL, bool OVW, bool ATOM>
+template <typename T, int ABL, bool OVW, bool ATOM, bool KEND = false>
 bool prepare(gpmi_ctx* ctx) {
     // 144 KiB of dynamic LDS need the attribute once per device and instantiation
     static bool done[64] = {false};
     const int dev = ctx->device & 63;
     if (done[dev]) return true;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&update256_kernel<T, ABL, OVW, ATOM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&update256_kernel<T, ABL, OVW, ATOM, KEND>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             U_NBUF * (U_BM + U_BN) * 128) != hipSuccess) {
         (void)hipGetLastError();
         return false;
@@ -435,7 +440,9 @@ static bool update256_plan(const gpmi_ctx* ctx, const T* C, int64_t ldc, const T
                            int64_t K, TileShape shape, TileShape* out, int64_t* ntiles_out, int flags = 0, const GemmBatch* batch = nullptr) {
     constexpr int BK = Mfma<T>::BK;
     if (!ctx->update256 || (shape.mode != 1 && shape.mode != 0) || (shape.g0 & 1) || ctx->beside_update) return false;
-    if (flags & ~GEMM_OVERWRITE) return false;  // (K-loop bounds per tile, negated output: the 128 x 128 kernel's)
+    // (K-loop start per tile, negated output: the 128 x 128 kernel's; the K-loop END per column tile only for overwriting rectangles)
+    if (flags & ~(GEMM_OVERWRITE | GEMM_KEND_COL)) return false;
+    if ((flags & GEMM_KEND_COL) && (!(flags & GEMM_OVERWRITE) || shape.mode != 0 || batch || !ctx->update256_kend)) return false;
     // rectangles: the tall products only (FITC's n x m matrices; predict_f's P x N updates stay on the 128 x 128 kernel, whose tile
     // count fills the chip in more even rounds at M = 1024)
     if (shape.mode == 0 && M < ctx->update256_rect_min_m) return false;
@@ -468,13 +475,13 @@ static bool update256_plan(const gpmi_ctx* ctx, const T* C, int64_t ldc, const T
     return true;
 }
 
-template <typename T, int ABL, bool OVW = false, bool ATOM = false>
+template <typename T, int ABL, bool OVW = false, bool ATOM = false, bool KEND = false>
 static bool launch_update256_abl(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
                                  TileShape shape, const int* info, int flags = 0, const GemmBatch* batch = nullptr) {
     TileShape s;
     int64_t tiles_per;
     if (!update256_plan<T>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, &s, &tiles_per, flags, batch)) return false;
-    if (!prepare<T, ABL, OVW, ATOM>(ctx)) return false;
+    if (!prepare<T, ABL, OVW, ATOM, KEND>(ctx)) return false;
     const int64_t ntiles = tiles_per * (batch ? batch->count : 1);
     // one workgroup per CU; the look-ahead's free slots (two per CU in the 128 x 128 kernel's terms) become whole free CUs
     // Beside a chain launch that is already resident (chol.h: chain_wait_kernel went first) the grid still covers EVERY compute unit: the
@@ -499,17 +506,18 @@ static bool launch_update256_abl(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, i
     if (ctx->attach_a) {  // profiled launch: the dispatch carries its own start / stop events (ProfScope attach mode)
         hipEvent_t ea = ctx->attach_a, eb = ctx->attach_b;
         ctx->attach_a = ctx->attach_b = nullptr;
-        hipExtLaunchKernelGGL((update256_kernel<T, ABL, OVW, ATOM>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, ea, eb, 0, C, ldc, A, lda, B, ldb, M, N, K, s,
+        hipExtLaunchKernelGGL((update256_kernel<T, ABL, OVW, ATOM, KEND>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, ea, eb, 0, C, ldc, A, lda, B, ldb, M, N, K, s,
                               ctx->d_queue, qa, info);
         return true;
     }
-    hipLaunchKernelGGL((update256_kernel<T, ABL, OVW, ATOM>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, C, ldc, A, lda, B, ldb, M, N, K, s, ctx->d_queue,
+    hipLaunchKernelGGL((update256_kernel<T, ABL, OVW, ATOM, KEND>), dim3((unsigned)grid), dim3(512), lds, ctx->stream, C, ldc, A, lda, B, ldb, M, N, K, s, ctx->d_queue,
                        qa, info);
     return true;
 }
 template <typename T>
 bool launch_update256(gpmi_ctx* ctx, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
                       TileShape shape, const int* info, int flags, const GemmBatch* batch) {
+    if (flags & GEMM_KEND_COL) return launch_update256_abl<T, 0, true, false, true>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags, batch);
     if (flags & GEMM_OVERWRITE) return launch_update256_abl<T, 0, true>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags, batch);
     if (batch) return launch_update256_abl<T, 0, false>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags, batch);
     if (ctx->update256_atomic) return launch_update256_abl<T, 0, false, true>(ctx, C, ldc, A, lda, B, ldb, M, N, K, shape, info, flags, batch);

@@ -161,6 +161,45 @@ def test_update_in_256x128_tiles_small(monkeypatch, n, dtype, cumask):
     np.testing.assert_allclose(var, rvar, rtol=0, atol=(1e-8 if dtype == np.float64 else 2e-3))
 
 
+@pytest.mark.parametrize("n,dtype", [(4100, np.float64), (6000, np.float64), (5000, np.float32)])
+def test_panel_solves_in_256x128_tiles(monkeypatch, n, dtype):
+    """Round 6: the panel solve X LW' (GEMM_OVERWRITE | GEMM_KEND_COL: a column tile's K loop ends at its last column — LW is the explicit
+    lower-triangular inverse of the diagonal super-block, chol.h rows_below_super) in 256 x 128 tiles (update256_kernel<T, 0, true, false,
+    true>).  By default only tall solves (>= 8192 rows, >= 1024 tiles) take it; GPMI_UPDATE256_RECT=1 / _MIN=1 send EVERY solve through an
+    inverse — and predict_f's V = R LW' with its 64 test rows — through it: edge tiles in both directions, the carried row, K loops of
+    8 ... 64 slabs.  Against the oracle, and against the same fit with GPMI_UPDATE256_KEND=0 (the 128 x 128 kernel of rounds 1-5)."""
+    monkeypatch.setenv("GPMI_UPDATE256_MIN", "1")
+    monkeypatch.setenv("GPMI_UPDATE256_RECT", "1")
+    monkeypatch.setenv("GPMI_CUMASK", "0")
+    monkeypatch.setenv("GPMI_SUPER", "1024,2048,100000")
+    d = 5
+    x, y, xs = G.synthetic_inputs(n, d, p=64)
+    spec = ("se_ard", [math.log(0.6)] * d, 0.0)
+    out = {}
+    for kend in ("1", "0"):
+        monkeypatch.setenv("GPMI_UPDATE256_KEND", kend)
+        ctx = g.Context(0)
+        gp = g.GP(x.astype(dtype), y, g.MeanZero(), g.from_spec(spec), math.log(0.1), dtype=dtype, ctx=ctx)
+        mu, var = gp.predict_f(xs.astype(dtype))
+        out[kend] = (gp.mll, np.array(gp.alpha, dtype=np.float64), np.array(mu, dtype=np.float64), np.array(var, dtype=np.float64),
+                     np.array(gp.cK.factor_diag(), dtype=np.float64))
+        del gp
+        ctx.close()
+    ref = G.update_mll(spec, x, y, math.log(0.1))
+    rmu, rvar = G.predict_f(spec, x, ref, xs)
+    f64 = dtype == np.float64
+    mll, alpha, mu, var, dg = out["1"]
+    assert abs(mll - ref["mll"]) <= (1e-9 if f64 else 2e-3) * abs(ref["mll"]), (mll, ref["mll"])
+    np.testing.assert_allclose(alpha, ref["alpha"], rtol=0, atol=(1e-7 if f64 else 5e-2) * np.abs(ref["alpha"]).max())
+    np.testing.assert_allclose(mu, rmu, rtol=0, atol=(1e-8 if f64 else 2e-3) * np.abs(rmu).max())
+    np.testing.assert_allclose(var, rvar, rtol=0, atol=(1e-8 if f64 else 2e-3))
+    # the two kernels accumulate a tile's K loop in the same slab order: rounding-level agreement of everything downstream
+    tol = 1e-11 if f64 else 1e-4
+    assert abs(mll - out["0"][0]) <= tol * abs(mll)
+    np.testing.assert_allclose(dg, out["0"][4], rtol=tol)
+    np.testing.assert_allclose(mu, out["0"][2], rtol=0, atol=tol * 10 * np.abs(rmu).max())
+
+
 def test_update_in_256x128_tiles_atomic_epilogue(monkeypatch):
     """GPMI_UPDATE256_ATOMIC=1: the C tile of a subtracting launch leaves as no-return global_atomic_add (one add per element: the same
     numbers as load / add / store).  Same factorisation with and without: mll, alpha and the factor's diagonal agree to rounding."""

@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_prediction_is_reproducible_and_sane():
-    committed = json.load(open(os.path.join(ROOT, "profiles", "r05_scale_model.json")))
+    newest = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_scale_model.json"))[-1]   # r06_scale_model.json
+    committed = json.load(open(os.path.join(ROOT, "profiles", newest)))
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "m.json")
         subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "scale_model.py"), "--chain-ms", str(committed["inputs"]["chain_ms_per_1024_block"]), "--out", out],
