@@ -46,6 +46,11 @@ if __name__ == "__main__":
                 {"GPMI_LOOKAHEAD_MIN": 2048}, {"GPMI_LOOKAHEAD_MIN": 1536, "GPMI_SUPER": "2048,6144,24576"},
                 {"GPMI_TAIL_FUSE": 1024}, {"GPMI_TAIL_FUSE": 1536}, {"GPMI_UPDATE256_MIN": 512}, {"GPMI_UPDATE256_MIN": 256, "GPMI_CUMASK_BELOW": 0}]
         for e in cfgs: run(n, e)
+    elif mode == "r6":  # round 6: the thresholds again, with potf2_wg and the update's full grid (profiles/r06_i_*)
+        for e in ({}, {"GPMI_SUPER": "2048,6144,16384"}, {"GPMI_SUPER": "2048,6144,11264"}, {"GPMI_SUPER": "2048,6144,9216"}, {"GPMI_SUPER": "2048,4096,13312"},
+                  {"GPMI_SUPER": "2048,8192,13312"}, {"GPMI_SUPER": "1024,6144,13312"}, {"GPMI_SUPER": "3072,6144,13312"}, {"GPMI_SUPER": "2048,4096,9216"},
+                  {"GPMI_CUMASK_BELOW": 0}, {"GPMI_CUMASK_BELOW": 16384}, {"GPMI_CUMASK_BELOW": 24576}, {"GPMI_TAIL_FUSE": 1024}, {"GPMI_TAIL_FUSE": 1536}, {}):
+            run(n, e)
     elif mode == "fine":
         for sup in ("2048,6144,16384", "2048,6144,12288", "2048,4096,12288", "1024,4096,12288", "2048,5120,10240", "1536,4096,8192"):
             for below in (32768, 0):
