@@ -884,7 +884,7 @@ def main():
         emit()
         persist("")
         with lock:
-            par = out.get("parity")
+            par = out.get("parity") if isinstance(out, dict) else None  # (`out` exists on rank 0 only)
         if rank == 0 and isinstance(par, dict) and par.get("checked") and not par.get("ok"):
             sys.stderr.write("bench.py: PARITY FAILED (sharded fit, solve residual on oracle-rebuilt rows): " + json.dumps(par) + "\n")
             exit_code = 3

@@ -313,6 +313,28 @@ def test_two_processes_on_one_gpu_gloo_device_buffers():
         assert rc == 0 and f"two-proc rank {r} ok" in o, (o[-1500:], e[-3000:])
 
 
+def test_bench_multi_gpu_line_rehearsed_on_one_gpu(tmp_path):
+    """The driver's multi-GPU tier runs `bench.py --gpus N` once, at the end of the round, on hardware no round has had: the whole world > 1
+    branch of bench.py (torchrun launch, sharded fit, max-over-ranks timing, the ONE line with `parity`, `per_step_ms` and `c4_sharded`,
+    the primary line persisted before the secondary objects, every rank leaving with exit code 0) is rehearsed here on one GPU
+    (--dry-run-one-gpu: two processes on the two CU partitions, gloo through the host).  Round 6 rewrote that branch and the first
+    rehearsal crashed rank 1 (`out` exists on rank 0 only) after the line was out — torchrun then reports failure for the whole job."""
+    import json
+
+    env = dict(os.environ)
+    env["GPMI_BENCH_SECONDARY_S"] = "600"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-one-gpu", "--n", "8192", "--c4-n", "12288", "--steps", "1",
+                          "--warmup", "1", "--secondary", "c4"], cwd=ROOT, capture_output=True, text=True, timeout=1200, env=env)
+    lines = [ln_ for ln_ in out.stdout.splitlines() if ln_.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.returncode, out.stdout[-1500:], out.stderr[-3000:])
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["scaling"] == "strong"
+    assert j["parity"]["checked"] and j["parity"]["ok"], j["parity"]
+    assert j["per_step_ms"] and j["c4_sharded"]["parity"]["ok"], j.get("c4_sharded")
+    for f in ("bench_gpus2_primary.json", "bench_gpus2.json"):
+        assert os.path.exists(os.path.join(ROOT, "gpurun_out", f)), f
+
+
 def test_rccl_native_communicator_in_a_group_of_one():
     """libgpmi's own RCCL communicator (librccl opened at run time, ncclCommInitRank / Broadcast / AllGather / AllReduce) with one
     rank: gpmi_comm_selftest, then a blocked fit with it (the collectives are skipped at world 1, the handle plumbing is not)."""
