@@ -774,6 +774,7 @@ static int create_one_context(int dev_code, gpmi_ctx** out) {
     //             GPMI_CHAIN_WGS=g  workgroups of every chain launch (test hook: 1 = a serial walk of the task list)
     if (const char* e = getenv("GPMI_CHAIN")) c->chain_kernel = atoi(e) != 0;
     if (const char* e = getenv("GPMI_CHAIN_WGS")) c->chain_wgs = std::max(0, atoi(e));
+    if (const char* e = getenv("GPMI_CHAIN_BESIDE_WGS")) c->chain_beside_wgs = std::max(8, atoi(e) / 8 * 8);
     //             GPMI_TAIL_FUSE=rows  the last `rows` rows (<= 2048) of a factorisation as ONE diagonal block (0 = off)
     //             GPMI_CUMASK_BELOW=rows  factorisations of fewer rows reserve whole compute units for the chain (default 32768)
     if (const char* e = getenv("GPMI_TAIL_FUSE")) c->tail_fuse = std::min<long long>(std::max<long long>(0, atoll(e)) / IB * IB, (long long)c->chain_nb_max * IB);

@@ -581,6 +581,7 @@ bool launch_chain_block(gpmi_ctx* ctx, T* A, int64_t ld, int64_t w, T* linv, T* 
     // workgroups: what fits beside the trailing update (chol.h beside_update: the reserved compute units / free slots), otherwise enough
     // for the tasks of one step (nb) with one workgroup per compute unit
     int64_t g = ctx->beside_update ? side_slots(ctx) : std::max<int64_t>(8, std::min<int64_t>(2 * nb, ctx->chain_wgs_max));
+    if (ctx->beside_update && ctx->side_one_per_xcd && ctx->chain_wide_ok) g = std::max<int64_t>(g, ctx->chain_beside_wgs);
     if (ctx->chain_wgs > 0) g = ctx->chain_wgs;
     if (g < 1) g = 1;
     const double flops = (LW ? 2.0 : 1.0) * (double)w * (double)w * (double)w / 3.0;

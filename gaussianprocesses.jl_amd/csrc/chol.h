@@ -403,11 +403,13 @@ inline int cholesky_lower(gpmi_ctx* c, T* A, int64_t ld, T* linv, T* invdiag, in
             {
                 StreamScope sc(c, side, c->num_cus);  // the block's factorisation and its inverse: small launches
                 c->beside_update = true;  // no launch larger than the reserved slots, no whole-CU kernels (common.h side_cap)
+                c->chain_wide_ok = !masked && c->update_full_grid;
                 if (tiles_on_side)
                     launch_gemm_shape<T>(c, A + ke * ld + ke, ld, A + ke * ld + ks, ld, A + ke * ld + ks, ld, w2, w2, K,
                                          TileShape{0, 0, 1, 0, 1, 0}, d_info, GEMM_AUX);
                 factor_and_invert_block<T>(c, A, ld, linv, invdiag, ke, w2, LW2, wld2, d_info);
                 c->beside_update = false;
+                c->chain_wide_ok = false;
             }
             c->side_one_per_xcd = false;
             hipEvent_t ec = la_event(c);

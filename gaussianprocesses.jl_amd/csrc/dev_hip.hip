@@ -183,6 +183,7 @@ struct HipDev : Dev {
     void use(DevStream s) override {
         c->beside_update = false;
         c->side_one_per_xcd = false;
+        c->chain_wide_ok = false;
         c->gemm_reserve = 0;
         c->update_late_wgs = false;
         c->num_cus = full_cus();
@@ -207,6 +208,7 @@ struct HipDev : Dev {
                 // per XCD): no chain launch of more than one workgroup per XCD (chol.h / common.h side_slots).  The driver only stays in
                 // this mode while the update is long enough for that kernel (blocked.cpp kWholeCusBelow).
                 c->side_one_per_xcd = !masked() && c->update256 != 0 && c->beside_update;
+                c->chain_wide_ok = solo && c->update_full_grid && c->side_one_per_xcd;
                 break;
             // the exchange: the main stream is idle while a factorisation runs on UPD / SIDE, so with whole CUs reserved the
             // collectives go there (their kernels find the reserved CUs free); with free slots they follow the chain
