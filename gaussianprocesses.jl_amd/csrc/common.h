@@ -171,8 +171,9 @@ struct gpmi_ctx {
     int chain_nb_max = 32;               // blocks of up to 32 x 64 = 2048 columns
     int chain_wgs_max = 64;              // workgroups of a chain launch that has the device to itself (the first block, serial tails)
     int chain_wgs = 0;                   // > 0: the number of workgroups of EVERY chain launch (GPMI_CHAIN_WGS: test hook)
-    int chain_beside_wgs = 8;            // workgroups of a chain launch beside a FULL-GRID update (update_full_grid: the chain is placed before the update starts, so
-                                         // more than one per XCD is no dispatcher lottery any more; its units go back to the update when it exits).  GPMI_CHAIN_BESIDE_WGS
+    int chain_beside_wgs = 16;           // workgroups of a chain launch beside a FULL-GRID update (update_full_grid: the chain is placed before the update starts, so
+                                         // more than one per XCD is no dispatcher lottery any more; its units go back to the update when it exits).  GPMI_CHAIN_BESIDE_WGS;
+                                         // 8 / 16 / 32: a 1024 block 0.82 / 0.60 / 0.52 ms by events beside the update, C2 59.8 / 59.5 / 59.8 ms, N = 50 000 flat (profiles/r06_m_*)
     bool chain_wide_ok = false;          // set around such a chain launch (chol.h dense path; dev_hip.hip one-rank blocked path)
     unsigned chain_started_expect = 0;   // workgroups of all chain launches so far (what the never-reset `started` word counts up to)
     bool chain_wait_pending = false;     // the next trailing update on an unmasked stream first waits for the last chain launch's workgroups to be placed
