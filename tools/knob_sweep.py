@@ -51,6 +51,10 @@ if __name__ == "__main__":
                   {"GPMI_SUPER": "2048,8192,13312"}, {"GPMI_SUPER": "1024,6144,13312"}, {"GPMI_SUPER": "3072,6144,13312"}, {"GPMI_SUPER": "2048,4096,9216"},
                   {"GPMI_CUMASK_BELOW": 0}, {"GPMI_CUMASK_BELOW": 16384}, {"GPMI_CUMASK_BELOW": 24576}, {"GPMI_TAIL_FUSE": 1024}, {"GPMI_TAIL_FUSE": 1536}, {}):
             run(n, e)
+    elif mode == "la":  # round 6, after the chain got sixteen workgroups beside the update: where the look-ahead stops paying (profiles/r06_n_*)
+        for e in ({}, {"GPMI_LOOKAHEAD_MIN": 2560}, {"GPMI_LOOKAHEAD_MIN": 3072}, {"GPMI_LOOKAHEAD_MIN": 3584}, {"GPMI_LOOKAHEAD_MIN": 4096}, {"GPMI_LOOKAHEAD_MIN": 5632},
+                  {"GPMI_LOOKAHEAD_MIN": 3072, "GPMI_SUPER": "2048,4096,13312"}, {"GPMI_SUPER": "2048,4096,13312"}, {}):
+            run(n, e)
     elif mode == "fine":
         for sup in ("2048,6144,16384", "2048,6144,12288", "2048,4096,12288", "1024,4096,12288", "2048,5120,10240", "1536,4096,8192"):
             for below in (32768, 0):
