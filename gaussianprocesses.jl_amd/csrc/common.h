@@ -136,7 +136,9 @@ struct gpmi_ctx {
     // {8192, 12288, 24576} in rounds 2-4 (profiles/r02_super_sweep.log); re-swept with the persistent chain kernel, whose blocks cost a
     // third of the multi-launch chain's: wider panels now pay at much smaller trailing sizes (N = 20 000: 66.0 -> 61.3 ms per fit + predict,
     // N = 50 000: 689.0 -> 683.9; profiles/r05_c_knob_sweeps_with_the_chain_kernel.log, r05_d_knob_sweeps_fine.log)
-    int64_t super_min[3] = {2048, 6144, 13312};
+    // round 6 (potf2_wg, sixteen chain workgroups beside a full-grid update): 1024-wide panels from 4096 rows (was 6144): N = 12 000 19.15 -> 18.95 ms,
+    // N = 20 000 58.75 -> 58.63, N = 50 000 flat; everything else of two 15-configuration sweeps within noise (profiles/r06_i_*, r06_n_*)
+    int64_t super_min[3] = {2048, 4096, 13312};
     // scratch of the two-level factorisation (grown on demand, chol.h): the explicit inverse of the current W x W diagonal
     // super-block (sup_lw, leading dimension sup_wld) and its transpose, the packed 256-inverses it is built from, an
     // (W/2)^2 product buffer, and the out-of-place image of the solved rows below (rows x W)
