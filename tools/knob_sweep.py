@@ -55,6 +55,9 @@ if __name__ == "__main__":
         for e in ({}, {"GPMI_LOOKAHEAD_MIN": 2560}, {"GPMI_LOOKAHEAD_MIN": 3072}, {"GPMI_LOOKAHEAD_MIN": 3584}, {"GPMI_LOOKAHEAD_MIN": 4096}, {"GPMI_LOOKAHEAD_MIN": 5632},
                   {"GPMI_LOOKAHEAD_MIN": 3072, "GPMI_SUPER": "2048,4096,13312"}, {"GPMI_SUPER": "2048,4096,13312"}, {}):
             run(n, e)
+    elif mode == "mask":  # round 6: below which size whole (CU-masked) compute units for the chain still beat the full-grid update with the chain placed first
+        for e in ({}, {"GPMI_CUMASK_BELOW": 0}, {"GPMI_CUMASK_BELOW": 8192}, {"GPMI_CUMASK_BELOW": 12288}, {}, {"GPMI_CUMASK_BELOW": 0}):
+            run(n, e)
     elif mode == "fine":
         for sup in ("2048,6144,16384", "2048,6144,12288", "2048,4096,12288", "1024,4096,12288", "2048,5120,10240", "1536,4096,8192"):
             for below in (32768, 0):
