@@ -26,7 +26,16 @@
 namespace gpmi {
 
 static const double LOG2PI = 1.8378770664093453;
-static const int64_t kWholeCusBelow = 20480;  // rows left below which a step reserves whole CUs for the chain (common.h whole_cus_below)
+// rows left below which a step of a ONE-rank factorisation reserves whole CUs for the chain (common.h whole_cus_below; with more ranks every
+// step does).  GPMI_BLOCKED_WHOLE_BELOW: test / sweep hook, read once.
+static int64_t whole_cus_below_rows() {
+    static const int64_t v = [] {
+        const char* e = getenv("GPMI_BLOCKED_WHOLE_BELOW");
+        return e ? (int64_t)atoll(e) : (int64_t)20480;
+    }();
+    return v;
+}
+#define kWholeCusBelow whole_cus_below_rows()
 
 // 1024-row blocks once the K = 1024 update outlasts a 1024-block chain for most of the factorisation; narrower blocks keep the
 // chain (and the exposed tail) short below that

@@ -123,10 +123,12 @@ struct gpmi_ctx {
     int reserved_cus = 0;
     int la_mode = -1;                // -1 none yet, 0 free slots (side_stream), 1 whole CUs (side_masked + upd_stream)
     bool mask_ok = false;            // CU-masked streams are available (256 CUs, GPMI_CUMASK != 0, creation has not failed)
-    int64_t whole_cus_below = 18432; // factorisations of fewer rows reserve whole CUs for the chain (the blocked path decides per
+    int64_t whole_cus_below = 12288; // factorisations of fewer rows reserve whole CUs for the chain (the blocked path decides per
                                      // step: its fixed-width blocks leave a long chain-bound tail, blocked.cpp).  32768 while the chain was a
                                      // string of launches; with the persistent chain kernel free slots win from ~20 000 rows on
-                                     // (N = 28 000: 140.2 against 144.0 ms; N = 12 288: 21.6 against 21.1; profiles/r05_d_knob_sweeps_fine.log)
+                                     // (N = 28 000: 140.2 against 144.0 ms; N = 12 288: 21.6 against 21.1; profiles/r05_d_knob_sweeps_fine.log); 18432 in round 5.
+                                     // Round 6 (the update's grid covers every CU and the chain, placed first, takes 16 workgroups): free slots win from
+                                     // ~13 000 rows on — N = 18 000 46.5 -> 45.2 ms, N = 16 000 35.4 -> 34.5, N = 12 000 18.67 against 18.77 (profiles/r06_o_*)
     int64_t lookahead_min_tiles_masked = 288;  // = a 3072-row trailing matrix at K = 256: the fast chain hides under shorter updates
     int lookahead_slots = 0;
     int64_t lookahead_min_tiles = 650;   // update length (in 128 x 128 x 256 tile products) below which the serial order is
