@@ -27,11 +27,13 @@ namespace gpmi {
 
 static const double LOG2PI = 1.8378770664093453;
 // rows left below which a step of a ONE-rank factorisation reserves whole CUs for the chain (common.h whole_cus_below; with more ranks every
-// step does).  GPMI_BLOCKED_WHOLE_BELOW: test / sweep hook, read once.
+// step does).  20480 in rounds 3-5; since the one-rank update's grid covers every compute unit and the chain is placed first (round 6) free
+// slots win at every size: 20480 / 12288 / 0 -> N = 50 000 709 / 708 / 703 ms, N = 20 000 69.8 / 68.8 / 69.0 (profiles/r06_p_*).
+// GPMI_BLOCKED_WHOLE_BELOW: test / sweep hook, read once.
 static int64_t whole_cus_below_rows() {
     static const int64_t v = [] {
         const char* e = getenv("GPMI_BLOCKED_WHOLE_BELOW");
-        return e ? (int64_t)atoll(e) : (int64_t)20480;
+        return e ? (int64_t)atoll(e) : (int64_t)0;
     }();
     return v;
 }
