@@ -25,7 +25,10 @@
 
 namespace gpmi {
 
-constexpr int TILE_GROUP = 8;
+#ifndef GPMI_TILE_GROUP
+#define GPMI_TILE_GROUP 8  // tile-rows per strip (tools/build_variant.sh -DGPMI_TILE_GROUP=n builds an A/B library; 4 / 8 / 16 measured in round 6: profiles/r06_r_*)
+#endif
+constexpr int TILE_GROUP = GPMI_TILE_GROUP;
 
 struct TileShape {
     int ntm, ntn, mode;
