@@ -7,7 +7,7 @@ import numpy as np
 import gpmi355x as g
 from gpmi355x import dist as gd
 
-KNOBS = ("GPMI_SUPER", "GPMI_CUMASK_BELOW", "GPMI_LOOKAHEAD_MIN", "GPMI_TAIL_FUSE", "GPMI_CHAIN", "GPMI_CHAIN_WGS", "GPMI_UPDATE256_MIN")
+KNOBS = ("GPMI_SUPER", "GPMI_CUMASK_BELOW", "GPMI_LOOKAHEAD_MIN", "GPMI_TAIL_FUSE", "GPMI_CHAIN", "GPMI_CHAIN_WGS", "GPMI_UPDATE256_MIN", "GPMI_LOOKAHEAD", "GPMI_CHAIN_BESIDE_WGS")
 
 def synth(n, d, p, seed=20240501):
     rng = np.random.default_rng(seed)
@@ -57,6 +57,10 @@ if __name__ == "__main__":
             run(n, e)
     elif mode == "mask":  # round 6: below which size whole (CU-masked) compute units for the chain still beat the full-grid update with the chain placed first
         for e in ({}, {"GPMI_CUMASK_BELOW": 0}, {"GPMI_CUMASK_BELOW": 8192}, {"GPMI_CUMASK_BELOW": 12288}, {}, {"GPMI_CUMASK_BELOW": 0}):
+            run(n, e)
+    elif mode == "misc":  # round 6: free slots beside the 128 x 128 updates, the 256 x 128 kernel's minimum launch, chain workgroups beside it
+        for e in ({}, {"GPMI_LOOKAHEAD": 8}, {"GPMI_LOOKAHEAD": 24}, {"GPMI_LOOKAHEAD": 32}, {"GPMI_UPDATE256_MIN": 768}, {"GPMI_UPDATE256_MIN": 512}, {"GPMI_UPDATE256_MIN": 1536},
+                  {"GPMI_CHAIN_BESIDE_WGS": 24}, {}):
             run(n, e)
     elif mode == "fine":
         for sup in ("2048,6144,16384", "2048,6144,12288", "2048,4096,12288", "1024,4096,12288", "2048,5120,10240", "1536,4096,8192"):
