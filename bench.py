@@ -267,11 +267,11 @@ def run_workload(g, ctx, n, d, p, dtype, steps, warmup, barrier, comm=None, shar
     # events (attached to the dispatch: hipExtLaunchKernelGGL start / stop events).  Marker events around EVERY other profiled launch —
     # thousands per fit for the chain kernels — cost 4 ms of a 69 ms step at N = 20 000, so the stage times are taken over the warm-up
     # steps and the timed steps bracket the roofline kernel only.  One measured exception: in the free-slot look-ahead mode (factorisations
-    # of >= 18 432 rows since round 5; N = 20 000 bracketed on the update alone: 81.6 ms per step against 61 – 62 un-instrumented) events on
+    # of >= 12 288 rows since round 6, 18 432 in round 5; N = 20 000 bracketed on the update alone: 81.6 ms per step against 61 – 62 un-instrumented) events on
     # the update alone cost MORE than events everywhere (N = 50 000 fit: none 652, everywhere 657, update
     # only 665 ms — the markers on the side stream's chain kernels evidently help the chain along once the update's dispatch carries a
     # completion signal), so those workloads keep every class bracketed, as in rounds 1 and 2.
-    syrk_only = (not sharded) and n < 18432
+    syrk_only = (not sharded) and n < 12288
     how = os.environ.get("GPMI_BENCH_PROFILE", "")   # measurement study: "none" = no event in the timed region (no roofline then), "all", "syrk"
     if how in ("all", "syrk"):
         syrk_only = how == "syrk"
@@ -349,7 +349,7 @@ def roofline_object(args, res, n, d, p, dtype, steps, ctx=None):
     return {
         **extra,
         "kernel": "Cholesky trailing update, K = super-panel width, v_mfma_f64_16x16x4: update256_kernel<T> (256x128 tiles: launches of >= 1024 tiles "
-                  "in factorisations of >= 18432 rows) + gemm_nt_kernel<T, 0, 4> (128x128 tiles, the others); all launches of the class are averaged",
+                  "in factorisations of >= 12288 rows) + gemm_nt_kernel<T, 0, 4> (128x128 tiles, the others); all launches of the class are averaged",
         "bound": "mfma",
         "achieved": achieved,
         "peak": peak,
