@@ -783,6 +783,7 @@ static int create_one_context(int dev_code, gpmi_ctx** out) {
     if (const char* e = getenv("GPMI_UPDATE_FULL_GRID")) c->update_full_grid = atoi(e) != 0;
     if (const char* e = getenv("GPMI_KEND_HEAVY_FIRST")) c->kend_heavy_first = atoi(e) != 0;
     if (const char* e = getenv("GPMI_UPDATE256_KEND")) c->update256_kend = atoi(e);
+    if (const char* e = getenv("GPMI_SUPER_W")) c->super_wide = atoll(e) / NB * NB;
     if (const char* e = getenv("GPMI_UPDATE256_MIN")) c->update256_min_tiles = std::max<long long>(1, atoll(e));
     if (const char* e = getenv("GPMI_UPDATE256_ATOMIC")) c->update256_atomic = atoi(e) != 0;
 

@@ -216,7 +216,11 @@ inline int64_t super_width(const gpmi_ctx* c, int64_t trailing) {
     if (c->tail_fuse > 0 && trailing <= c->tail_fuse && chain_takes(c, trailing)) return trailing;
     // widest first; widths are multiples of NB.  Below super_min[0] the factorisation is the plain NB = 256 one.
     for (int i = 2; i >= 0; --i)
-        if (c->super_min[i] > 0 && trailing >= c->super_min[i]) return (int64_t)NB << (i + 1);
+        if (c->super_min[i] > 0 && trailing >= c->super_min[i]) {
+            // (the widest class may be any multiple of NB the chain kernel takes: GPMI_SUPER_W, a sweep hook — 1536 / 1792 against 2048 in round 6)
+            if (i == 2 && c->super_wide > 0 && chain_takes(c, c->super_wide)) return c->super_wide;
+            return (int64_t)NB << (i + 1);
+        }
     return NB;
 }
 // the widest block a factorisation of npad rows will use (scratch / store sizing)

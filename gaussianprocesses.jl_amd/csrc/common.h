@@ -141,6 +141,7 @@ struct gpmi_ctx {
     // round 6 (potf2_wg, sixteen chain workgroups beside a full-grid update): 1024-wide panels from 4096 rows (was 6144): N = 12 000 19.15 -> 18.95 ms,
     // N = 20 000 58.75 -> 58.63, N = 50 000 flat; everything else of two 15-configuration sweeps within noise (profiles/r06_i_*, r06_n_*)
     int64_t super_min[3] = {2048, 4096, 13312};
+    int64_t super_wide = 0;              // > 0: the width of the widest super-panel class instead of 2048 (a multiple of 256 up to 2048; GPMI_SUPER_W: sweep hook)
     // scratch of the two-level factorisation (grown on demand, chol.h): the explicit inverse of the current W x W diagonal
     // super-block (sup_lw, leading dimension sup_wld) and its transpose, the packed 256-inverses it is built from, an
     // (W/2)^2 product buffer, and the out-of-place image of the solved rows below (rows x W)

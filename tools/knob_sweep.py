@@ -7,7 +7,7 @@ import numpy as np
 import gpmi355x as g
 from gpmi355x import dist as gd
 
-KNOBS = ("GPMI_SUPER", "GPMI_CUMASK_BELOW", "GPMI_LOOKAHEAD_MIN", "GPMI_TAIL_FUSE", "GPMI_CHAIN", "GPMI_CHAIN_WGS", "GPMI_UPDATE256_MIN", "GPMI_LOOKAHEAD", "GPMI_CHAIN_BESIDE_WGS")
+KNOBS = ("GPMI_SUPER", "GPMI_CUMASK_BELOW", "GPMI_LOOKAHEAD_MIN", "GPMI_TAIL_FUSE", "GPMI_CHAIN", "GPMI_CHAIN_WGS", "GPMI_UPDATE256_MIN", "GPMI_LOOKAHEAD", "GPMI_CHAIN_BESIDE_WGS", "GPMI_SUPER_W")
 
 def synth(n, d, p, seed=20240501):
     rng = np.random.default_rng(seed)
@@ -61,6 +61,9 @@ if __name__ == "__main__":
     elif mode == "misc":  # round 6: free slots beside the 128 x 128 updates, the 256 x 128 kernel's minimum launch, chain workgroups beside it
         for e in ({}, {"GPMI_LOOKAHEAD": 8}, {"GPMI_LOOKAHEAD": 24}, {"GPMI_LOOKAHEAD": 32}, {"GPMI_UPDATE256_MIN": 768}, {"GPMI_UPDATE256_MIN": 512}, {"GPMI_UPDATE256_MIN": 1536},
                   {"GPMI_CHAIN_BESIDE_WGS": 24}, {}):
+            run(n, e)
+    elif mode == "wide":  # round 6: the widest super-panel class at 1536 / 1792 columns instead of 2048 (panel solves ~ W, the update's C passes ~ 1 / W)
+        for e in ({}, {"GPMI_SUPER_W": 1536}, {"GPMI_SUPER_W": 1792}, {"GPMI_SUPER_W": 1280}, {}, {"GPMI_SUPER_W": 1536}):
             run(n, e)
     elif mode == "fine":
         for sup in ("2048,6144,16384", "2048,6144,12288", "2048,4096,12288", "1024,4096,12288", "2048,5120,10240", "1536,4096,8192"):
